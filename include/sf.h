@@ -1,0 +1,219 @@
+/*
+ * sf.h — C ABI of the StaticFusion coupled odometry + static/dynamic segmentation solver.
+ *
+ * This is the drop-in boundary for the ONE hot path of raluca-scona/staticfusion that this
+ * repository rebuilds for MI355X (gfx950): the public surface of `class StaticFusion`
+ * (reference StaticFusion.h:66-189) as exercised by the three drivers
+ * (reference StaticFusion-datasets.cpp:79-94,148-199).  The reference has no FFI layer; its
+ * "operator API" is: write public members, call four methods, read public members.  Each entry
+ * point below names the reference member / method it replaces.
+ *
+ * Conventions (identical to the reference, Eigen::MatrixXf):
+ *   - every image is column-major float32, element (v,u) at  v + u*rows,  rows x cols
+ *   - depth in metres, 0 = invalid; intensity in [0,1]
+ *   - labels are int32, SF_NUM_CLUSTERS (24) = invalid pixel
+ *   - 4x4 transforms are column-major float32 (Eigen::Matrix4f storage order)
+ *   - twists are (vx, vy, vz, wx, wy, wz)
+ *
+ * One handle owns `batch` independent streams (independent RGB-D sequences).  The MI355X build
+ * runs one workgroup per stream; streams never exchange data.  All calls on one handle are
+ * issued on one HIP stream in call order; handles are independent (thread-safe across handles).
+ *
+ * Every function returns SF_OK (0) or a negative error code; sf_last_error() returns a
+ * human-readable description of the last failure on the calling thread.
+ *
+ * Two libraries implement this ABI with different symbol prefixes:
+ *   libsf_hip.so     sf_*    the product: hand-written HIP for gfx950  (staticfusion_amd/csrc)
+ *   liboracle.so     sfo_*   the CPU oracle used ONLY by tests / smoke / bench cpu_baseline (oracle/)
+ * The product never links, loads or calls the oracle.
+ */
+#ifndef SF_H_
+#define SF_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef SF_PREFIX
+#define SF_PREFIX sf_
+#endif
+#define SF_CAT2(a, b) a##b
+#define SF_CAT(a, b) SF_CAT2(a, b)
+#define SF_FN(name) SF_CAT(SF_PREFIX, name)
+
+#define SF_NUM_CLUSTERS 24 /* reference StaticFusion.h:61 NUM_CLUSTERS */
+#define SF_MAX_LEVELS 8
+#define SF_HISTORY 5   /* reference StaticFusion.h:96 bufferLength */
+#define SF_MAX_OUTER 32 /* trace capacity: ctf_levels * max_iter_per_level must not exceed it */
+
+enum {
+    SF_OK = 0,
+    SF_ERR_ARG = -1,     /* bad argument (null pointer, index out of range, unsupported size) */
+    SF_ERR_DEVICE = -2,  /* HIP runtime error / no usable device */
+    SF_ERR_STATE = -3,   /* call sequence error */
+    SF_ERR_NOMEM = -4
+};
+
+/* status bits in sf_frame_stats.status */
+enum {
+    SF_STATUS_EIG_SKIPPED = 1, /* non-finite covariance: pose update skipped (reference FrontEnd.cpp:720-724) */
+    SF_STATUS_EMPTY_LEVEL = 2  /* a level had no valid pixel (reference divides by zero there, FrontEnd.cpp:505-509) */
+};
+
+/* The reference's parameter set: public members written by the drivers
+ * (reference FrontEnd.cpp:57-76 ctor defaults, StaticFusion-datasets.cpp:79-94 driver values). */
+typedef struct sf_params {
+    int32_t ctf_levels;          /* 0 = log2(cols/40)+2 as in FrontEnd.cpp:61 */
+    int32_t max_iter_per_level;  /* FrontEnd.cpp:69 / datasets.cpp:83 */
+    int32_t max_iter_irls;       /* FrontEnd.cpp:68 / datasets.cpp:89 */
+    int32_t use_motion_filter;   /* FrontEnd.cpp:76 / datasets.cpp:79 */
+    int32_t segmentation_enabled; /* 1 = reference behaviour. 0 = "everything static": b_segm held at 1
+                                     (the commented alternative at FrontEnd.cpp:606-607), K-means and the
+                                     b-solve skipped: pure 6-DoF Cauchy IRLS (BASELINE.json configs[1]) */
+    int32_t debug_planes;        /* 1 = also keep the Warped/Inter planes of every level for sf_get_plane */
+    float fovh;                  /* FrontEnd.cpp:57 (radians); fovv is unused by the solver */
+    float k_photometric_res;     /* FrontEnd.cpp:66 */
+    float irls_delta_threshold;  /* FrontEnd.cpp:67 */
+    float previous_speed_const_weight; /* FrontEnd.cpp:70 */
+    float previous_speed_eig_weight;   /* FrontEnd.cpp:71 */
+    float kc_Cauchy;             /* FrontEnd.cpp:72 */
+    float kb;                    /* FrontEnd.cpp:73; per-stream override: sf_set_kb */
+    float kz;                    /* FrontEnd.cpp:74 */
+    float lambda_reg;            /* uninitialised in the ctor; datasets.cpp:90 */
+    float lambda_prior;          /* datasets.cpp:91 */
+} sf_params;
+
+/* One record per executed outer ("linearisation") iteration, reference FrontEnd.cpp:1094-1132. */
+typedef struct sf_outer_trace {
+    int32_t level;      /* 0 = coarsest (reference `level`) */
+    int32_t k;          /* iteration within the level */
+    int32_t n_valid;    /* validPixels.size() */
+    int32_t irls_iters; /* IRLS loop bodies executed (FrontEnd.cpp:611-684) */
+    float aver_res;     /* after the last IRLS iteration */
+    float var[6];       /* last IRLS solution, before the motion filter */
+    float twist_level[6]; /* twist_level_odometry */
+    float b_segm[SF_NUM_CLUSTERS];
+    float T[16];        /* T_odometry after this iteration, column-major */
+} sf_outer_trace;
+
+typedef struct sf_frame_stats {
+    int32_t n_outer;      /* outer iterations executed by the last sf_run_solver */
+    int32_t n_irls;       /* IRLS loop bodies executed ("solver iterations") */
+    int64_t pixel_iters;  /* sum of n_valid over IRLS iterations */
+    int32_t kmeans_iters; /* Lloyd iterations executed (KMeans.cpp:167-228) */
+    int32_t status;       /* SF_STATUS_* bits */
+    sf_outer_trace outer[SF_MAX_OUTER];
+} sf_frame_stats;
+
+typedef struct sf_handle sf_handle;
+
+/* plane selectors for sf_get_plane: which pyramid, which channel */
+enum { SF_SET_NEW = 0, SF_SET_PRED = 1, SF_SET_WARPED = 2, SF_SET_INTER = 3 };
+enum { SF_CH_DEPTH = 0, SF_CH_INTENSITY = 1, SF_CH_XX = 2, SF_CH_YY = 3 };
+/* linearisation planes of the LAST executed outer iteration (sf_get_lin_plane) */
+enum {
+    SF_LIN_DCU = 0, SF_LIN_DCV, SF_LIN_DCT, SF_LIN_DDU, SF_LIN_DDV, SF_LIN_DDT,
+    SF_LIN_WC, SF_LIN_WD, /* weights_c / weights_d AFTER division by their maximum */
+    SF_LIN_NULL,          /* Null mask as 0/1 float */
+    SF_LIN_COUNT
+};
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+
+/* Driver parameter values (StaticFusion-datasets.cpp:79-94) with kb = 1.5. */
+void SF_FN(default_params)(sf_params *p);
+/* Constructor defaults (FrontEnd.cpp:57-76); lambda_reg / lambda_prior set to the driver values. */
+void SF_FN(ctor_params)(sf_params *p);
+
+/* Replaces StaticFusion::StaticFusion(res_factor) (FrontEnd.cpp:52-181) minus the GUI / map objects.
+ * rows x cols is the solver resolution (240 x 320 for res_factor 2). device = HIP ordinal. */
+int SF_FN(create)(const sf_params *p, int rows, int cols, int batch, int device, sf_handle **out);
+void SF_FN(destroy)(sf_handle *h);
+int SF_FN(set_params)(sf_handle *h, const sf_params *p);
+int SF_FN(get_params)(const sf_handle *h, sf_params *p);
+/* Replaces `staticFusion.kb = ...` per frame (StaticFusion-datasets.cpp:158,163). stream = -1: all. */
+int SF_FN(set_kb)(sf_handle *h, int stream, float kb);
+/* Use an externally owned hipStream_t for all work of this handle (NULL = the handle's own stream). */
+int SF_FN(set_hip_stream)(sf_handle *h, void *hip_stream);
+int SF_FN(synchronize)(sf_handle *h);
+const char *SF_FN(last_error)(void);
+/* "hip:gfx950" for the product, "cpu-oracle" for the oracle. */
+const char *SF_FN(backend)(void);
+
+/* ---- inputs: the members the drivers write ------------------------------------------------ */
+
+/* depthCurrent / intensityCurrent (StaticFusion.h:90). Host pointers, rows*cols floats each. */
+int SF_FN(set_current)(sf_handle *h, int stream, const float *depth, const float *intensity);
+/* depthPrediction / intensityPrediction (StaticFusion.h:91). */
+int SF_FN(set_prediction)(sf_handle *h, int stream, const float *depth, const float *intensity);
+/* Same, for the whole batch from DEVICE-resident buffers laid out [batch][cols][rows]
+ * (what an MI355X-resident producer such as a HIP renderer / loader hands over). */
+int SF_FN(set_current_device)(sf_handle *h, const void *d_depth, const void *d_intensity);
+int SF_FN(set_prediction_device)(sf_handle *h, const void *d_depth, const void *d_intensity);
+/* The bootstrap `depthCurrent.swap(depthPrediction)` (StaticFusion-imagesequenceassoc.cpp:105-108):
+ * prediction := current, for every stream. */
+int SF_FN(current_to_prediction)(sf_handle *h);
+/* twist_odometry_old (carried motion-filter state, FrontEnd.cpp:1141-1144); rarely needed. */
+int SF_FN(set_twist_old)(sf_handle *h, int stream, const float twist[6]);
+
+/* ---- the four methods the drivers call (all streams of the batch) ------------------------- */
+
+/* StaticFusion::createImagePyramid(bool old_im)  FrontEnd.cpp:256-391 */
+int SF_FN(build_pyramid)(sf_handle *h, int old_im);
+/* StaticFusion::kMeans3DCoord() + createClustersPyramidUsingKMeans()  KMeans.cpp:137-391
+ * (public in the reference, called only from runSolver; needs the NEW pyramid) */
+int SF_FN(kmeans)(sf_handle *h);
+/* StaticFusion::runSolver(bool create_image_pyr)  FrontEnd.cpp:1071-1146 */
+int SF_FN(run_solver)(sf_handle *h, int create_image_pyr);
+/* ring[im_count % 5] = (depthCurrent, intensityCurrent, T_odometry)  StaticFusion-datasets.cpp:182-184 */
+int SF_FN(push_history)(sf_handle *h, int im_count);
+/* StaticFusion::computeResidualsAgainstPreviousImage(int index)  FrontEnd.cpp:896-1069 */
+int SF_FN(residuals_vs_history)(sf_handle *h, int index);
+/* StaticFusion::buildSegmImage()  SegmentationBackground.cpp:176-197 */
+int SF_FN(build_segm_image)(sf_handle *h);
+/* The drivers' per-frame sequence in one call (StaticFusion-datasets.cpp:171-184):
+ * createImagePyramid(true); runSolver(true); if (im_count >= 5) computeResiduals(im_count);
+ * buildSegmImage(); push_history(im_count). */
+int SF_FN(process_frame)(sf_handle *h, int im_count);
+
+/* ---- outputs: the members the drivers read ------------------------------------------------ */
+
+int SF_FN(get_T)(sf_handle *h, int stream, float T[16]);           /* T_odometry */
+int SF_FN(get_twist)(sf_handle *h, int stream, float twist[6]);    /* twist_odometry */
+int SF_FN(get_twist_old)(sf_handle *h, int stream, float twist[6]);/* twist_odometry_old */
+int SF_FN(get_b)(sf_handle *h, int stream, float b[SF_NUM_CLUSTERS]); /* b_segm */
+int SF_FN(get_b_image)(sf_handle *h, int stream, float *out);      /* b_segm_perpixel, rows*cols */
+int SF_FN(get_labels)(sf_handle *h, int stream, int level, int32_t *out); /* clusterAllocation[level] */
+int SF_FN(get_kmeans)(sf_handle *h, int stream, float centres[3 * SF_NUM_CLUSTERS]); /* kmeans, col-major 3x24 */
+int SF_FN(get_connectivity)(sf_handle *h, int stream, uint8_t conn[SF_NUM_CLUSTERS * SF_NUM_CLUSTERS]);
+int SF_FN(get_cluster_residuals)(sf_handle *h, int stream, float r[SF_NUM_CLUSTERS]); /* perClusterAverageResidual */
+int SF_FN(get_stats)(sf_handle *h, int stream, sf_frame_stats *out);
+/* Batched readback of the pose + iteration counters (what a throughput harness needs):
+ * T is [batch][16], n_irls / n_outer are [batch]; any pointer may be NULL. */
+int SF_FN(get_batch_results)(sf_handle *h, float *T, int32_t *n_irls, int32_t *n_outer, int64_t *pixel_iters);
+
+/* Pyramid planes (depthPyr / intensityPredPyr / xxWarpedPyr ...). WARPED and INTER sets hold the
+ * planes of the last outer iteration executed at that level and need params.debug_planes = 1. */
+int SF_FN(get_plane)(sf_handle *h, int stream, int set, int channel, int level, float *out);
+/* dcu..ddt, weights, Null of the last executed outer iteration (size of that iteration's level). */
+int SF_FN(get_lin_plane)(sf_handle *h, int stream, int which, float *out, int *rows, int *cols);
+
+int SF_FN(level_rows)(const sf_handle *h, int level);
+int SF_FN(level_cols)(const sf_handle *h, int level);
+int SF_FN(batch)(const sf_handle *h);
+
+/* ---- measurement support ------------------------------------------------------------------ */
+
+/* Time `calls` repetitions of sf_process_frame(im_count) with HIP events recorded on the handle's
+ * stream (events bracket the whole timed region; inputs must already be resident). Returns the
+ * elapsed milliseconds of the region. */
+int SF_FN(timed_process_frames)(sf_handle *h, int im_count, int calls, float *elapsed_ms);
+/* Elapsed ms of the most recent solver kernel launch (HIP events around that launch). */
+int SF_FN(last_solver_kernel_ms)(sf_handle *h, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SF_H_ */

@@ -1,0 +1,376 @@
+// sf_oracle_capi.cpp — CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+// Exposes the scalar restatement (sf_oracle.hpp) through the SAME C ABI as the product
+// (include/sf.h) with the symbol prefix `sfo_`, so that tests drive both through one harness.
+// PARITY UNPINNED — see sf_oracle.hpp.
+#define SF_PREFIX sfo_
+#include "../include/sf.h"
+
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "sf_oracle.hpp"
+
+struct sf_handle {
+    int rows, cols, batch;
+    sf_params params;
+    std::vector<std::unique_ptr<sfo::StaticFusion>> s;
+    int last_level = -1;  // image level of the last outer iteration (for get_lin_plane)
+    float last_ms = 0.f;
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const char *msg) {
+    g_err = msg;
+    return code;
+}
+
+static sfo::Params to_oracle(const sf_params &p) {
+    sfo::Params o;
+    o.ctf_levels = p.ctf_levels;
+    o.max_iter_per_level = p.max_iter_per_level;
+    o.max_iter_irls = p.max_iter_irls;
+    o.use_motion_filter = p.use_motion_filter != 0;
+    o.segmentation_enabled = p.segmentation_enabled != 0;
+    o.fovh = p.fovh;
+    o.k_photometric_res = p.k_photometric_res;
+    o.irls_delta_threshold = p.irls_delta_threshold;
+    o.previous_speed_const_weight = p.previous_speed_const_weight;
+    o.previous_speed_eig_weight = p.previous_speed_eig_weight;
+    o.kc_Cauchy = p.kc_Cauchy;
+    o.kb = p.kb;
+    o.kz = p.kz;
+    o.lambda_reg = p.lambda_reg;
+    o.lambda_prior = p.lambda_prior;
+    return o;
+}
+
+extern "C" {
+
+void sfo_ctor_params(sf_params *p) {  // FrontEnd.cpp:57-76
+    std::memset(p, 0, sizeof(*p));
+    p->ctf_levels = 0;
+    p->max_iter_per_level = 2;
+    p->max_iter_irls = 10;
+    p->use_motion_filter = 0;
+    p->segmentation_enabled = 1;
+    p->debug_planes = 0;
+    p->fovh = float(M_PI * 62.5 / 180.0);
+    p->k_photometric_res = 0.15f;
+    p->irls_delta_threshold = 1e-6f;
+    p->previous_speed_const_weight = 0.05f;
+    p->previous_speed_eig_weight = 0.5f;
+    p->kc_Cauchy = 0.5f;
+    p->kb = 1.25f;
+    p->kz = 1.5f;
+    p->lambda_reg = 0.35f;
+    p->lambda_prior = 0.5f;
+}
+
+void sfo_default_params(sf_params *p) {  // StaticFusion-datasets.cpp:79-94
+    sfo_ctor_params(p);
+    p->use_motion_filter = 1;
+    p->max_iter_per_level = 3;
+    p->previous_speed_const_weight = 0.1f;
+    p->previous_speed_eig_weight = 2.f;
+    p->k_photometric_res = 0.15f;
+    p->irls_delta_threshold = 0.0015f;
+    p->max_iter_irls = 6;
+    p->lambda_reg = 0.35f;
+    p->lambda_prior = 0.5f;
+    p->kc_Cauchy = 0.5f;
+    p->kb = 1.5f;
+    p->kz = 1.5f;
+}
+
+const char *sfo_last_error(void) { return g_err.c_str(); }
+const char *sfo_backend(void) { return "cpu-oracle"; }
+
+int sfo_create(const sf_params *p, int rows, int cols, int batch, int device, sf_handle **out) {
+    (void)device;
+    if (!p || !out || rows < 8 || cols < 8 || batch < 1) return fail(SF_ERR_ARG, "bad argument");
+    auto *h = new sf_handle;
+    h->rows = rows;
+    h->cols = cols;
+    h->batch = batch;
+    h->params = *p;
+    sfo::Params op = to_oracle(*p);
+    for (int i = 0; i < batch; i++) h->s.emplace_back(new sfo::StaticFusion(rows, cols, op));
+    h->params.ctf_levels = int(h->s[0]->ctf_levels);
+    if (h->params.ctf_levels < 2 || h->params.ctf_levels > SF_MAX_LEVELS ||
+        h->params.ctf_levels * h->params.max_iter_per_level > SF_MAX_OUTER ||
+        (rows >> (h->params.ctf_levels - 1)) < 3 || (cols >> (h->params.ctf_levels - 1)) < 3) {
+        delete h;
+        return fail(SF_ERR_ARG, "unsupported ctf_levels for this resolution");
+    }
+    *out = h;
+    return SF_OK;
+}
+
+void sfo_destroy(sf_handle *h) { delete h; }
+
+int sfo_set_params(sf_handle *h, const sf_params *p) {
+    if (!h || !p) return fail(SF_ERR_ARG, "null");
+    if (p->ctf_levels > 0 && p->ctf_levels > int(h->s[0]->pyr_levels_alloc))
+        return fail(SF_ERR_ARG, "ctf_levels exceeds the allocated pyramid");
+    const int keep = h->params.ctf_levels;
+    h->params = *p;
+    if (p->ctf_levels <= 0) h->params.ctf_levels = keep;
+    sfo::Params op = to_oracle(h->params);
+    for (auto &s : h->s) s->setParams(op);
+    return SF_OK;
+}
+int sfo_get_params(const sf_handle *h, sf_params *p) {
+    if (!h || !p) return fail(SF_ERR_ARG, "null");
+    *p = h->params;
+    return SF_OK;
+}
+int sfo_set_kb(sf_handle *h, int stream, float kb) {
+    if (!h || stream < -1 || stream >= h->batch) return fail(SF_ERR_ARG, "bad stream");
+    for (int i = 0; i < h->batch; i++)
+        if (stream < 0 || stream == i) h->s[i]->kb = kb;
+    return SF_OK;
+}
+int sfo_set_hip_stream(sf_handle *, void *) { return SF_OK; }
+int sfo_synchronize(sf_handle *) { return SF_OK; }
+
+static int check_stream(sf_handle *h, int stream) {
+    if (!h) return fail(SF_ERR_ARG, "null handle");
+    if (stream < 0 || stream >= h->batch) return fail(SF_ERR_ARG, "stream out of range");
+    return SF_OK;
+}
+
+int sfo_set_current(sf_handle *h, int stream, const float *depth, const float *intensity) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!depth || !intensity) return fail(SF_ERR_ARG, "null image");
+    auto &s = *h->s[stream];
+    std::memcpy(s.depthCurrent.d.data(), depth, sizeof(float) * size_t(h->rows) * h->cols);
+    std::memcpy(s.intensityCurrent.d.data(), intensity, sizeof(float) * size_t(h->rows) * h->cols);
+    return SF_OK;
+}
+int sfo_set_prediction(sf_handle *h, int stream, const float *depth, const float *intensity) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!depth || !intensity) return fail(SF_ERR_ARG, "null image");
+    auto &s = *h->s[stream];
+    std::memcpy(s.depthPrediction.d.data(), depth, sizeof(float) * size_t(h->rows) * h->cols);
+    std::memcpy(s.intensityPrediction.d.data(), intensity, sizeof(float) * size_t(h->rows) * h->cols);
+    return SF_OK;
+}
+int sfo_set_current_device(sf_handle *h, const void *d, const void *i) {
+    // "device" buffers of the CPU oracle are host buffers [batch][cols][rows]
+    if (!h || !d || !i) return fail(SF_ERR_ARG, "null");
+    const size_t n = size_t(h->rows) * h->cols;
+    for (int b = 0; b < h->batch; b++) sfo_set_current(h, b, (const float *)d + b * n, (const float *)i + b * n);
+    return SF_OK;
+}
+int sfo_set_prediction_device(sf_handle *h, const void *d, const void *i) {
+    if (!h || !d || !i) return fail(SF_ERR_ARG, "null");
+    const size_t n = size_t(h->rows) * h->cols;
+    for (int b = 0; b < h->batch; b++) sfo_set_prediction(h, b, (const float *)d + b * n, (const float *)i + b * n);
+    return SF_OK;
+}
+int sfo_current_to_prediction(sf_handle *h) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    for (auto &s : h->s) {
+        s->depthPrediction = s->depthCurrent;
+        s->intensityPrediction = s->intensityCurrent;
+    }
+    return SF_OK;
+}
+int sfo_set_twist_old(sf_handle *h, int stream, const float twist[6]) {
+    if (int e = check_stream(h, stream)) return e;
+    for (int i = 0; i < 6; i++) h->s[stream]->twist_odometry_old[i] = twist[i];
+    return SF_OK;
+}
+
+int sfo_build_pyramid(sf_handle *h, int old_im) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    for (auto &s : h->s) s->createImagePyramid(old_im != 0);
+    return SF_OK;
+}
+int sfo_kmeans(sf_handle *h) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    for (auto &s : h->s) {
+        s->stats.kmeans_iters = 0;
+        s->kMeans3DCoord();
+        s->createClustersPyramidUsingKMeans();
+    }
+    return SF_OK;
+}
+int sfo_run_solver(sf_handle *h, int create_image_pyr) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    auto t0 = std::chrono::steady_clock::now();
+    for (auto &s : h->s) s->runSolver(create_image_pyr != 0);
+    h->last_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return SF_OK;
+}
+int sfo_push_history(sf_handle *h, int im_count) {
+    if (!h || im_count < 0) return fail(SF_ERR_ARG, "bad argument");
+    for (auto &s : h->s) s->pushHistory(im_count);
+    return SF_OK;
+}
+int sfo_residuals_vs_history(sf_handle *h, int index) {
+    if (!h || index < SF_HISTORY) return fail(SF_ERR_ARG, "index must be >= 5");
+    for (auto &s : h->s) s->computeResidualsAgainstPreviousImage(index);
+    return SF_OK;
+}
+int sfo_build_segm_image(sf_handle *h) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    for (auto &s : h->s) s->buildSegmImage();
+    return SF_OK;
+}
+int sfo_process_frame(sf_handle *h, int im_count) {  // StaticFusion-datasets.cpp:171-184
+    if (!h || im_count < 0) return fail(SF_ERR_ARG, "bad argument");
+    sfo_build_pyramid(h, 1);
+    sfo_run_solver(h, 1);
+    if (im_count - SF_HISTORY >= 0) sfo_residuals_vs_history(h, im_count);
+    sfo_build_segm_image(h);
+    sfo_push_history(h, im_count);
+    return SF_OK;
+}
+
+int sfo_get_T(sf_handle *h, int stream, float T[16]) {
+    if (int e = check_stream(h, stream)) return e;
+    std::memcpy(T, h->s[stream]->T_odometry.m, 16 * sizeof(float));
+    return SF_OK;
+}
+int sfo_get_twist(sf_handle *h, int stream, float t[6]) {
+    if (int e = check_stream(h, stream)) return e;
+    std::memcpy(t, h->s[stream]->twist_odometry, 6 * sizeof(float));
+    return SF_OK;
+}
+int sfo_get_twist_old(sf_handle *h, int stream, float t[6]) {
+    if (int e = check_stream(h, stream)) return e;
+    std::memcpy(t, h->s[stream]->twist_odometry_old, 6 * sizeof(float));
+    return SF_OK;
+}
+int sfo_get_b(sf_handle *h, int stream, float b[SF_NUM_CLUSTERS]) {
+    if (int e = check_stream(h, stream)) return e;
+    std::memcpy(b, h->s[stream]->b_segm, SF_NUM_CLUSTERS * sizeof(float));
+    return SF_OK;
+}
+int sfo_get_b_image(sf_handle *h, int stream, float *out) {
+    if (int e = check_stream(h, stream)) return e;
+    std::memcpy(out, h->s[stream]->b_segm_perpixel.d.data(), sizeof(float) * size_t(h->rows) * h->cols);
+    return SF_OK;
+}
+int sfo_get_labels(sf_handle *h, int stream, int level, int32_t *out) {
+    if (int e = check_stream(h, stream)) return e;
+    if (level < 0 || level >= h->params.ctf_levels) return fail(SF_ERR_ARG, "bad level");
+    const auto &m = h->s[stream]->clusterAllocation[level];
+    std::memcpy(out, m.d.data(), sizeof(int32_t) * m.size());
+    return SF_OK;
+}
+int sfo_get_kmeans(sf_handle *h, int stream, float c[3 * SF_NUM_CLUSTERS]) {
+    if (int e = check_stream(h, stream)) return e;
+    std::memcpy(c, h->s[stream]->kmeans, 3 * SF_NUM_CLUSTERS * sizeof(float));
+    return SF_OK;
+}
+int sfo_get_connectivity(sf_handle *h, int stream, uint8_t conn[SF_NUM_CLUSTERS * SF_NUM_CLUSTERS]) {
+    if (int e = check_stream(h, stream)) return e;
+    for (int i = 0; i < SF_NUM_CLUSTERS; i++)
+        for (int j = 0; j < SF_NUM_CLUSTERS; j++) conn[i * SF_NUM_CLUSTERS + j] = h->s[stream]->connectivity[i][j];
+    return SF_OK;
+}
+int sfo_get_cluster_residuals(sf_handle *h, int stream, float r[SF_NUM_CLUSTERS]) {
+    if (int e = check_stream(h, stream)) return e;
+    std::memcpy(r, h->s[stream]->perClusterAverageResidual, SF_NUM_CLUSTERS * sizeof(float));
+    return SF_OK;
+}
+int sfo_get_stats(sf_handle *h, int stream, sf_frame_stats *out) {
+    if (int e = check_stream(h, stream)) return e;
+    const sfo::FrameStats &st = h->s[stream]->stats;
+    std::memset(out, 0, sizeof(*out));
+    out->n_outer = st.n_outer;
+    out->n_irls = st.n_irls;
+    out->pixel_iters = st.pixel_iters;
+    out->kmeans_iters = st.kmeans_iters;
+    out->status = st.status;
+    for (int i = 0; i < st.n_outer && i < SF_MAX_OUTER; i++) {
+        const sfo::OuterTrace &a = st.outer[i];
+        sf_outer_trace &b = out->outer[i];
+        b.level = a.level; b.k = a.k; b.n_valid = a.n_valid; b.irls_iters = a.irls_iters;
+        b.aver_res = a.aver_res;
+        std::memcpy(b.var, a.var, sizeof(b.var));
+        std::memcpy(b.twist_level, a.twist_level, sizeof(b.twist_level));
+        std::memcpy(b.b_segm, a.b_segm, sizeof(b.b_segm));
+        std::memcpy(b.T, a.T, sizeof(b.T));
+    }
+    return SF_OK;
+}
+int sfo_get_batch_results(sf_handle *h, float *T, int32_t *n_irls, int32_t *n_outer, int64_t *pixel_iters) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    for (int b = 0; b < h->batch; b++) {
+        if (T) std::memcpy(T + 16 * b, h->s[b]->T_odometry.m, 16 * sizeof(float));
+        if (n_irls) n_irls[b] = h->s[b]->stats.n_irls;
+        if (n_outer) n_outer[b] = h->s[b]->stats.n_outer;
+        if (pixel_iters) pixel_iters[b] = h->s[b]->stats.pixel_iters;
+    }
+    return SF_OK;
+}
+
+int sfo_get_plane(sf_handle *h, int stream, int set, int channel, int level, float *out) {
+    if (int e = check_stream(h, stream)) return e;
+    if (level < 0 || level >= h->params.ctf_levels || set < 0 || set > 3 || channel < 0 || channel > 3)
+        return fail(SF_ERR_ARG, "bad selector");
+    auto &s = *h->s[stream];
+    std::vector<sfo::MatF> *tab[4][4] = {
+        {&s.depthPyr, &s.intensityPyr, &s.xxPyr, &s.yyPyr},
+        {&s.depthPredPyr, &s.intensityPredPyr, &s.xxPredPyr, &s.yyPredPyr},
+        {&s.depthWarpedPyr, &s.intensityWarpedPyr, &s.xxWarpedPyr, &s.yyWarpedPyr},
+        {&s.depthInterPyr, &s.intensityInterPyr, &s.xxInterPyr, &s.yyInterPyr}};
+    const sfo::MatF &m = (*tab[set][channel])[level];
+    std::memcpy(out, m.d.data(), sizeof(float) * m.size());
+    return SF_OK;
+}
+
+int sfo_get_lin_plane(sf_handle *h, int stream, int which, float *out, int *rows, int *cols) {
+    if (int e = check_stream(h, stream)) return e;
+    if (which < 0 || which >= SF_LIN_COUNT) return fail(SF_ERR_ARG, "bad selector");
+    auto &s = *h->s[stream];
+    const int r = int(s.rows_i), c = int(s.cols_i);
+    if (rows) *rows = r;
+    if (cols) *cols = c;
+    if (!out) return SF_OK;
+    for (int u = 0; u < c; u++)
+        for (int v = 0; v < r; v++) {
+            float val = 0.f;
+            const bool valid = !s.Null(v, u) && u != 0 && v != 0 && u != c - 1 && v != r - 1;
+            switch (which) {
+                // dcu/dcv/ddu/ddv hold stale values outside validPixels in the reference: report 0 there
+                case SF_LIN_DCU: val = valid ? s.dcu(v, u) : 0.f; break;
+                case SF_LIN_DCV: val = valid ? s.dcv(v, u) : 0.f; break;
+                case SF_LIN_DCT: val = s.dct(v, u); break;
+                case SF_LIN_DDU: val = valid ? s.ddu(v, u) : 0.f; break;
+                case SF_LIN_DDV: val = valid ? s.ddv(v, u) : 0.f; break;
+                case SF_LIN_DDT: val = s.ddt(v, u); break;
+                case SF_LIN_WC: val = s.weights_c(v, u); break;
+                case SF_LIN_WD: val = s.weights_d(v, u); break;
+                case SF_LIN_NULL: val = s.Null(v, u) ? 1.f : 0.f; break;
+            }
+            out[v + size_t(u) * r] = val;
+        }
+    return SF_OK;
+}
+
+int sfo_level_rows(const sf_handle *h, int level) { return h ? (h->rows >> level) : 0; }
+int sfo_level_cols(const sf_handle *h, int level) { return h ? (h->cols >> level) : 0; }
+int sfo_batch(const sf_handle *h) { return h ? h->batch : 0; }
+
+int sfo_timed_process_frames(sf_handle *h, int im_count, int calls, float *elapsed_ms) {
+    if (!h || calls < 1) return fail(SF_ERR_ARG, "bad argument");
+    auto t0 = std::chrono::steady_clock::now();
+    for (int c = 0; c < calls; c++) sfo_process_frame(h, im_count);
+    if (elapsed_ms)
+        *elapsed_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return SF_OK;
+}
+int sfo_last_solver_kernel_ms(sf_handle *h, float *ms) {
+    if (!h || !ms) return fail(SF_ERR_ARG, "null");
+    *ms = h->last_ms;
+    return SF_OK;
+}
+
+}  // extern "C"

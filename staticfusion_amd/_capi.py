@@ -1,0 +1,320 @@
+"""ctypes plumbing for the C ABI declared in include/sf.h.
+
+`Api(lib_path, prefix)` binds one shared library implementing the ABI; `Solver` is a thin
+numpy-in / numpy-out convenience wrapper over one `sf_handle`.  The product library is bound by
+`staticfusion_amd.load()` (prefix ``sf_``); the test oracle binds the same declarations with the
+prefix ``sfo_`` from `oracle/binding.py`.  Nothing here computes anything.
+"""
+import ctypes as C
+
+import numpy as np
+
+NUM_CLUSTERS = 24
+MAX_OUTER = 32
+HISTORY = 5
+
+SET_NEW, SET_PRED, SET_WARPED, SET_INTER = 0, 1, 2, 3
+CH_DEPTH, CH_INTENSITY, CH_XX, CH_YY = 0, 1, 2, 3
+(LIN_DCU, LIN_DCV, LIN_DCT, LIN_DDU, LIN_DDV, LIN_DDT, LIN_WC, LIN_WD, LIN_NULL) = range(9)
+
+STATUS_EIG_SKIPPED = 1
+STATUS_EMPTY_LEVEL = 2
+
+
+class SfParams(C.Structure):
+    _fields_ = [
+        ("ctf_levels", C.c_int32),
+        ("max_iter_per_level", C.c_int32),
+        ("max_iter_irls", C.c_int32),
+        ("use_motion_filter", C.c_int32),
+        ("segmentation_enabled", C.c_int32),
+        ("debug_planes", C.c_int32),
+        ("fovh", C.c_float),
+        ("k_photometric_res", C.c_float),
+        ("irls_delta_threshold", C.c_float),
+        ("previous_speed_const_weight", C.c_float),
+        ("previous_speed_eig_weight", C.c_float),
+        ("kc_Cauchy", C.c_float),
+        ("kb", C.c_float),
+        ("kz", C.c_float),
+        ("lambda_reg", C.c_float),
+        ("lambda_prior", C.c_float),
+    ]
+
+
+class SfOuterTrace(C.Structure):
+    _fields_ = [
+        ("level", C.c_int32),
+        ("k", C.c_int32),
+        ("n_valid", C.c_int32),
+        ("irls_iters", C.c_int32),
+        ("aver_res", C.c_float),
+        ("var", C.c_float * 6),
+        ("twist_level", C.c_float * 6),
+        ("b_segm", C.c_float * NUM_CLUSTERS),
+        ("T", C.c_float * 16),
+    ]
+
+
+class SfFrameStats(C.Structure):
+    _fields_ = [
+        ("n_outer", C.c_int32),
+        ("n_irls", C.c_int32),
+        ("pixel_iters", C.c_int64),
+        ("kmeans_iters", C.c_int32),
+        ("status", C.c_int32),
+        ("outer", SfOuterTrace * MAX_OUTER),
+    ]
+
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_H = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/sf.h declares
+SIGNATURES = {
+    "default_params": (None, [C.POINTER(SfParams)]),
+    "ctor_params": (None, [C.POINTER(SfParams)]),
+    "create": (C.c_int, [C.POINTER(SfParams), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
+    "destroy": (None, [_H]),
+    "set_params": (C.c_int, [_H, C.POINTER(SfParams)]),
+    "get_params": (C.c_int, [_H, C.POINTER(SfParams)]),
+    "set_kb": (C.c_int, [_H, C.c_int, C.c_float]),
+    "set_hip_stream": (C.c_int, [_H, C.c_void_p]),
+    "synchronize": (C.c_int, [_H]),
+    "last_error": (C.c_char_p, []),
+    "backend": (C.c_char_p, []),
+    "set_current": (C.c_int, [_H, C.c_int, _fp, _fp]),
+    "set_prediction": (C.c_int, [_H, C.c_int, _fp, _fp]),
+    "set_current_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    "set_prediction_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    "current_to_prediction": (C.c_int, [_H]),
+    "set_twist_old": (C.c_int, [_H, C.c_int, _fp]),
+    "build_pyramid": (C.c_int, [_H, C.c_int]),
+    "kmeans": (C.c_int, [_H]),
+    "run_solver": (C.c_int, [_H, C.c_int]),
+    "push_history": (C.c_int, [_H, C.c_int]),
+    "residuals_vs_history": (C.c_int, [_H, C.c_int]),
+    "build_segm_image": (C.c_int, [_H]),
+    "process_frame": (C.c_int, [_H, C.c_int]),
+    "get_T": (C.c_int, [_H, C.c_int, _fp]),
+    "get_twist": (C.c_int, [_H, C.c_int, _fp]),
+    "get_twist_old": (C.c_int, [_H, C.c_int, _fp]),
+    "get_b": (C.c_int, [_H, C.c_int, _fp]),
+    "get_b_image": (C.c_int, [_H, C.c_int, _fp]),
+    "get_labels": (C.c_int, [_H, C.c_int, C.c_int, _ip]),
+    "get_kmeans": (C.c_int, [_H, C.c_int, _fp]),
+    "get_connectivity": (C.c_int, [_H, C.c_int, C.POINTER(C.c_uint8)]),
+    "get_cluster_residuals": (C.c_int, [_H, C.c_int, _fp]),
+    "get_stats": (C.c_int, [_H, C.c_int, C.POINTER(SfFrameStats)]),
+    "get_batch_results": (C.c_int, [_H, _fp, _ip, _ip, C.POINTER(C.c_int64)]),
+    "get_plane": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "get_lin_plane": (C.c_int, [_H, C.c_int, C.c_int, _fp, _ip, _ip]),
+    "level_rows": (C.c_int, [_H, C.c_int]),
+    "level_cols": (C.c_int, [_H, C.c_int]),
+    "batch": (C.c_int, [_H]),
+    "timed_process_frames": (C.c_int, [_H, C.c_int, C.c_int, _fp]),
+    "last_solver_kernel_ms": (C.c_int, [_H, _fp]),
+}
+
+
+class SfError(RuntimeError):
+    pass
+
+
+class Api:
+    """One loaded implementation of include/sf.h."""
+
+    def __init__(self, lib_path, prefix):
+        self.lib_path = str(lib_path)
+        self.prefix = prefix
+        self.lib = C.CDLL(self.lib_path)  # raises OSError if missing: callers must not swallow it
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.lib, prefix + name)  # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+
+    def check(self, code):
+        if code != 0:
+            msg = self.last_error()
+            raise SfError("%s%s failed with %d: %s" % (self.prefix, "call", code, msg.decode() if msg else ""))
+
+    def default_params_struct(self):
+        p = SfParams()
+        self.default_params(C.byref(p))
+        return p
+
+    def ctor_params_struct(self):
+        p = SfParams()
+        self.ctor_params(C.byref(p))
+        return p
+
+    def backend_name(self):
+        return self.backend().decode()
+
+
+def _f32(a):
+    """column-major float32 contiguous buffer of a (rows, cols) array"""
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32).T)
+
+
+class Solver:
+    """numpy convenience wrapper over one sf_handle (a batch of independent streams)."""
+
+    def __init__(self, api, rows, cols, batch=1, params=None, device=0):
+        self.api = api
+        self.rows, self.cols, self.batch_size = rows, cols, batch
+        p = params if params is not None else api.default_params_struct()
+        self.h = _H()
+        api.check(api.create(C.byref(p), rows, cols, batch, device, C.byref(self.h)))
+        self.params = SfParams()
+        api.check(api.get_params(self.h, C.byref(self.params)))
+        self.levels = self.params.ctf_levels
+
+    def close(self):
+        if self.h:
+            self.api.destroy(self.h)
+            self.h = _H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- inputs -------------------------------------------------------------------------------
+    def set_params(self, p):
+        self.api.check(self.api.set_params(self.h, C.byref(p)))
+        self.api.check(self.api.get_params(self.h, C.byref(self.params)))
+        self.levels = self.params.ctf_levels
+
+    def set_kb(self, kb, stream=-1):
+        self.api.check(self.api.set_kb(self.h, stream, kb))
+
+    def set_current(self, stream, depth, intensity):
+        d, i = _f32(depth), _f32(intensity)
+        assert d.shape == (self.cols, self.rows) and i.shape == d.shape
+        self.api.check(self.api.set_current(self.h, stream, d.ctypes.data_as(_fp), i.ctypes.data_as(_fp)))
+
+    def set_prediction(self, stream, depth, intensity):
+        d, i = _f32(depth), _f32(intensity)
+        assert d.shape == (self.cols, self.rows) and i.shape == d.shape
+        self.api.check(self.api.set_prediction(self.h, stream, d.ctypes.data_as(_fp), i.ctypes.data_as(_fp)))
+
+    def current_to_prediction(self):
+        self.api.check(self.api.current_to_prediction(self.h))
+
+    def set_twist_old(self, stream, twist):
+        t = np.ascontiguousarray(twist, dtype=np.float32)
+        self.api.check(self.api.set_twist_old(self.h, stream, t.ctypes.data_as(_fp)))
+
+    # -- the reference methods ------------------------------------------------------------------
+    def build_pyramid(self, old_im):
+        self.api.check(self.api.build_pyramid(self.h, int(bool(old_im))))
+
+    def kmeans(self):
+        self.api.check(self.api.kmeans(self.h))
+
+    def run_solver(self, create_image_pyr=True):
+        self.api.check(self.api.run_solver(self.h, int(bool(create_image_pyr))))
+
+    def push_history(self, im_count):
+        self.api.check(self.api.push_history(self.h, im_count))
+
+    def residuals_vs_history(self, index):
+        self.api.check(self.api.residuals_vs_history(self.h, index))
+
+    def build_segm_image(self):
+        self.api.check(self.api.build_segm_image(self.h))
+
+    def process_frame(self, im_count):
+        self.api.check(self.api.process_frame(self.h, im_count))
+
+    def synchronize(self):
+        self.api.check(self.api.synchronize(self.h))
+
+    # -- outputs --------------------------------------------------------------------------------
+    def _vec(self, fn, stream, n):
+        out = np.zeros(n, dtype=np.float32)
+        self.api.check(fn(self.h, stream, out.ctypes.data_as(_fp)))
+        return out
+
+    def T(self, stream=0):
+        return self._vec(self.api.get_T, stream, 16).reshape(4, 4).T.copy()  # column-major -> [r, c]
+
+    def twist(self, stream=0):
+        return self._vec(self.api.get_twist, stream, 6)
+
+    def twist_old(self, stream=0):
+        return self._vec(self.api.get_twist_old, stream, 6)
+
+    def b(self, stream=0):
+        return self._vec(self.api.get_b, stream, NUM_CLUSTERS)
+
+    def cluster_residuals(self, stream=0):
+        return self._vec(self.api.get_cluster_residuals, stream, NUM_CLUSTERS)
+
+    def kmeans_centres(self, stream=0):
+        return self._vec(self.api.get_kmeans, stream, 3 * NUM_CLUSTERS).reshape(NUM_CLUSTERS, 3).T.copy()  # (3, 24)
+
+    def b_image(self, stream=0):
+        out = np.zeros((self.cols, self.rows), dtype=np.float32)
+        self.api.check(self.api.get_b_image(self.h, stream, out.ctypes.data_as(_fp)))
+        return out.T.copy()
+
+    def level_shape(self, level):
+        return self.api.level_rows(self.h, level), self.api.level_cols(self.h, level)
+
+    def labels(self, level, stream=0):
+        r, c = self.level_shape(level)
+        out = np.zeros((c, r), dtype=np.int32)
+        self.api.check(self.api.get_labels(self.h, stream, level, out.ctypes.data_as(_ip)))
+        return out.T.copy()
+
+    def connectivity(self, stream=0):
+        out = np.zeros((NUM_CLUSTERS, NUM_CLUSTERS), dtype=np.uint8)
+        self.api.check(self.api.get_connectivity(self.h, stream, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out.astype(bool)
+
+    def plane(self, pset, channel, level, stream=0):
+        r, c = self.level_shape(level)
+        out = np.zeros((c, r), dtype=np.float32)
+        self.api.check(self.api.get_plane(self.h, stream, pset, channel, level, out.ctypes.data_as(_fp)))
+        return out.T.copy()
+
+    def lin_plane(self, which, stream=0):
+        r, c = C.c_int32(), C.c_int32()
+        self.api.check(self.api.get_lin_plane(self.h, stream, which, None, C.byref(r), C.byref(c)))
+        out = np.zeros((c.value, r.value), dtype=np.float32)
+        self.api.check(self.api.get_lin_plane(self.h, stream, which, out.ctypes.data_as(_fp), C.byref(r), C.byref(c)))
+        return out.T.copy()
+
+    def stats(self, stream=0):
+        st = SfFrameStats()
+        self.api.check(self.api.get_stats(self.h, stream, C.byref(st)))
+        return st
+
+    def batch_results(self):
+        B = self.batch_size
+        T = np.zeros((B, 16), dtype=np.float32)
+        n_irls = np.zeros(B, dtype=np.int32)
+        n_outer = np.zeros(B, dtype=np.int32)
+        pix = np.zeros(B, dtype=np.int64)
+        self.api.check(
+            self.api.get_batch_results(
+                self.h, T.ctypes.data_as(_fp), n_irls.ctypes.data_as(_ip), n_outer.ctypes.data_as(_ip),
+                pix.ctypes.data_as(C.POINTER(C.c_int64)),
+            )
+        )
+        return T.reshape(B, 4, 4).transpose(0, 2, 1).copy(), n_irls, n_outer, pix
+
+    def timed_process_frames(self, im_count, calls):
+        ms = C.c_float()
+        self.api.check(self.api.timed_process_frames(self.h, im_count, calls, C.byref(ms)))
+        return ms.value
+
+    def last_solver_kernel_ms(self):
+        ms = C.c_float()
+        self.api.check(self.api.last_solver_kernel_ms(self.h, C.byref(ms)))
+        return ms.value

@@ -89,7 +89,7 @@ void ldlt_solve(const float *Ain, const float *b, float *x, int n) {
         // dst = L^-T dst
         for (int i = n - 1; i >= 0; i--) {
             float acc = y[i];
-            for (int j = i + 1; j < n; j++) acc -= M(j, i) * y[j];
+            for (int j = n - 1; j > i; j--) acc -= M(j, i) * y[j];
             y[i] = acc;
         }
     }
@@ -863,8 +863,8 @@ void StaticFusion::solveOdometryAndSegmJoint() {
             for (size_t r = 0; r < M; r++) {
                 int q = 0;
                 for (int i = 0; i < 6; i++)
-                    for (int j = i; j < 6; j++) acc[q++] += double(Aw_(r, i) * Aw_(r, j));
-                for (int i = 0; i < 6; i++) acc[21 + i] += double(Aw_(r, i) * Bw[r]);
+                    for (int j = i; j < 6; j++) acc[q++] += double(Aw_(r, i)) * double(Aw_(r, j));
+                for (int i = 0; i < 6; i++) acc[21 + i] += double(Aw_(r, i)) * double(Bw[r]);
             }
             int q = 0;
             for (int i = 0; i < 6; i++)
@@ -921,7 +921,7 @@ void StaticFusion::solveOdometryAndSegmJoint() {
         for (int i = 0; i < 36; i++) Ad[i] = double(AtA[i]);
         inverse_double(Ad, Ai, 6);
         double sqn = 0.0;
-        for (size_t r = 0; r < M; r++) sqn += double(res[r] * res[r]);
+        for (size_t r = 0; r < M; r++) sqn += double(res[r]) * double(res[r]);
         const float sqnf = float(sqn);
         for (int i = 0; i < 36; i++) est_cov[i] = float(Ai[i]) * sqnf;
     }

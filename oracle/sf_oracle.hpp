@@ -17,8 +17,8 @@
 // Where the reference delegates to Eigen internals whose evaluation order is not visible in the
 // reference source (and whose version is unpinned), this restatement fixes a convention, stated at
 // the call site and in DESIGN.md §"Arithmetic conventions":
-//   [C1] Eigen GEMM / dynamic-size reductions (AtA, AtB, sumAll, squaredNorm): float products,
-//        accumulated in double in row order, rounded to float once.
+//   [C1] Eigen GEMM / dynamic-size reductions (AtA, AtB, sumAll, squaredNorm): the float operands
+//        are multiplied and accumulated in double (the products are exact), rounded to float once.
 //   [C2] small fixed-size Eigen reductions (4x4 mask sum, 2x2 sum): SSE packet order of Eigen 3.3.
 //   [C3] 3-vector squaredNorm: ((a0^2 + a1^2) + a2^2) in float.
 //   [C4] LDLT: Eigen 3.3's pivoted unblocked LDLT in float, zero pivot => solution component 0.

@@ -1,0 +1,163 @@
+// sf_device_common.h — shared definitions of the gfx950 solver kernels.
+//
+// Execution model: ONE WORKGROUP PER STREAM (independent RGB-D sequence).  A
+// workgroup of SF_NT threads (8 wave64) owns a stream for a whole stage sequence; every
+// "grid-wide" dependency of the reference algorithm (global max of the pre-weights, the 21+6
+// normal-equation reduction, per-label residual sums, IRLS / level convergence tests) becomes a
+// workgroup-local reduction through wave shuffles + LDS, so there is no inter-workgroup
+// communication, no host round trip and no launch inside the coarse-to-fine loop.  256 CUs x 2
+// resident workgroups keep 512 streams in flight; the streamed records of one stream (3.5 MB at
+// QVGA) do not fit on chip, so the IRLS passes are HBM-bound.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sf.h"
+
+#define SF_NT 512          // threads per workgroup
+#define SF_NW (SF_NT / 64) // waves per workgroup
+#define SF_NC SF_NUM_CLUSTERS
+#define SF_INVALID_LABEL 255
+
+// record planes written by the linearisation and streamed by the IRLS passes
+enum { R_D = 0, R_X, R_Y, R_DCU, R_DCV, R_DCT, R_DDU, R_DDV, R_DDT, R_WC, R_WD, R_COUNT };
+
+// stage mask bits of the frame kernel
+enum {
+    ST_PYR_OLD = 1,      // createImagePyramid(true)
+    ST_PYR_NEW = 2,      // createImagePyramid(false)
+    ST_KMEANS = 4,       // kMeans3DCoord + createClustersPyramidUsingKMeans
+    ST_SOLVE = 8,        // coarse-to-fine loop of runSolver
+    ST_RESIDUALS = 16,   // computeResidualsAgainstPreviousImage(index)
+    ST_SEGM_IMAGE = 32,  // buildSegmImage
+    ST_PUSH_HISTORY = 64 // ring[im_count % 5] = current
+};
+
+// fixed-point scales of the order-independent accumulations
+#define FIX_DEPTH 67108864.f        /* 2^26 : warp depth accumulators */
+#define FIX_INTENS 1073741824.f     /* 2^30 : warp intensity accumulators */
+#define FIX_RES 4294967296.f        /* 2^32 : per-label residual / prior sums */
+
+// Per-stream persistent state (global memory, one per stream).
+struct StreamState {
+    float T[16];            // T_odometry, column-major
+    float twist[6];         // twist_odometry
+    float twist_level[6];   // twist_level_odometry
+    float twist_old[6];     // twist_odometry_old
+    float est_cov[36];
+    float b_segm[SF_NC];
+    float b_prior[SF_NC];
+    float lambda_t_w[SF_NC];
+    float kmeans[3 * SF_NC];        // column-major 3 x 24
+    uint32_t conn[SF_NC];           // connectivity bit rows
+    float cluster_res[SF_NC];       // perClusterAverageResidual
+    float hist_T[SF_HISTORY][16];   // odomBuffer
+    float kb;
+    int32_t last_level;             // image level of the last executed outer iteration
+    float inv_max_c, inv_max_d;     // 1/max of the raw pre-weights of that iteration
+};
+
+// Geometry, parameters and buffer table of a handle: lives in device memory, read through
+// scalar loads (uniform addresses).  Per-launch values (stage mask, frame index) are kernel arguments.
+struct KArgs {
+    // geometry
+    int rows, cols, levels, batch;
+    int lrows[SF_MAX_LEVELS], lcols[SF_MAX_LEVELS], loff[SF_MAX_LEVELS], ln[SF_MAX_LEVELS];
+    int n_tot;  // sum of level sizes
+    int n0;     // level-0 size
+    // parameters
+    sf_params p;
+    float tan_half_fovh;  // tanf(0.5f*fovh), evaluated on the host like the reference does
+    // buffers
+    float *pyr_new[4];   // [ch][batch][n_tot]  depth, intensity, xx, yy
+    float *pyr_pred[4];
+    float *dbg_warped[4];  // debug_planes only, else null
+    float *dbg_inter[4];
+    uint8_t *labels;     // [batch][n_tot]
+    long long *acc_d;    // [batch][n0] warp accumulators
+    long long *acc_i;
+    uint32_t *acc_w;
+    float *rec[R_COUNT];  // [plane][batch][n0]
+    uint8_t *rec_lab;     // [batch][n0]  label of a valid pixel, SF_INVALID_LABEL otherwise
+    uint8_t *rec_null;    // [batch][n0]  Null mask of the last linearisation
+    float *km_sorted[3];  // [coord][batch][n1] K-means partition scratch
+    uint8_t *km_lab_tmp;  // unused for now
+    float *hist_d, *hist_i;  // [SF_HISTORY][batch][n0]
+    float *b_img;            // [batch][n0]
+    StreamState *state;      // [batch]
+    sf_frame_stats *stats;   // [batch]
+    int *queue;              // work-queue counter (zeroed before every launch)
+};
+
+// ---------------------------------------------------------------------------------------------
+//  wave / workgroup reductions (deterministic: fixed shuffle tree, fixed wave order)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;  // lane 0
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float w = __shfl_down(v, o, 64);
+        v = (w > v) ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// x86 cvttss2si semantics of the reference's int(float) (reference FrontEnd.cpp:819-820): NaN and
+// out-of-range -> INT_MIN.  (v_cvt_i32_f32 would saturate and turn NaN into 0, which the
+// reference's `uwarp >= 0` test would then ACCEPT.)
+__device__ __forceinline__ int cvt_trunc_x86(float x) {
+    if (!(x > -2147483648.f && x < 2147483648.f)) return (int)0x80000000;
+    return (int)x;
+}
+
+__device__ __forceinline__ float sqf(float x) { return x * x; }
+// std::max / std::min of the reference (argument order matters for NaN)
+__device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }
+__device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }
+
+__device__ __forceinline__ long long to_fix(float x, float scale, float lim) {
+    float y = x;
+    if (!(y < lim)) y = lim;  // also catches NaN
+    if (!(y > -lim)) y = -lim;
+    return (long long)(y * scale);
+}
+
+// aggregate a per-lane 64-bit value into bins[label], one LDS atomic per distinct label per wave
+__device__ __forceinline__ void wave_label_add_i64(bool active, int lab, long long v, long long *bins, int lane) {
+    unsigned long long rem = __ballot(active);
+    while (rem) {
+        const int src = __ffsll((long long)rem) - 1;
+        const int l = __builtin_amdgcn_readlane(lab, src);
+        const bool mine = active && lab == l;
+        const unsigned long long m = __ballot(mine);
+        const long long sum = wave_sum_i64(mine ? v : 0ll);
+        if (lane == 0) atomicAdd((unsigned long long *)&bins[l], (unsigned long long)sum);
+        rem &= ~m;
+    }
+}
+__device__ __forceinline__ void wave_label_count(bool active, int lab, int *bins, int lane) {
+    unsigned long long rem = __ballot(active);
+    while (rem) {
+        const int src = __ffsll((long long)rem) - 1;
+        const int l = __builtin_amdgcn_readlane(lab, src);
+        const unsigned long long m = __ballot(active && lab == l);
+        if (lane == 0) atomicAdd(&bins[l], (int)__popcll(m));
+        rem &= ~m;
+    }
+}
+

@@ -1,0 +1,560 @@
+// sf_hip.hip — the product: libsf_hip.so, the MI355X (gfx950) implementation of include/sf.h.
+//
+// One persistent kernel, `sf_frame_kernel`, runs any subset of the frame stages for every
+// stream of the batch; workgroups pull stream indices from an atomic queue.  Each C-ABI entry
+// point that the reference exposes as a StaticFusion method is one launch of that kernel with
+// the corresponding stage mask; sf_process_frame is ONE launch with the whole per-frame
+// sequence of the reference drivers (StaticFusion-datasets.cpp:171-184).
+//
+// There is no CPU fallback and no dependence on the test oracle.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sf_device_common.h"
+#include "sf_kmeans.h"
+#include "sf_pyramid.h"
+#include "sf_residuals.h"
+#include "sf_smallmath.h"
+#include "sf_solver.h"
+
+union FrameShared {
+    KmShared km;
+    SolveShared sv;
+    ResShared rs;
+};
+
+__global__ __launch_bounds__(SF_NT, 4) void sf_frame_kernel(const KArgs *__restrict__ ka, int stage_mask, int im_count) {
+    __shared__ FrameShared sh;
+    __shared__ int s_next;
+    const KArgs &a = *ka;
+    const int tid = threadIdx.x;
+    for (;;) {
+        if (tid == 0) s_next = atomicAdd(a.queue, 1);
+        __syncthreads();
+        const int b = s_next;
+        __syncthreads();
+        if (b >= a.batch) break;
+        if (stage_mask & ST_PYR_OLD) stage_pyramid(a, b, true, tid);
+        if (stage_mask & ST_PYR_NEW) stage_pyramid(a, b, false, tid);
+        if (stage_mask & ST_KMEANS) stage_kmeans(a, b, sh.km, tid);
+        if (stage_mask & ST_SOLVE) stage_solve(a, b, sh.sv, tid);
+        if (stage_mask & ST_RESIDUALS) stage_residuals(a, b, im_count, sh.rs, tid);
+        __syncthreads();
+        if (stage_mask & ST_SEGM_IMAGE) stage_segm_image(a, b, tid);
+        if (stage_mask & ST_PUSH_HISTORY) stage_push_history(a, b, im_count, tid);
+        __syncthreads();
+    }
+}
+
+// =============================================================================================
+//  host side
+// =============================================================================================
+struct sf_handle {
+    KArgs k{};
+    int device = 0;
+    int max_blocks = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+    bool solver_timed = false;
+    KArgs *d_args = nullptr;  // device copy of k (geometry, parameters, buffer table)
+    bool args_dirty = true;
+    std::vector<void *> allocs;
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(SF_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+    } while (0)
+
+template <class T>
+static int dev_alloc(sf_handle *h, T **p, size_t count) {
+    void *q = nullptr;
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(SF_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    e = hipMemset(q, 0, bytes);
+    if (e != hipSuccess) return fail(SF_ERR_DEVICE, std::string("hipMemset: ") + hipGetErrorString(e));
+    h->allocs.push_back(q);
+    *p = (T *)q;
+    return SF_OK;
+}
+
+static int launch(sf_handle *h, int mask, int im_count) {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemsetAsync(h->k.queue, 0, sizeof(int), h->stream));
+    if (h->args_dirty) {
+        HIP_TRY(hipMemcpyAsync(h->d_args, &h->k, sizeof(KArgs), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->args_dirty = false;
+    }
+    const int grid = std::min(h->k.batch, h->max_blocks);
+    const bool timed = (mask & ST_SOLVE) != 0;
+    if (timed) HIP_TRY(hipEventRecord(h->evk0, h->stream));
+    hipLaunchKernelGGL(sf_frame_kernel, dim3(grid), dim3(SF_NT), 0, h->stream, (const KArgs *)h->d_args, mask, im_count);
+    HIP_TRY(hipGetLastError());
+    if (timed) {
+        HIP_TRY(hipEventRecord(h->evk1, h->stream));
+        h->solver_timed = true;
+    }
+    return SF_OK;
+}
+
+static int solve_mask(const sf_handle *h, int create_image_pyr) {
+    int m = ST_SOLVE;
+    if (create_image_pyr) m |= ST_PYR_NEW;
+    if (h->k.p.segmentation_enabled) m |= ST_KMEANS;
+    return m;
+}
+
+extern "C" {
+
+void sf_ctor_params(sf_params *p) {  // reference FrontEnd.cpp:57-76
+    std::memset(p, 0, sizeof(*p));
+    p->ctf_levels = 0;
+    p->max_iter_per_level = 2;
+    p->max_iter_irls = 10;
+    p->use_motion_filter = 0;
+    p->segmentation_enabled = 1;
+    p->debug_planes = 0;
+    p->fovh = float(M_PI * 62.5 / 180.0);
+    p->k_photometric_res = 0.15f;
+    p->irls_delta_threshold = 1e-6f;
+    p->previous_speed_const_weight = 0.05f;
+    p->previous_speed_eig_weight = 0.5f;
+    p->kc_Cauchy = 0.5f;
+    p->kb = 1.25f;
+    p->kz = 1.5f;
+    p->lambda_reg = 0.35f;
+    p->lambda_prior = 0.5f;
+}
+
+void sf_default_params(sf_params *p) {  // reference StaticFusion-datasets.cpp:79-94
+    sf_ctor_params(p);
+    p->use_motion_filter = 1;
+    p->max_iter_per_level = 3;
+    p->previous_speed_const_weight = 0.1f;
+    p->previous_speed_eig_weight = 2.f;
+    p->k_photometric_res = 0.15f;
+    p->irls_delta_threshold = 0.0015f;
+    p->max_iter_irls = 6;
+    p->lambda_reg = 0.35f;
+    p->lambda_prior = 0.5f;
+    p->kc_Cauchy = 0.5f;
+    p->kb = 1.5f;
+    p->kz = 1.5f;
+}
+
+const char *sf_last_error(void) { return g_err.c_str(); }
+const char *sf_backend(void) { return "hip:gfx950"; }
+
+static int validate_params(const sf_params *p, int levels) {
+    if (levels < 2 || levels > SF_MAX_LEVELS) return fail(SF_ERR_ARG, "ctf_levels must be in [2, 8]");
+    if (p->max_iter_per_level < 1 || p->max_iter_irls < 1 || levels * p->max_iter_per_level > SF_MAX_OUTER)
+        return fail(SF_ERR_ARG, "iteration counts out of range");
+    return SF_OK;
+}
+
+void sf_destroy(sf_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->evk0) (void)hipEventDestroy(h->evk0);
+    if (h->evk1) (void)hipEventDestroy(h->evk1);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int sf_create(const sf_params *p, int rows, int cols, int batch, int device, sf_handle **out) {
+    if (!p || !out || rows < 8 || cols < 8 || batch < 1) return fail(SF_ERR_ARG, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(SF_ERR_DEVICE, "no HIP device visible: libsf_hip.so has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(SF_ERR_ARG, "device ordinal out of range");
+    int levels = p->ctf_levels > 0 ? p->ctf_levels : int(std::log2(double(cols / 40)) + 2);  // FrontEnd.cpp:61
+    if (int e = validate_params(p, levels)) return e;
+    if ((rows >> (levels - 1)) < 3 || (cols >> (levels - 1)) < 3)
+        return fail(SF_ERR_ARG, "unsupported ctf_levels for this resolution");
+
+    sf_handle *h = new sf_handle;
+    h->device = device;
+    KArgs &k = h->k;
+    k.rows = rows;
+    k.cols = cols;
+    k.levels = levels;
+    k.batch = batch;
+    k.p = *p;
+    k.p.ctf_levels = levels;
+    k.tan_half_fovh = std::tan(0.5f * p->fovh);  // float overload, as in the reference
+    int off = 0;
+    for (int L = 0; L < levels; L++) {
+        const unsigned s = 1u << L;  // pow(2.f, int(i))
+        k.lrows[L] = rows / s;
+        k.lcols[L] = cols / s;
+        k.ln[L] = k.lrows[L] * k.lcols[L];
+        k.loff[L] = off;
+        off += k.ln[L];
+    }
+    k.n_tot = off;
+    k.n0 = k.ln[0];
+
+#define TRY_OR_FREE(expr)          \
+    do {                           \
+        int e_ = (expr);           \
+        if (e_ != SF_OK) {         \
+            sf_destroy(h);         \
+            return e_;             \
+        }                          \
+    } while (0)
+#define HIP_OR_FREE(expr)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            sf_destroy(h);                                                                       \
+            return fail(SF_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+        }                                                                                        \
+    } while (0)
+
+    HIP_OR_FREE(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_OR_FREE(hipGetDeviceProperties(&prop, device));
+    h->max_blocks = prop.multiProcessorCount * 2;
+    HIP_OR_FREE(hipStreamCreate(&h->own_stream));
+    h->stream = h->own_stream;
+    HIP_OR_FREE(hipEventCreate(&h->ev0));
+    HIP_OR_FREE(hipEventCreate(&h->ev1));
+    HIP_OR_FREE(hipEventCreate(&h->evk0));
+    HIP_OR_FREE(hipEventCreate(&h->evk1));
+
+    const size_t B = batch, NT = k.n_tot, N0 = k.n0, N1 = k.ln[1];
+    for (int c = 0; c < 4; c++) {
+        TRY_OR_FREE(dev_alloc(h, &k.pyr_new[c], B * NT));
+        TRY_OR_FREE(dev_alloc(h, &k.pyr_pred[c], B * NT));
+        if (p->debug_planes) {
+            TRY_OR_FREE(dev_alloc(h, &k.dbg_warped[c], B * NT));
+            TRY_OR_FREE(dev_alloc(h, &k.dbg_inter[c], B * NT));
+        }
+    }
+    TRY_OR_FREE(dev_alloc(h, &k.labels, B * NT));
+    TRY_OR_FREE(dev_alloc(h, &k.acc_d, B * N0));
+    TRY_OR_FREE(dev_alloc(h, &k.acc_i, B * N0));
+    TRY_OR_FREE(dev_alloc(h, &k.acc_w, B * N0));
+    for (int q = 0; q < R_COUNT; q++) TRY_OR_FREE(dev_alloc(h, &k.rec[q], B * N0));
+    TRY_OR_FREE(dev_alloc(h, &k.rec_lab, B * N0));
+    TRY_OR_FREE(dev_alloc(h, &k.rec_null, B * N0));
+    for (int c = 0; c < 3; c++) TRY_OR_FREE(dev_alloc(h, &k.km_sorted[c], B * N1));
+    TRY_OR_FREE(dev_alloc(h, &k.hist_d, (size_t)SF_HISTORY * B * N0));
+    TRY_OR_FREE(dev_alloc(h, &k.hist_i, (size_t)SF_HISTORY * B * N0));
+    TRY_OR_FREE(dev_alloc(h, &k.b_img, B * N0));
+    TRY_OR_FREE(dev_alloc(h, &k.state, B));
+    TRY_OR_FREE(dev_alloc(h, &k.stats, B));
+    TRY_OR_FREE(dev_alloc(h, &k.queue, (size_t)1));
+    TRY_OR_FREE(dev_alloc(h, &h->d_args, (size_t)1));
+
+    // constructor state (reference FrontEnd.cpp:79-81,110,152-154)
+    std::vector<StreamState> st(B);
+    std::memset(st.data(), 0, B * sizeof(StreamState));
+    for (auto &s : st) {
+        for (int q = 0; q < 16; q++) s.T[q] = (q % 5 == 0) ? 1.f : 0.f;
+        for (int l = 0; l < SF_NC; l++) {
+            s.b_segm[l] = 0.5f;
+            s.conn[l] = 1u << l;
+            s.cluster_res[l] = std::nanf("");
+        }
+        for (int i = 0; i < SF_HISTORY; i++)
+            for (int q = 0; q < 16; q++) s.hist_T[i][q] = (q % 5 == 0) ? 1.f : 0.f;
+        s.kb = p->kb;
+    }
+    HIP_OR_FREE(hipMemcpy(k.state, st.data(), B * sizeof(StreamState), hipMemcpyHostToDevice));
+    {
+        std::vector<float> half(B * N0, 0.5f);  // b_segm_perpixel.fill(0.5f)
+        HIP_OR_FREE(hipMemcpy(k.b_img, half.data(), B * N0 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    *out = h;
+    return SF_OK;
+}
+
+int sf_set_params(sf_handle *h, const sf_params *p) {
+    if (!h || !p) return fail(SF_ERR_ARG, "null");
+    int levels = p->ctf_levels > 0 ? p->ctf_levels : h->k.levels;
+    if (levels > h->k.levels) return fail(SF_ERR_ARG, "ctf_levels exceeds the allocated pyramid");
+    if (int e = validate_params(p, levels)) return e;
+    if (p->debug_planes && !h->k.dbg_warped[0]) return fail(SF_ERR_ARG, "debug_planes must be set at sf_create");
+    if (levels != h->k.levels) return fail(SF_ERR_ARG, "ctf_levels cannot change after sf_create");
+    const float kb_old = h->k.p.kb;
+    h->k.p = *p;
+    h->k.p.ctf_levels = levels;
+    h->k.tan_half_fovh = std::tan(0.5f * p->fovh);
+    h->args_dirty = true;
+    if (p->kb != kb_old) return sf_set_kb(h, -1, p->kb);
+    return SF_OK;
+}
+int sf_get_params(const sf_handle *h, sf_params *p) {
+    if (!h || !p) return fail(SF_ERR_ARG, "null");
+    *p = h->k.p;
+    return SF_OK;
+}
+
+static int check_stream(const sf_handle *h, int stream) {
+    if (!h) return fail(SF_ERR_ARG, "null handle");
+    if (stream < 0 || stream >= h->k.batch) return fail(SF_ERR_ARG, "stream out of range");
+    return SF_OK;
+}
+
+int sf_set_kb(sf_handle *h, int stream, float kb) {
+    if (!h || stream < -1 || stream >= h->k.batch) return fail(SF_ERR_ARG, "bad stream");
+    HIP_TRY(hipSetDevice(h->device));
+    for (int b = 0; b < h->k.batch; b++)
+        if (stream < 0 || stream == b)
+            HIP_TRY(hipMemcpyAsync(&h->k.state[b].kb, &kb, sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));  // kb is a stack variable
+    if (stream < 0) h->k.p.kb = kb;
+    return SF_OK;
+}
+int sf_set_hip_stream(sf_handle *h, void *hip_stream) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return SF_OK;
+}
+int sf_synchronize(sf_handle *h) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SF_OK;
+}
+
+static int upload_pair(sf_handle *h, float *const *set, int stream, const float *depth, const float *intensity) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!depth || !intensity) return fail(SF_ERR_ARG, "null image");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t bytes = sizeof(float) * h->k.n0, o = (size_t)stream * h->k.n_tot;
+    HIP_TRY(hipMemcpyAsync(set[0] + o, depth, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(set[1] + o, intensity, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));  // the caller may reuse its buffers on return
+    return SF_OK;
+}
+// depthCurrent / intensityCurrent ARE level 0 of the new pyramid (createImagePyramid copies them there)
+int sf_set_current(sf_handle *h, int stream, const float *depth, const float *intensity) {
+    return h ? upload_pair(h, h->k.pyr_new, stream, depth, intensity) : fail(SF_ERR_ARG, "null");
+}
+int sf_set_prediction(sf_handle *h, int stream, const float *depth, const float *intensity) {
+    return h ? upload_pair(h, h->k.pyr_pred, stream, depth, intensity) : fail(SF_ERR_ARG, "null");
+}
+static int copy_batch_device(sf_handle *h, float *const *set, const void *d, const void *i) {
+    if (!h || !d || !i) return fail(SF_ERR_ARG, "null");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t w = sizeof(float) * h->k.n0;
+    HIP_TRY(hipMemcpy2DAsync(set[0], sizeof(float) * h->k.n_tot, d, w, w, h->k.batch, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpy2DAsync(set[1], sizeof(float) * h->k.n_tot, i, w, w, h->k.batch, hipMemcpyDeviceToDevice, h->stream));
+    return SF_OK;
+}
+int sf_set_current_device(sf_handle *h, const void *d, const void *i) {
+    return h ? copy_batch_device(h, h->k.pyr_new, d, i) : fail(SF_ERR_ARG, "null");
+}
+int sf_set_prediction_device(sf_handle *h, const void *d, const void *i) {
+    return h ? copy_batch_device(h, h->k.pyr_pred, d, i) : fail(SF_ERR_ARG, "null");
+}
+int sf_current_to_prediction(sf_handle *h) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t w = sizeof(float) * h->k.n0, pitch = sizeof(float) * h->k.n_tot;
+    for (int c = 0; c < 2; c++)
+        HIP_TRY(hipMemcpy2DAsync(h->k.pyr_pred[c], pitch, h->k.pyr_new[c], pitch, w, h->k.batch, hipMemcpyDeviceToDevice,
+                                 h->stream));
+    return SF_OK;
+}
+int sf_set_twist_old(sf_handle *h, int stream, const float twist[6]) {
+    if (int e = check_stream(h, stream)) return e;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->k.state[stream].twist_old, twist, 6 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SF_OK;
+}
+
+int sf_build_pyramid(sf_handle *h, int old_im) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    return launch(h, old_im ? ST_PYR_OLD : ST_PYR_NEW, 0);
+}
+int sf_kmeans(sf_handle *h) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    return launch(h, ST_KMEANS, 0);
+}
+int sf_run_solver(sf_handle *h, int create_image_pyr) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    return launch(h, solve_mask(h, create_image_pyr), 0);
+}
+int sf_push_history(sf_handle *h, int im_count) {
+    if (!h || im_count < 0) return fail(SF_ERR_ARG, "bad argument");
+    return launch(h, ST_PUSH_HISTORY, im_count);
+}
+int sf_residuals_vs_history(sf_handle *h, int index) {
+    if (!h || index < SF_HISTORY) return fail(SF_ERR_ARG, "index must be >= 5");
+    return launch(h, ST_RESIDUALS, index);
+}
+int sf_build_segm_image(sf_handle *h) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    return launch(h, ST_SEGM_IMAGE, 0);
+}
+int sf_process_frame(sf_handle *h, int im_count) {
+    if (!h || im_count < 0) return fail(SF_ERR_ARG, "bad argument");
+    int m = ST_PYR_OLD | solve_mask(h, 1) | ST_SEGM_IMAGE | ST_PUSH_HISTORY;
+    if (im_count - SF_HISTORY >= 0) m |= ST_RESIDUALS;
+    return launch(h, m, im_count);
+}
+
+// ---- getters (synchronise the handle's stream, then copy) ----------------------------------
+static int d2h(sf_handle *h, void *dst, const void *src, size_t bytes) {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return SF_OK;
+}
+int sf_get_T(sf_handle *h, int stream, float T[16]) {
+    if (int e = check_stream(h, stream)) return e;
+    return d2h(h, T, h->k.state[stream].T, 16 * sizeof(float));
+}
+int sf_get_twist(sf_handle *h, int stream, float t[6]) {
+    if (int e = check_stream(h, stream)) return e;
+    return d2h(h, t, h->k.state[stream].twist, 6 * sizeof(float));
+}
+int sf_get_twist_old(sf_handle *h, int stream, float t[6]) {
+    if (int e = check_stream(h, stream)) return e;
+    return d2h(h, t, h->k.state[stream].twist_old, 6 * sizeof(float));
+}
+int sf_get_b(sf_handle *h, int stream, float b[SF_NUM_CLUSTERS]) {
+    if (int e = check_stream(h, stream)) return e;
+    return d2h(h, b, h->k.state[stream].b_segm, SF_NC * sizeof(float));
+}
+int sf_get_b_image(sf_handle *h, int stream, float *out) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!out) return fail(SF_ERR_ARG, "null");
+    return d2h(h, out, h->k.b_img + (size_t)stream * h->k.n0, sizeof(float) * h->k.n0);
+}
+int sf_get_labels(sf_handle *h, int stream, int level, int32_t *out) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!out || level < 0 || level >= h->k.levels) return fail(SF_ERR_ARG, "bad level");
+    std::vector<uint8_t> tmp(h->k.ln[level]);
+    if (int e = d2h(h, tmp.data(), h->k.labels + (size_t)stream * h->k.n_tot + h->k.loff[level], tmp.size())) return e;
+    for (size_t q = 0; q < tmp.size(); q++) out[q] = tmp[q];
+    return SF_OK;
+}
+int sf_get_kmeans(sf_handle *h, int stream, float c[3 * SF_NUM_CLUSTERS]) {
+    if (int e = check_stream(h, stream)) return e;
+    return d2h(h, c, h->k.state[stream].kmeans, 3 * SF_NC * sizeof(float));
+}
+int sf_get_connectivity(sf_handle *h, int stream, uint8_t conn[SF_NUM_CLUSTERS * SF_NUM_CLUSTERS]) {
+    if (int e = check_stream(h, stream)) return e;
+    uint32_t rows[SF_NC];
+    if (int e = d2h(h, rows, h->k.state[stream].conn, sizeof(rows))) return e;
+    for (int i = 0; i < SF_NC; i++)
+        for (int j = 0; j < SF_NC; j++) conn[i * SF_NC + j] = (rows[i] >> j) & 1u;
+    return SF_OK;
+}
+int sf_get_cluster_residuals(sf_handle *h, int stream, float r[SF_NUM_CLUSTERS]) {
+    if (int e = check_stream(h, stream)) return e;
+    return d2h(h, r, h->k.state[stream].cluster_res, SF_NC * sizeof(float));
+}
+int sf_get_stats(sf_handle *h, int stream, sf_frame_stats *out) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!out) return fail(SF_ERR_ARG, "null");
+    return d2h(h, out, &h->k.stats[stream], sizeof(sf_frame_stats));
+}
+int sf_get_batch_results(sf_handle *h, float *T, int32_t *n_irls, int32_t *n_outer, int64_t *pixel_iters) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    const int B = h->k.batch;
+    if (T) {
+        std::vector<StreamState> st(B);
+        if (int e = d2h(h, st.data(), h->k.state, B * sizeof(StreamState))) return e;
+        for (int b = 0; b < B; b++) std::memcpy(T + 16 * b, st[b].T, 16 * sizeof(float));
+    }
+    if (n_irls || n_outer || pixel_iters) {
+        std::vector<sf_frame_stats> fs(B);
+        if (int e = d2h(h, fs.data(), h->k.stats, B * sizeof(sf_frame_stats))) return e;
+        for (int b = 0; b < B; b++) {
+            if (n_irls) n_irls[b] = fs[b].n_irls;
+            if (n_outer) n_outer[b] = fs[b].n_outer;
+            if (pixel_iters) pixel_iters[b] = fs[b].pixel_iters;
+        }
+    }
+    return SF_OK;
+}
+
+int sf_get_plane(sf_handle *h, int stream, int set, int channel, int level, float *out) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!out || level < 0 || level >= h->k.levels || set < 0 || set > 3 || channel < 0 || channel > 3)
+        return fail(SF_ERR_ARG, "bad selector");
+    float *const *tab[4] = {h->k.pyr_new, h->k.pyr_pred, h->k.dbg_warped, h->k.dbg_inter};
+    const float *base = tab[set][channel];
+    if (!base) return fail(SF_ERR_STATE, "WARPED / INTER planes need params.debug_planes = 1 at sf_create");
+    return d2h(h, out, base + (size_t)stream * h->k.n_tot + h->k.loff[level], sizeof(float) * h->k.ln[level]);
+}
+
+int sf_get_lin_plane(sf_handle *h, int stream, int which, float *out, int *rows, int *cols) {
+    if (int e = check_stream(h, stream)) return e;
+    if (which < 0 || which >= SF_LIN_COUNT) return fail(SF_ERR_ARG, "bad selector");
+    StreamState st;
+    if (int e = d2h(h, &st, &h->k.state[stream], sizeof(st))) return e;
+    const int L = st.last_level;
+    if (L < 0 || L >= h->k.levels) return fail(SF_ERR_STATE, "no outer iteration executed yet");
+    if (rows) *rows = h->k.lrows[L];
+    if (cols) *cols = h->k.lcols[L];
+    if (!out) return SF_OK;
+    const size_t n = h->k.ln[L], o = (size_t)stream * h->k.n0;
+    if (which == SF_LIN_NULL) {
+        std::vector<uint8_t> tmp(n);
+        if (int e = d2h(h, tmp.data(), h->k.rec_null + o, n)) return e;
+        for (size_t q = 0; q < n; q++) out[q] = tmp[q] ? 1.f : 0.f;
+        return SF_OK;
+    }
+    static const int plane_of[SF_LIN_COUNT] = {R_DCU, R_DCV, R_DCT, R_DDU, R_DDV, R_DDT, R_WC, R_WD, -1};
+    if (int e = d2h(h, out, h->k.rec[plane_of[which]] + o, sizeof(float) * n)) return e;
+    if (which == SF_LIN_WC || which == SF_LIN_WD) {  // weights_c = inv_max_c*weights_c (reference :505-509)
+        const float inv_max = (which == SF_LIN_WC) ? st.inv_max_c : st.inv_max_d;
+        for (size_t q = 0; q < n; q++) out[q] = inv_max * out[q];
+    }
+    return SF_OK;
+}
+
+int sf_level_rows(const sf_handle *h, int level) { return (h && level >= 0 && level < h->k.levels) ? h->k.lrows[level] : 0; }
+int sf_level_cols(const sf_handle *h, int level) { return (h && level >= 0 && level < h->k.levels) ? h->k.lcols[level] : 0; }
+int sf_batch(const sf_handle *h) { return h ? h->k.batch : 0; }
+
+int sf_timed_process_frames(sf_handle *h, int im_count, int calls, float *elapsed_ms) {
+    if (!h || calls < 1) return fail(SF_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    for (int c = 0; c < calls; c++)
+        if (int e = sf_process_frame(h, im_count)) return e;
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    return SF_OK;
+}
+int sf_last_solver_kernel_ms(sf_handle *h, float *ms) {
+    if (!h || !ms) return fail(SF_ERR_ARG, "null");
+    if (!h->solver_timed) return fail(SF_ERR_STATE, "no solver launch yet");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventSynchronize(h->evk1));
+    HIP_TRY(hipEventElapsedTime(ms, h->evk0, h->evk1));
+    return SF_OK;
+}
+
+}  // extern "C"

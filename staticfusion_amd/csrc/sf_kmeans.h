@@ -1,0 +1,361 @@
+// sf_kmeans.h — geometric clustering of one stream: K-means(24) on (z, x, y), region connectivity,
+// label pyramid.  Replaces initializeKMeans / kMeans3DCoord / computeRegionConnectivity /
+// createClustersPyramidUsingKMeans (reference KMeans.cpp:63-391).
+//
+// Bit-exact labels need the reference's SEQUENTIAL float32 centre sums (KMeans.cpp:215-221, pixels
+// in column-major order).  The assignment step is data parallel; the centre update is made
+// parallel across the 72 (cluster, coordinate) sums while each sum stays strictly sequential:
+//   pass A  assign labels, count members per (wave range, label) with ballots
+//   scan    exclusive offsets per (wave range, label)
+//   pass B  stable partition: write (z,x,y) of every pixel to its cluster's contiguous run, in
+//           pixel order (rank = members in earlier wave ranges + earlier iterations + lower lanes)
+//   sum     lane (c, r) adds the run of cluster c, coordinate r, front to back
+// The per-seed median depth (std::nth_element at size/2, KMeans.cpp:104-123) is an exact
+// 4 x 8-bit radix select on the float bit patterns.
+// The sorted centre-distance lists (std::sort, KMeans.cpp:172-183) use a stable rank sort; it
+// equals std::sort whenever no two distances in a row are exactly equal.
+#pragma once
+
+#include "sf_device_common.h"
+
+struct KmShared {
+    float cent_a[3 * SF_NC], cent_b[3 * SF_NC];
+    float sdist[SF_NC * SF_NC];    // row l: distances to the other centres, ascending
+    uint8_t sidx[SF_NC * SF_NC];   // row l: centre index at each sorted position
+    float pair_dist[SF_NC * SF_NC];
+    int wcnt[SF_NW][SF_NC];        // members per (wave range, label); then exclusive offsets
+    int count[SF_NC];
+    int off[SF_NC];
+    unsigned conn[SF_NC];
+    unsigned useed[SF_NC], vseed[SF_NC];
+    unsigned prefix[SF_NC], krank[SF_NC];
+    unsigned hist[SF_NC * 256];
+    float red[SF_NW];
+    int stop;
+};
+
+__device__ __forceinline__ float sqdist3(float a0, float a1, float a2, float b0, float b1, float b2) {
+    const float d0 = a0 - b0, d1 = a1 - b1, d2 = a2 - b2;
+    return (d0 * d0 + d1 * d1) + d2 * d2;
+}
+
+// pairwise centre distances + per-row stable rank sort (KMeans.cpp:172-183)
+__device__ __noinline__ void km_sort_centres(KmShared &s, int tid) {
+    for (int q = tid; q < SF_NC * SF_NC; q += SF_NT) {
+        const int l = q / SF_NC, li = q - l * SF_NC;
+        s.pair_dist[q] = sqdist3(s.cent_a[3 * l], s.cent_a[3 * l + 1], s.cent_a[3 * l + 2], s.cent_a[3 * li],
+                                 s.cent_a[3 * li + 1], s.cent_a[3 * li + 2]);
+    }
+    __syncthreads();
+    for (int q = tid; q < SF_NC * SF_NC; q += SF_NT) {
+        const int l = q / SF_NC, li = q - l * SF_NC;
+        const float d = s.pair_dist[q];
+        int rank = 0;
+        for (int lj = 0; lj < SF_NC; lj++) {
+            const float dj = s.pair_dist[l * SF_NC + lj];
+            rank += (dj < d || (dj == d && lj < li)) ? 1 : 0;
+        }
+        s.sdist[l * SF_NC + rank] = d;
+        s.sidx[l * SF_NC + rank] = (uint8_t)li;
+    }
+    __syncthreads();
+}
+
+// pruned nearest-centre search starting from `last` (KMeans.cpp:196-212 and :263-285)
+__device__ __forceinline__ int km_search(const KmShared &s, int last, float pz, float px, float py) {
+    int best = last;
+    const float d_last = sqdist3(s.cent_a[3 * last], s.cent_a[3 * last + 1], s.cent_a[3 * last + 2], pz, px, py);
+    float best_d = d_last;
+    for (int li = 1; li < SF_NC; li++) {
+        const float cd = s.sdist[last * SF_NC + li];
+        if (cd > 4.f * d_last) break;
+        const int c = s.sidx[last * SF_NC + li];
+        const float dl = sqdist3(s.cent_a[3 * c], s.cent_a[3 * c + 1], s.cent_a[3 * c + 2], pz, px, py);
+        if (dl < best_d) {
+            best_d = dl;
+            best = c;
+        }
+    }
+    return best;
+}
+
+__device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const size_t sb = (size_t)b * a.n_tot;
+    const float *depth = a.pyr_new[0] + sb, *xx = a.pyr_new[2] + sb, *yy = a.pyr_new[3] + sb;
+    uint8_t *labels = a.labels + sb;
+    StreamState &st = a.state[b];
+
+    // ------------------------------------------------------------------ initializeKMeans (K1)
+    const int rows_km = a.lrows[1], cols_km = a.lcols[1], n1 = a.ln[1], o1 = a.loff[1];
+    if (tid < SF_NC) {
+        const unsigned vert_div = 5;  // ceil(sqrt(24))
+        const float u_div = float(cols_km) / float(SF_NC + 1);
+        const float v_div = float(rows_km) / float(vert_div + 1);
+        s.useed[tid] = (unsigned)roundf((unsigned)(tid + 1) * u_div);
+        s.vseed[tid] = (unsigned)roundf((unsigned)(tid % vert_div + 1) * v_div);
+        s.prefix[tid] = 0;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n1; idx += SF_NT) {
+        const unsigned u = idx / rows_km, v = idx - u * rows_km;
+        unsigned lab = SF_NC;
+        if (depth[o1 + idx] != 0.f) {
+            unsigned min_dist = 1000000u;
+            for (unsigned l = 0; l < SF_NC; l++) {
+                const unsigned dv = v - s.vseed[l], du = u - s.useed[l];  // unsigned wrap-around as in the reference
+                const unsigned q = dv * dv + du * du;
+                if (q < min_dist) {
+                    lab = l;
+                    min_dist = q;
+                }
+            }
+        }
+        labels[o1 + idx] = (uint8_t)lab;
+    }
+    __syncthreads();
+    // per-seed median depth: radix select, most significant byte first
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 24 - 8 * pass;
+        for (int q = tid; q < SF_NC * 256; q += SF_NT) s.hist[q] = 0;
+        __syncthreads();
+        for (int idx = tid; idx < n1; idx += SF_NT) {
+            const unsigned lab = labels[o1 + idx];
+            if (lab < SF_NC) {
+                const unsigned bits = __float_as_uint(depth[o1 + idx]);
+                if (pass == 0 || (bits >> (shift + 8)) == s.prefix[lab]) atomicAdd(&s.hist[lab * 256 + ((bits >> shift) & 255u)], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < SF_NC) {
+            if (pass == 0) {
+                unsigned size = 0;
+                for (int q = 0; q < 256; q++) size += s.hist[tid * 256 + q];
+                s.count[tid] = (int)size;
+                s.krank[tid] = size / 2;
+            }
+            if (s.count[tid] > 0) {
+                unsigned k = s.krank[tid], cum = 0;
+                int bin = 0;
+                for (; bin < 256; bin++) {
+                    const unsigned h = s.hist[tid * 256 + bin];
+                    if (cum + h > k) break;
+                    cum += h;
+                }
+                s.prefix[tid] = (s.prefix[tid] << 8) | (unsigned)bin;
+                s.krank[tid] = k - cum;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < SF_NC) {
+        const float inv_f_i = 2.f * a.tan_half_fovh / float(cols_km);
+        const float disp_u_i = 0.5f * (cols_km - 1);
+        const float disp_v_i = 0.5f * (rows_km - 1);
+        float z = 0.f, x = 0.f, y = 0.f;
+        if (s.count[tid] > 0) {
+            z = __uint_as_float(s.prefix[tid]);
+            x = (s.useed[tid] - disp_u_i) * z * inv_f_i;
+            y = (s.vseed[tid] - disp_v_i) * z * inv_f_i;
+        }
+        s.cent_a[3 * tid] = z;
+        s.cent_a[3 * tid + 1] = x;
+        s.cent_a[3 * tid + 2] = y;
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ Lloyd iterations (K2)
+    float *srt0 = a.km_sorted[0] + (size_t)b * n1, *srt1 = a.km_sorted[1] + (size_t)b * n1,
+          *srt2 = a.km_sorted[2] + (size_t)b * n1;
+    const int chunk = ((n1 + SF_NW - 1) / SF_NW + 63) & ~63;  // pixels per wave range, multiple of 64
+    const int w_begin = wave * chunk, w_end = min(n1, w_begin + chunk);
+    int iters = 0;
+    for (int it = 0; it < 9; it++) {
+        iters++;
+        km_sort_centres(s, tid);
+
+        // pass A: assignment + member counts of this wave range
+        int cnt = 0;  // lane l < 24 holds the count of label l
+        for (int base = w_begin; base < w_end; base += 64) {
+            const int idx = base + lane;
+            bool valid = false;
+            int best = 0;
+            if (idx < w_end) {
+                const float pz = depth[o1 + idx];
+                if (pz != 0.f) {
+                    valid = true;
+                    best = km_search(s, labels[o1 + idx], pz, xx[o1 + idx], yy[o1 + idx]);
+                    labels[o1 + idx] = (uint8_t)best;
+                }
+            }
+            unsigned long long rem = __ballot(valid);
+            while (rem) {
+                const int src = __ffsll((long long)rem) - 1;
+                const int l = __builtin_amdgcn_readlane(best, src);
+                const unsigned long long m = __ballot(valid && best == l);
+                if (lane == l) cnt += __popcll(m);
+                rem &= ~m;
+            }
+        }
+        if (lane < SF_NC) s.wcnt[wave][lane] = cnt;
+        __syncthreads();
+        if (tid < SF_NC) {
+            int run = 0;
+            for (int w = 0; w < SF_NW; w++) {
+                const int c = s.wcnt[w][tid];
+                s.wcnt[w][tid] = run;
+                run += c;
+            }
+            s.count[tid] = run;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int l = 0; l < SF_NC; l++) {
+                s.off[l] = run;
+                run += s.count[l];
+            }
+        }
+        __syncthreads();
+
+        // pass B: stable partition into per-cluster runs
+        int running = (lane < SF_NC) ? (s.off[lane] + s.wcnt[wave][lane]) : 0;
+        for (int base = w_begin; base < w_end; base += 64) {
+            const int idx = base + lane;
+            bool valid = false;
+            int lab = 0;
+            float pz = 0.f;
+            if (idx < w_end) {
+                pz = depth[o1 + idx];
+                if (pz != 0.f) {
+                    valid = true;
+                    lab = labels[o1 + idx];
+                }
+            }
+            unsigned long long rem = __ballot(valid);
+            while (rem) {
+                const int src = __ffsll((long long)rem) - 1;
+                const int l = __builtin_amdgcn_readlane(lab, src);
+                const unsigned long long m = __ballot(valid && lab == l);
+                const int start = __builtin_amdgcn_readlane(running, l);
+                if (valid && lab == l) {
+                    const int pos = start + __popcll(m & ((1ull << lane) - 1ull));
+                    srt0[pos] = pz;
+                    srt1[pos] = xx[o1 + idx];
+                    srt2[pos] = yy[o1 + idx];
+                }
+                if (lane == l) running += __popcll(m);
+                rem &= ~m;
+            }
+        }
+        __syncthreads();
+
+        // sequential float sums, one (cluster, coordinate) per lane (KMeans.cpp:215-221)
+        if (tid < 3 * SF_NC) {
+            const int c = tid / 3, r = tid - 3 * c;
+            const float *src = (r == 0 ? srt0 : (r == 1 ? srt1 : srt2)) + s.off[c];
+            const int n = s.count[c];
+            float acc = 0.f;
+            int j = 0;
+            for (; j + 4 <= n; j += 4) {
+                const float v0 = src[j], v1 = src[j + 1], v2 = src[j + 2], v3 = src[j + 3];
+                acc += v0;
+                acc += v1;
+                acc += v2;
+                acc += v3;
+            }
+            for (; j < n; j++) acc += src[j];
+            if (n > 0) acc /= float(n);
+            s.cent_b[tid] = acc;  // cent_b[r + 3c] with tid = 3c + r
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float dmax = 0.f;
+            for (int q = tid; q < 3 * SF_NC; q += 64) dmax = std_max(dmax, fabsf(s.cent_a[q] - s.cent_b[q]));
+            dmax = wave_max_f32(dmax);
+            if (tid == 0) s.stop = (dmax < 1e-2f) ? 1 : 0;
+        }
+        __syncthreads();
+        if (tid < 3 * SF_NC) s.cent_a[tid] = s.cent_b[tid];
+        const int stop = s.stop;
+        __syncthreads();
+        if (stop) break;
+    }
+    if (tid < 3 * SF_NC) st.kmeans[tid] = s.cent_a[tid];
+    if (tid == 0) a.stats[b].kmeans_iters = iters;
+
+    // ------------------------------------------------------------------ labels at full resolution
+    km_sort_centres(s, tid);
+    {
+        const int rows0 = a.lrows[0], n0 = a.ln[0];
+        for (int idx = tid; idx < n0; idx += SF_NT) {
+            const float pz = depth[idx];
+            int lab = SF_NC;
+            if (pz != 0.f) {
+                const int u = idx / rows0, v = idx - u * rows0;
+                const int low = labels[o1 + (v / 2) + (u / 2) * rows_km];
+                const int last = (low == SF_NC) ? 0 : low;
+                lab = km_search(s, last, pz, xx[idx], yy[idx]);
+            }
+            labels[idx] = (uint8_t)lab;
+        }
+    }
+    if (tid < SF_NC) s.conn[tid] = 1u << tid;
+    __syncthreads();
+
+    // ------------------------------------------------------------------ computeRegionConnectivity (K3)
+    {
+        const int rows0 = a.lrows[0], cols0 = a.lcols[0], n0 = a.ln[0];
+        const float dist2_threshold = sqf(0.03f * 120.f / float(rows0));
+        for (int idx = tid; idx < n0; idx += SF_NT) {
+            const int u = idx / rows0, v = idx - u * rows0;
+            if (u >= cols0 - 1 || v >= rows0 - 1) continue;
+            const float dz = depth[idx];
+            if (dz == 0.f) continue;
+            const int la = labels[idx];
+            const int ld = labels[idx + 1], lr = labels[idx + rows0];
+            if (la != ld && ld != SF_NC) {
+                const float disty = sqf(dz - depth[idx + 1]) + sqf(yy[idx] - yy[idx + 1]);
+                if (disty < dist2_threshold) {
+                    atomicOr(&s.conn[la], 1u << ld);
+                    atomicOr(&s.conn[ld], 1u << la);
+                }
+            }
+            if (la != lr && lr != SF_NC) {
+                const float distx = sqf(dz - depth[idx + rows0]) + sqf(xx[idx] - xx[idx + rows0]);
+                if (distx < dist2_threshold) {
+                    atomicOr(&s.conn[la], 1u << lr);
+                    atomicOr(&s.conn[lr], 1u << la);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < SF_NC) st.conn[tid] = s.conn[tid];
+
+    // ------------------------------------------------------------------ createClustersPyramidUsingKMeans (K4)
+    // pair_dist holds |kmeans_la - kmeans_lb|^2 from the last km_sort_centres (cent_a == kmeans)
+    for (int L = 2; L < a.levels; L++) {
+        const int n = a.ln[L], o = a.loff[L];
+        for (int idx = tid; idx < n; idx += SF_NT) {
+            const float pz = depth[o + idx];
+            int lab = SF_NC;
+            if (pz != 0.f) {
+                const float px = xx[o + idx], py = yy[o + idx];
+                int label = 0;
+                float min_dist = sqdist3(s.cent_a[0], s.cent_a[1], s.cent_a[2], pz, px, py);
+                for (int l = 1; l < SF_NC; l++) {
+                    if (s.pair_dist[label * SF_NC + l] > 4.f * min_dist) continue;
+                    const float dh = sqdist3(s.cent_a[3 * l], s.cent_a[3 * l + 1], s.cent_a[3 * l + 2], pz, px, py);
+                    if (dh < min_dist) {
+                        label = l;
+                        min_dist = dh;
+                    }
+                }
+                lab = label;
+            }
+            labels[o + idx] = (uint8_t)lab;
+        }
+    }
+    __syncthreads();
+}

@@ -1,0 +1,117 @@
+// sf_pyramid.h — depth / intensity / xx / yy pyramid of one stream.
+// Replaces StaticFusion::createImagePyramid (reference FrontEnd.cpp:256-391).
+// One output pixel per thread, column-major (v fastest) so that a wave reads and writes
+// consecutive addresses.  Every per-pixel expression keeps the reference's operation order
+// (-ffp-contract=off), which makes the planes bit-identical to the CPU path.
+#pragma once
+
+#include "sf_device_common.h"
+
+// convMask(k) = v_mask(i)*v_mask(j)/36.f with k = i + 4j  (reference FrontEnd.cpp:146-149)
+__device__ __forceinline__ float conv_mask(int k) {
+    const float vi = ((k & 3) == 0 || (k & 3) == 3) ? 1.f : 2.f;
+    const float vj = ((k >> 2) == 0 || (k >> 2) == 3) ? 1.f : 2.f;
+    return vi * vj / 36.f;
+}
+
+__device__ __noinline__ void stage_pyramid(const KArgs &a, int b, bool old_im, int tid) {
+    float *const *set = old_im ? a.pyr_pred : a.pyr_new;
+    float *depth = set[0] + (size_t)b * a.n_tot;
+    float *inten = set[1] + (size_t)b * a.n_tot;
+    float *xx = set[2] + (size_t)b * a.n_tot;
+    float *yy = set[3] + (size_t)b * a.n_tot;
+    const float max_depth_dif = 0.1f;
+
+    for (int L = 0; L < a.levels; L++) {
+        const int rows_i = a.lrows[L], cols_i = a.lcols[L], n = a.ln[L];
+        float *d_here = depth + a.loff[L], *i_here = inten + a.loff[L];
+        const float inv_f_i = 2.f * a.tan_half_fovh / float(cols_i);
+        const float disp_u_i = 0.5f * (cols_i - 1);
+        const float disp_v_i = 0.5f * (rows_i - 1);
+
+        if (L > 0) {
+            __syncthreads();  // level L-1 complete (written by this workgroup)
+            const float *d_prev = depth + a.loff[L - 1], *i_prev = inten + a.loff[L - 1];
+            const int rows_p = a.lrows[L - 1];
+            for (int idx = tid; idx < n; idx += SF_NT) {
+                const int u = idx / rows_i, v = idx - u * rows_i;
+                const int u2 = 2 * u, v2 = 2 * v;
+                float dout, iout;
+                if ((v > 0) && (v < rows_i - 1) && (u > 0) && (u < cols_i - 1)) {
+                    float db[16], ib[16];
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int src = (v2 - 1 + r) + (u2 - 1 + c) * rows_p;
+                            db[r + 4 * c] = d_prev[src];
+                            ib[r + 4 * c] = i_prev[src];
+                        }
+                    float d0 = db[5], d1 = db[6], d2 = db[9], d3 = db[10];
+                    if (d1 < d0) { const float t = d1; d1 = d0; d0 = t; }
+                    if (d3 < d2) { const float t = d3; d3 = d2; d2 = t; }
+                    const float dcenter = (d3 < d1) ? std_max(d3, d0) : std_max(d1, d2);
+                    if (dcenter != 0.f) {
+                        float sum_d = 0.f, sum_c = 0.f, weight = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const float abs_dif = fabsf(db[k] - dcenter);
+                            if (abs_dif < max_depth_dif) {
+                                const float aux_w = conv_mask(k) * (max_depth_dif - abs_dif);
+                                weight += aux_w;
+                                sum_d += aux_w * db[k];
+                                sum_c += aux_w * ib[k];
+                            }
+                        }
+                        dout = sum_d / weight;
+                        iout = sum_c / weight;
+                    } else {
+                        float lane4[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const float m0 = conv_mask(j) * ib[j];
+                            const float m1 = conv_mask(4 + j) * ib[4 + j];
+                            const float m2 = conv_mask(8 + j) * ib[8 + j];
+                            const float m3 = conv_mask(12 + j) * ib[12 + j];
+                            lane4[j] = (m0 + m1) + (m2 + m3);
+                        }
+                        iout = (lane4[0] + lane4[2]) + (lane4[1] + lane4[3]);
+                        dout = 0.f;
+                    }
+                } else {
+                    float db[4], ib[4];
+#pragma unroll
+                    for (int c = 0; c < 2; c++)
+#pragma unroll
+                        for (int r = 0; r < 2; r++) {
+                            const int src = (v2 + r) + (u2 + c) * rows_p;
+                            db[r + 2 * c] = d_prev[src];
+                            ib[r + 2 * c] = i_prev[src];
+                        }
+                    iout = 0.25f * ((ib[0] + ib[2]) + (ib[1] + ib[3]));
+                    float new_d = 0.f;
+                    unsigned cont = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (db[k] != 0.f) {
+                            new_d += db[k];
+                            cont++;
+                        }
+                    dout = (cont != 0) ? new_d / float(cont) : 0.f;
+                }
+                d_here[idx] = dout;
+                i_here[idx] = iout;
+                xx[a.loff[L] + idx] = (inv_f_i * (float(u) - disp_u_i)) * dout;
+                yy[a.loff[L] + idx] = (inv_f_i * (float(v) - disp_v_i)) * dout;
+            }
+        } else {
+            for (int idx = tid; idx < n; idx += SF_NT) {
+                const int u = idx / rows_i, v = idx - u * rows_i;
+                const float dd = d_here[idx];
+                xx[idx] = (inv_f_i * (float(u) - disp_u_i)) * dd;
+                yy[idx] = (inv_f_i * (float(v) - disp_v_i)) * dd;
+            }
+        }
+    }
+    __syncthreads();
+}

@@ -1,0 +1,171 @@
+// sf_residuals.h — the stages that follow runSolver in the drivers' frame loop:
+//   computeResidualsAgainstPreviousImage  (reference FrontEnd.cpp:896-1069)
+//   buildSegmImage                        (reference SegmentationBackground.cpp:176-197)
+//   ring-buffer push                      (reference StaticFusion-datasets.cpp:182-184)
+#pragma once
+
+#include "sf_device_common.h"
+#include "sf_smallmath.h"
+
+struct ResShared {
+    float Tinv[16];
+    long long lab_sum[SF_NC];
+    int lab_cnt[SF_NC];
+    double dwork[32];
+};
+
+__device__ __forceinline__ int level0_label(const KArgs &a, const uint8_t *labels0, int idx) {
+    // without segmentation the reference's clusterAllocation[0] stays at its constructor value 0
+    return a.p.segmentation_enabled ? (int)labels0[idx] : 0;
+}
+
+__device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, ResShared &s, int tid) {
+    const int lane = tid & 63;
+    StreamState &st = a.state[b];
+    const int rows = a.lrows[0], cols = a.lcols[0], n = a.ln[0];
+    const size_t sb = (size_t)b * a.n_tot, rb = (size_t)b * a.n0;
+    const float *dcur = a.pyr_new[0] + sb, *icur = a.pyr_new[1] + sb;  // depthCurrent / intensityCurrent
+    const uint8_t *labels0 = a.labels + sb;
+    const int idx_to_warp = (index - SF_HISTORY) % SF_HISTORY;
+    const float *dbuf = a.hist_d + ((size_t)idx_to_warp * a.batch + b) * a.n0;
+    const float *ibuf = a.hist_i + ((size_t)idx_to_warp * a.batch + b) * a.n0;
+    long long *acc_d = a.acc_d + rb, *acc_i = a.acc_i + rb;
+    uint32_t *acc_w = a.acc_w + rb;
+
+    if (tid == 0) {
+        // T = prod odomBuffer[(index-4 .. index-1) % 5] * T_odometry, then inverse (:901-909)
+        float T[16], Tn[16];
+        for (int q = 0; q < 16; q++) T[q] = (q % 5 == 0) ? 1.f : 0.f;
+        for (int i = index - SF_HISTORY + 1; i < index; i++) {
+            mul4_cm(T, st.hist_T[i % SF_HISTORY], Tn);
+            for (int q = 0; q < 16; q++) T[q] = Tn[q];
+        }
+        mul4_cm(T, st.T, Tn);
+        inverse4_cm(Tn, s.Tinv, s.dwork);
+    }
+    if (tid < SF_NC) {
+        s.lab_sum[tid] = 0;
+        s.lab_cnt[tid] = 0;
+    }
+    for (int idx = tid; idx < n; idx += SF_NT) {
+        acc_d[idx] = 0;
+        acc_i[idx] = 0;
+        acc_w[idx] = 0;
+    }
+    __syncthreads();
+
+    const float inv_f_i = 2.f * a.tan_half_fovh / float(cols);
+    const float disp_u_i = 0.5f * (cols - 1);
+    const float disp_v_i = 0.5f * (rows - 1);
+    const float f = float(cols) / (2.f * a.tan_half_fovh);
+    const int cols_lim = 100 * (cols - 1);
+    const int rows_lim = 100 * (rows - 1);
+    float T[12];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) T[r * 4 + c] = s.Tinv[r + 4 * c];
+
+    for (int idx = tid; idx < n; idx += SF_NT) {
+        const float z = dbuf[idx];
+        if (!(z != 0.f && dcur[idx] != 0.f)) continue;
+        const int u = idx / rows, v = idx - u * rows;
+        const float xb = (inv_f_i * (float(u) - disp_u_i)) * z;  // xxBuffer / yyBuffer (:922-926)
+        const float yb = (inv_f_i * (float(v) - disp_v_i)) * z;
+        const float intensity_w = ibuf[idx];
+        const float x_w = T[0] * xb + T[1] * yb + T[2] * z + T[3];
+        const float y_w = T[4] * xb + T[5] * yb + T[6] * z + T[7];
+        const float depth_w = T[8] * xb + T[9] * yb + T[10] * z + T[11];
+        const int uwarp = cvt_trunc_x86(100.f * (f * x_w / depth_w + disp_u_i));
+        const int vwarp = cvt_trunc_x86(100.f * (f * y_w / depth_w + disp_v_i));
+        if (!((uwarp >= 0) && (uwarp < cols_lim) && (vwarp >= 0) && (vwarp < rows_lim))) continue;
+        const int uwarp_l = uwarp - uwarp % 100, uwarp_r = uwarp_l + 100;
+        const int vwarp_d = vwarp - vwarp % 100, vwarp_u = vwarp_d + 100;
+        const int delta_r = uwarp_r - uwarp, delta_l = 100 - delta_r;
+        const int delta_u = vwarp_u - vwarp, delta_d = 100 - delta_u;
+        const long long dfix = to_fix(depth_w, FIX_DEPTH, 1000.f);
+        const long long ifix = to_fix(intensity_w, FIX_INTENS, 4.f);
+        auto splat = [&](int vv, int uu, int w) {
+            const int t = vv + uu * rows;
+            atomicAdd((unsigned long long *)&acc_d[t], (unsigned long long)((long long)w * dfix));
+            atomicAdd((unsigned long long *)&acc_i[t], (unsigned long long)((long long)w * ifix));
+            atomicAdd(&acc_w[t], (uint32_t)w);
+        };
+        if (min(delta_r, delta_l) + min(delta_u, delta_d) < 5) {
+            splat(delta_u > delta_d ? vwarp_d / 100 : vwarp_u / 100, delta_r > delta_l ? uwarp_l / 100 : uwarp_r / 100, 200);
+        } else {
+            const int v_d = vwarp_d / 100, u_l = uwarp_l / 100;
+            splat(v_d + 1, u_l + 1, delta_l + delta_d);
+            splat(v_d + 1, u_l, delta_r + delta_d);
+            splat(v_d, u_l + 1, delta_l + delta_u);
+            splat(v_d, u_l, delta_r + delta_u);
+        }
+    }
+    __syncthreads();
+
+    // residuals, cluster-wise (:1036-1068)
+    const float kph = a.p.k_photometric_res;
+    for (int base = 0; base < n; base += SF_NT) {
+        const int idx = base + tid;
+        bool ok = false;
+        int lab = 0;
+        long long fx = 0;
+        if (idx < n) {
+            const uint32_t w = __hip_atomic_load(&acc_w[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float dc = dcur[idx];
+            if (w != 0 && dc != 0.f) {
+                const long long sd = __hip_atomic_load(&acc_d[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long si = __hip_atomic_load(&acc_i[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float dw = (float)(((double)sd * (1.0 / 67108864.0)) / (double)w);
+                const float iw = (float)(((double)si * (1.0 / 1073741824.0)) / (double)w);
+                if (dw != 0.f) {
+                    // intensity_diff is intensityCurrent where both depths are valid, else 0 (:937,1022)
+                    const float idiff = (dbuf[idx] != 0.f) ? icur[idx] : 0.f;
+                    const float cumulative = fabsf(dc - dw) + kph * fabsf(idiff - iw);
+                    ok = true;
+                    lab = level0_label(a, labels0, idx);
+                    fx = to_fix(cumulative, FIX_RES, 1.0e6f);
+                }
+            }
+        }
+        ok = ok && lab < SF_NC;
+        wave_label_add_i64(ok, lab, fx, s.lab_sum, lane);
+        wave_label_count(ok, lab, s.lab_cnt, lane);
+    }
+    __syncthreads();
+    if (tid < SF_NC) {
+        const int c = s.lab_cnt[tid];
+        const float sum = (float)((double)s.lab_sum[tid] * (1.0 / 4294967296.0));
+        st.cluster_res[tid] = (c > 0) ? sum / float(2 * (c + 1)) : __int_as_float(0x7fc00000);
+    }
+    __syncthreads();
+}
+
+__device__ __noinline__ void stage_segm_image(const KArgs &a, int b, int tid) {
+    const StreamState &st = a.state[b];
+    const int n = a.ln[0];
+    const uint8_t *labels0 = a.labels + (size_t)b * a.n_tot;
+    float *out = a.b_img + (size_t)b * a.n0;
+    for (int idx = tid; idx < n; idx += SF_NT) {
+        const int lab = level0_label(a, labels0, idx);
+        float bb = 1.f;  // "assume static for invalid cluster"
+        if (lab != SF_NC) {
+            bb = std_max(0.f, std_min(1.f, st.b_segm[lab]));
+            if ((double)st.cluster_res[lab] < 0.017) bb = std_max(bb, 1.0f - bb);
+        }
+        out[idx] = bb;
+    }
+}
+
+__device__ __noinline__ void stage_push_history(const KArgs &a, int b, int im_count, int tid) {
+    StreamState &st = a.state[b];
+    const int slot = im_count % SF_HISTORY, n = a.ln[0];
+    const float *dcur = a.pyr_new[0] + (size_t)b * a.n_tot, *icur = a.pyr_new[1] + (size_t)b * a.n_tot;
+    float *dbuf = a.hist_d + ((size_t)slot * a.batch + b) * a.n0;
+    float *ibuf = a.hist_i + ((size_t)slot * a.batch + b) * a.n0;
+    for (int idx = tid; idx < n; idx += SF_NT) {
+        dbuf[idx] = dcur[idx];
+        ibuf[idx] = icur[idx];
+    }
+    if (tid < 16) st.hist_T[slot][tid] = st.T[tid];
+}

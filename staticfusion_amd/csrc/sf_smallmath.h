@@ -1,0 +1,334 @@
+// sf_smallmath.h — the small dense algebra of the solver, on device.
+//
+//  * pivoted LDL^T (float) of the 6x6 normal equations (reference FrontEnd.cpp:642) and of the
+//    24x24 segmentation system (reference SegmentationBackground.cpp:168): one wave, one matrix
+//    row per lane, matrix in LDS.  Every element is updated with the same operation sequence
+//    as a scalar unblocked left-looking LDL^T with diagonal pivoting (Eigen's algorithm), so the
+//    result does not depend on the lane count.
+//  * 6x6 inverse, symmetric 6x6 eigen-decomposition (cyclic Jacobi), SE(3) exp / log, 4x4 and
+//    3x3 inverse in double on one lane (reference FrontEnd.cpp:689,719-771,800,1139-1144) — a few
+//    thousand flops per outer iteration, off the streaming path.
+#pragma once
+
+#include "sf_device_common.h"
+
+// ---------------------------------------------------------------------------------------------
+//  wave-parallel pivoted LDL^T.  M is [N][N+1] floats in LDS (lower triangle used).
+//  Must be called by all 64 lanes of ONE wave.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ inline bool ldlt_factor_wave(volatile float *M, volatile float *temp, volatile int *transp, int lane) {
+    constexpr int LD = N + 1;
+    bool all_zero = false;
+#pragma unroll 1
+    for (int k = 0; k < N; k++) {
+        // largest |diagonal| of the trailing block; the first maximum wins
+        float a = (lane >= k && lane < N) ? fabsf(M[lane * LD + lane]) : -1.f;
+        int idx = lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float a2 = __shfl_xor(a, o, 64);
+            const int i2 = __shfl_xor(idx, o, 64);
+            if (a2 > a || (a2 == a && i2 < idx)) {
+                a = a2;
+                idx = i2;
+            }
+        }
+        const int big = __builtin_amdgcn_readfirstlane(idx);
+        if (lane == 0) transp[k] = big;
+        if (big != k) {  // symmetric swap on the lower triangle: four disjoint element sets
+            if (lane < k) {
+                const float t = M[k * LD + lane];
+                M[k * LD + lane] = M[big * LD + lane];
+                M[big * LD + lane] = t;
+            }
+            if (lane > big && lane < N) {
+                const float t = M[lane * LD + k];
+                M[lane * LD + k] = M[lane * LD + big];
+                M[lane * LD + big] = t;
+            }
+            if (lane == k) {
+                const float t = M[k * LD + k];
+                M[k * LD + k] = M[big * LD + big];
+                M[big * LD + big] = t;
+            }
+            if (lane > k && lane < big) {
+                const float t = M[lane * LD + k];
+                M[lane * LD + k] = M[big * LD + lane];
+                M[big * LD + lane] = t;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (k > 0) {
+            if (lane < k) temp[lane] = M[lane * LD + lane] * M[k * LD + lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= k && lane < N) {
+                float acc = 0.f;
+                for (int j = 0; j < k; j++) acc += M[lane * LD + j] * temp[j];
+                M[lane * LD + k] -= acc;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        const float akk = M[k * LD + k];
+        const bool pivot_valid = fabsf(akk) > 0.f;
+        if (k == 0 && !pivot_valid) {
+            if (lane < N) transp[lane] = lane;
+            all_zero = true;
+            break;
+        }
+        if (pivot_valid && lane > k && lane < N) M[lane * LD + k] /= akk;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_wave_barrier();
+    return all_zero;
+}
+
+// Solves with the factors above. y is [N] floats in LDS holding b on entry and x on exit.
+template <int N>
+__device__ inline void ldlt_solve_wave(volatile const float *M, volatile const int *transp, bool all_zero,
+                                       volatile float *y, int lane) {
+    constexpr int LD = N + 1;
+    if (lane == 0) {
+        for (int k = 0; k < N; k++) {
+            const int t = transp[k];
+            if (t != k) {
+                const float s = y[k];
+                y[k] = y[t];
+                y[t] = s;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (!all_zero) {
+#pragma unroll 1
+        for (int j = 0; j < N; j++) {
+            const float yj = y[j];
+            if (lane > j && lane < N) y[lane] -= M[lane * LD + j] * yj;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (lane < N) {
+        const float di = all_zero ? 0.f : M[lane * LD + lane];
+        const float tol = 1.17549435e-38f;  // std::numeric_limits<float>::min(), Eigen's LDLT tolerance
+        y[lane] = (fabsf(di) > tol) ? (y[lane] / di) : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (!all_zero) {
+#pragma unroll 1
+        for (int j = N - 1; j >= 0; j--) {
+            const float yj = y[j];
+            if (lane < j) y[lane] -= M[j * LD + lane] * yj;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (lane == 0) {
+        for (int k = N - 1; k >= 0; k--) {
+            const int t = transp[k];
+            if (t != k) {
+                const float s = y[k];
+                y[k] = y[t];
+                y[t] = s;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------
+//  single-lane double-precision helpers (arrays live in LDS; row-major)
+// ---------------------------------------------------------------------------------------------
+__device__ inline void inverse_double_lds(double *A, double *Ainv, int n) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) Ainv[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int c = 0; c < n; c++) {
+        int p = c;
+        double pv = fabs(A[c * n + c]);
+        for (int r = c + 1; r < n; r++)
+            if (fabs(A[r * n + c]) > pv) {
+                pv = fabs(A[r * n + c]);
+                p = r;
+            }
+        if (p != c)
+            for (int j = 0; j < n; j++) {
+                double t = A[c * n + j];
+                A[c * n + j] = A[p * n + j];
+                A[p * n + j] = t;
+                t = Ainv[c * n + j];
+                Ainv[c * n + j] = Ainv[p * n + j];
+                Ainv[p * n + j] = t;
+            }
+        const double inv = 1.0 / A[c * n + c];
+        for (int j = 0; j < n; j++) {
+            A[c * n + j] *= inv;
+            Ainv[c * n + j] *= inv;
+        }
+        for (int r = 0; r < n; r++) {
+            if (r == c) continue;
+            const double f = A[r * n + c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < n; j++) {
+                A[r * n + j] -= f * A[c * n + j];
+                Ainv[r * n + j] -= f * Ainv[c * n + j];
+            }
+        }
+    }
+}
+
+// cyclic Jacobi, symmetric 6x6: A is destroyed (diagonal = eigenvalues), V columns = eigenvectors
+__device__ inline void jacobi_eig6_lds(double *A, double *V) {
+    const int n = 6;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; i++) {
+            diag += A[i * n + i] * A[i * n + i];
+            for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+        }
+        if (off <= 1e-60 || off <= 1e-34 * diag) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++) {
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+__device__ inline void skew_sq_d(const double w[3], double K[9], double K2[9]) {
+    K[0] = 0;     K[1] = -w[2]; K[2] = w[1];
+    K[3] = w[2];  K[4] = 0;     K[5] = -w[0];
+    K[6] = -w[1]; K[7] = w[0];  K[8] = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s += K[i * 3 + k] * K[k * 3 + j];
+            K2[i * 3 + j] = s;
+        }
+}
+
+// SE(3) exponential, twist (v, w) -> row-major 4x4
+__device__ inline void se3_exp_d(const double xi[6], double T[16]) {
+    const double *v = xi, *w = xi + 3;
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double th = sqrt(th2);
+    double a, b, c;
+    if (th < 1e-5) {
+        a = 1.0 - th2 / 6.0;
+        b = 0.5 - th2 / 24.0;
+        c = 1.0 / 6.0 - th2 / 120.0;
+    } else {
+        a = sin(th) / th;
+        b = (1.0 - cos(th)) / th2;
+        c = (th - sin(th)) / (th2 * th);
+    }
+    double K[9], K2[9];
+    skew_sq_d(w, K, K2);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double t = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double I = (i == j) ? 1.0 : 0.0;
+            T[i * 4 + j] = I + a * K[i * 3 + j] + b * K2[i * 3 + j];
+            t += (I + b * K[i * 3 + j] + c * K2[i * 3 + j]) * v[j];
+        }
+        T[i * 4 + 3] = t;
+    }
+    T[12] = T[13] = T[14] = 0.0;
+    T[15] = 1.0;
+}
+
+// SE(3) logarithm of a rigid row-major 4x4 -> twist (v, w)
+__device__ inline void se3_log_d(const double T[16], double xi[6]) {
+    const double rx = 0.5 * (T[2 * 4 + 1] - T[1 * 4 + 2]);
+    const double ry = 0.5 * (T[0 * 4 + 2] - T[2 * 4 + 0]);
+    const double rz = 0.5 * (T[1 * 4 + 0] - T[0 * 4 + 1]);
+    const double s = sqrt(rx * rx + ry * ry + rz * rz);
+    const double cth = 0.5 * (T[0] + T[5] + T[10] - 1.0);
+    const double th = atan2(s, cth);
+    double w[3];
+    if (s < 1e-9) {
+        const double k = 1.0 + th * th / 6.0;
+        w[0] = k * rx; w[1] = k * ry; w[2] = k * rz;
+    } else {
+        const double k = th / s;
+        w[0] = k * rx; w[1] = k * ry; w[2] = k * rz;
+    }
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double tha = sqrt(th2);
+    double d;
+    if (tha < 1e-4)
+        d = 1.0 / 12.0 + th2 / 720.0;
+    else
+        d = (1.0 - (tha * sin(tha)) / (2.0 * (1.0 - cos(tha)))) / th2;
+    double K[9], K2[9];
+    skew_sq_d(w, K, K2);
+    const double t[3] = {T[3], T[7], T[11]};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double vv = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double I = (i == j) ? 1.0 : 0.0;
+            vv += (I - 0.5 * K[i * 3 + j] + d * K2[i * 3 + j]) * t[j];
+        }
+        xi[i] = vv;
+    }
+    xi[3] = w[0]; xi[4] = w[1]; xi[5] = w[2];
+}
+
+// column-major float 4x4 helpers --------------------------------------------------------------
+// twist = vee(log(T)) for a column-major float T
+__device__ inline void log_twist_cm(const volatile float *Tcm, float out[6]) {
+    double Td[16], xi[6];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) Td[r * 4 + c] = (double)Tcm[r + 4 * c];
+    se3_log_d(Td, xi);
+#pragma unroll
+    for (int i = 0; i < 6; i++) out[i] = (float)xi[i];
+}
+
+// C = A * B, column-major float, inner sum left to right (reference FrontEnd.cpp:766)
+__device__ inline void mul4_cm(const float *A, const volatile float *B, float *C) {
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) {
+            float s = A[r + 0] * B[0 + 4 * c];
+            s += A[r + 4] * B[1 + 4 * c];
+            s += A[r + 8] * B[2 + 4 * c];
+            s += A[r + 12] * B[3 + 4 * c];
+            C[r + 4 * c] = s;
+        }
+}
+
+// inverse of a column-major float 4x4 through double Gauss-Jordan (scratch: 32 doubles in LDS)
+__device__ inline void inverse4_cm(const volatile float *Tcm, float *out, double *scratch) {
+    double *A = scratch, *Ai = scratch + 16;
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) A[r * 4 + c] = (double)Tcm[r + 4 * c];
+    inverse_double_lds(A, Ai, 4);
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) out[r + 4 * c] = (float)Ai[r * 4 + c];
+}

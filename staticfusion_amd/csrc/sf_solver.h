@@ -1,0 +1,859 @@
+// sf_solver.h — the coarse-to-fine coupled odometry + segmentation solve of one stream.
+// Replaces the loop of StaticFusion::runSolver (reference FrontEnd.cpp:1091-1144) and everything
+// it calls: warpImagesAccurateInverse (:775-892), calculateCoord (:393-430), calculateDerivatives
+// (:432-479), computeWeights (:481-510), computeSegPrior (SegmentationBackground.cpp:53-103),
+// solveOdometryAndSegmJoint (:513-692) with buildSystemSegm / solveSegmIteration
+// (SegmentationBackground.cpp:105-174) and filterEstimateAndComputeT (:713-772).
+//
+// Data flow per outer iteration at level L (N_L pixels):
+//   warp        scatter the Pred level into 3 order-independent fixed-point accumulators
+//               (64-bit integer atomics: the result does not depend on the scatter order)
+//   linearise   64x8 tiles + 1-px halo staged in LDS: Inter images, edge-aware gradients, temporal
+//               differences, raw pre-weights  ->  11 float planes + 1 label byte per pixel
+//               ("records", 45 B/px), plus the global max of the pre-weights and the per-label prior
+//   IRLS        <= max_iter_irls iterations of two streaming passes over the records:
+//                 pass 1  rebuild the two Jacobian rows, Cauchy x b weights, accumulate the 21+6
+//                         normal-equation sums in fp64 registers -> wave shuffle -> LDS -> 6x6 LDL^T
+//                 pass 2  residuals with the new solution, per-label |res| sums (fixed point),
+//                         ||res||^2 -> 24x24 LDL^T for b, convergence test
+//   filter      covariance, eigen-space velocity filter, SE(3) update (one lane, fp64)
+// The Jacobian matrix A (2N x 6) of the reference is never materialised.
+#pragma once
+
+#include "sf_device_common.h"
+#include "sf_smallmath.h"
+
+#define TILE_V 64
+#define TILE_U 8
+#define TILE_LV (TILE_V + 2)
+#define TILE_LU (TILE_U + 2)
+#define TILE_N (TILE_LV * TILE_LU)
+
+struct SolveShared {
+    // linearisation tile (with halo)
+    float t_D[TILE_N], t_I[TILE_N];      // Inter depth / intensity
+    float t_dn[TILE_N], t_in[TILE_N];    // new depth / intensity
+    float t_dw[TILE_N], t_iw[TILE_N];    // warped depth / intensity
+    uint8_t t_null[TILE_N];
+    // reductions
+    double red[SF_NW][28];
+    float redf[SF_NW][2];
+    int redi[SF_NW];
+    long long lab_sum[SF_NC];
+    long long prior_sum[SF_NC];
+    int prior_size[SF_NC], prior_nonnull[SF_NC], valid_cnt[SF_NC];
+    // stream state
+    float T[16], Tinv[16];
+    float twist[6], twist_level[6], twist_old[6];
+    float est_cov[36];
+    float b_segm[SF_NC], b_prior[SF_NC], lambda_t_w[SF_NC];
+    unsigned conn[SF_NC];
+    float kb;
+    // IRLS
+    float AtA[36], AtB[6], Var[6], prev_sol[6];
+    float aver_res, aver_res_old, inv_max_c, inv_max_d, res_sqnorm;
+    int n_valid, ctrl, status, n_irls, n_outer;
+    long long pixel_iters;
+    // small solves
+    float M6[6 * 7], tmp6[6], y6[6];
+    int tr6[6];
+    float M24[SF_NC * (SF_NC + 1)], tmp24[SF_NC], y24[SF_NC], seg_diag[SF_NC], aver_res_label[SF_NC];
+    int tr24[SF_NC];
+    int seg_allzero;
+    double dwork[36 * 3 + 32];
+};
+
+// ---------------------------------------------------------------------------------------------
+//  Jacobian rows of one pixel (reference FrontEnd.cpp:544-585). Expressions keep the reference's
+//  association; the build uses -ffp-contract=off.
+// ---------------------------------------------------------------------------------------------
+struct PixRows {
+    float ac[6], bc, ad[6], bd;
+};
+
+__device__ __forceinline__ void build_rows(float d, float x, float y, float dcu_, float dcv_, float dct_, float ddu_,
+                                           float ddv_, float ddt_, float wc_norm, float wd_norm, float f_inv,
+                                           float k_photometric_res, PixRows &r) {
+    const float inv_d = 1.f / d;
+    const float dycomp_c = dcu_ * f_inv * inv_d;
+    const float dzcomp_c = dcv_ * f_inv * inv_d;
+    const float twc = wc_norm * k_photometric_res;
+    r.ac[0] = twc * (-dycomp_c);
+    r.ac[1] = twc * (-dzcomp_c);
+    r.ac[2] = twc * (dycomp_c * x * inv_d + dzcomp_c * y * inv_d);
+    r.ac[3] = twc * (dycomp_c * inv_d * y * x + dzcomp_c * (y * y * inv_d + d));
+    r.ac[4] = twc * (-dycomp_c * (x * x * inv_d + d) - dzcomp_c * inv_d * y * x);
+    r.ac[5] = twc * (dycomp_c * y - dzcomp_c * x);
+    r.bc = twc * (-dct_);
+
+    const float dycomp_d = ddu_ * f_inv * inv_d;
+    const float dzcomp_d = ddv_ * f_inv * inv_d;
+    const float twd = wd_norm;
+    r.ad[0] = twd * (-dycomp_d);
+    r.ad[1] = twd * (-dzcomp_d);
+    r.ad[2] = twd * (1.f + dycomp_d * x * inv_d + dzcomp_d * y * inv_d);
+    r.ad[3] = twd * (y + dycomp_d * inv_d * y * x + dzcomp_d * (y * y * inv_d + d));
+    r.ad[4] = twd * (-x - dycomp_d * (x * x * inv_d + d) - dzcomp_d * inv_d * y * x);
+    r.ad[5] = twd * (dycomp_d * y - dzcomp_d * x);
+    r.bd = twd * (-ddt_);
+}
+
+struct RecPtrs {
+    const float *p[R_COUNT];
+    const uint8_t *lab;
+};
+
+__device__ __forceinline__ bool load_rows(const RecPtrs &rp, int idx, float inv_max_c, float inv_max_d, float f_inv,
+                                          float kph, PixRows &r, int &lab) {
+    lab = rp.lab[idx];
+    if (lab == SF_INVALID_LABEL) return false;
+    build_rows(rp.p[R_D][idx], rp.p[R_X][idx], rp.p[R_Y][idx], rp.p[R_DCU][idx], rp.p[R_DCV][idx], rp.p[R_DCT][idx],
+               rp.p[R_DDU][idx], rp.p[R_DDV][idx], rp.p[R_DDT][idx], inv_max_c * rp.p[R_WC][idx],
+               inv_max_d * rp.p[R_WD][idx], f_inv, kph, r);
+    return true;
+}
+
+// res = -B; res += Var(k)*A(k), k = 0..5   (reference FrontEnd.cpp:644-646)
+__device__ __forceinline__ float residual(const float a[6], float bb, const volatile float *Var) {
+    float res = -bb;
+#pragma unroll
+    for (int k = 0; k < 6; k++) res += Var[k] * a[k];
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------
+//  warp (reference FrontEnd.cpp:775-892), scatter part.  Normalisation happens when the
+//  accumulators are read by the linearisation.
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, SolveShared &s, int tid) {
+    const int rows_i = a.lrows[L], cols_i = a.lcols[L], n = a.ln[L], o = a.loff[L];
+    const size_t sb = (size_t)b * a.n_tot;
+    const float *dpred = a.pyr_pred[0] + sb + o, *ipred = a.pyr_pred[1] + sb + o;
+    const float *xpred = a.pyr_pred[2] + sb + o, *ypred = a.pyr_pred[3] + sb + o;
+    long long *acc_d = a.acc_d + (size_t)b * a.n0;
+    long long *acc_i = a.acc_i + (size_t)b * a.n0;
+    uint32_t *acc_w = a.acc_w + (size_t)b * a.n0;
+
+    if (tid == 0) inverse4_cm(s.T, s.Tinv, s.dwork);  // T = T_odometry.inverse()  (:800)
+    for (int idx = tid; idx < n; idx += SF_NT) {
+        acc_d[idx] = 0;
+        acc_i[idx] = 0;
+        acc_w[idx] = 0;
+    }
+    __syncthreads();
+
+    const float f = float(cols_i) / (2.f * a.tan_half_fovh);
+    const float disp_u_i = 0.5f * float(cols_i - 1);
+    const float disp_v_i = 0.5f * float(rows_i - 1);
+    const int cols_lim = 100 * (cols_i - 1);
+    const int rows_lim = 100 * (rows_i - 1);
+    float T[12];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) T[r * 4 + c] = s.Tinv[r + 4 * c];
+
+    for (int idx = tid; idx < n; idx += SF_NT) {
+        const float z = dpred[idx];
+        if (z == 0.f) continue;
+        const float intensity_w = ipred[idx];
+        const float xr = xpred[idx], yr = ypred[idx];
+        const float x_w = T[0] * xr + T[1] * yr + T[2] * z + T[3];
+        const float y_w = T[4] * xr + T[5] * yr + T[6] * z + T[7];
+        const float depth_w = T[8] * xr + T[9] * yr + T[10] * z + T[11];
+
+        const int uwarp = cvt_trunc_x86(100.f * (f * x_w / depth_w + disp_u_i));
+        const int vwarp = cvt_trunc_x86(100.f * (f * y_w / depth_w + disp_v_i));
+        if (!((uwarp >= 0) && (uwarp < cols_lim) && (vwarp >= 0) && (vwarp < rows_lim))) continue;
+
+        const int uwarp_l = uwarp - uwarp % 100;
+        const int uwarp_r = uwarp_l + 100;
+        const int vwarp_d = vwarp - vwarp % 100;
+        const int vwarp_u = vwarp_d + 100;
+        const int delta_r = uwarp_r - uwarp;
+        const int delta_l = 100 - delta_r;
+        const int delta_u = vwarp_u - vwarp;
+        const int delta_d = 100 - delta_u;
+
+        const long long dfix = to_fix(depth_w, FIX_DEPTH, 1000.f);
+        const long long ifix = to_fix(intensity_w, FIX_INTENS, 4.f);
+        auto splat = [&](int v, int u, int w) {
+            const int t = v + u * rows_i;
+            atomicAdd((unsigned long long *)&acc_d[t], (unsigned long long)((long long)w * dfix));
+            atomicAdd((unsigned long long *)&acc_i[t], (unsigned long long)((long long)w * ifix));
+            atomicAdd(&acc_w[t], (uint32_t)w);
+        };
+        if (min(delta_r, delta_l) + min(delta_u, delta_d) < 5) {
+            const int ind_u = delta_r > delta_l ? uwarp_l / 100 : uwarp_r / 100;
+            const int ind_v = delta_u > delta_d ? vwarp_d / 100 : vwarp_u / 100;
+            splat(ind_v, ind_u, 200);
+        } else {
+            const int v_d = vwarp_d / 100, u_l = uwarp_l / 100;
+            const int v_u = v_d + 1, u_r = u_l + 1;
+            splat(v_u, u_r, delta_l + delta_d);
+            splat(v_u, u_l, delta_r + delta_d);
+            splat(v_d, u_r, delta_l + delta_u);
+            splat(v_d, u_l, delta_r + delta_u);
+        }
+    }
+    __syncthreads();  // all atomics of this workgroup performed at L2
+}
+
+// ---------------------------------------------------------------------------------------------
+//  linearise: calculateCoord + calculateDerivatives + computeWeights (raw) + computeSegPrior
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool first, SolveShared &s, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int rows_i = a.lrows[L], cols_i = a.lcols[L], o = a.loff[L];
+    const size_t sb = (size_t)b * a.n_tot, rb = (size_t)b * a.n0;
+    const float *dnew = a.pyr_new[0] + sb + o, *inew = a.pyr_new[1] + sb + o;
+    const float *xnew = a.pyr_new[2] + sb + o, *ynew = a.pyr_new[3] + sb + o;
+    const float *dpred = a.pyr_pred[0] + sb + o, *ipred = a.pyr_pred[1] + sb + o;
+    const float *xpred = a.pyr_pred[2] + sb + o, *ypred = a.pyr_pred[3] + sb + o;
+    const long long *acc_d = a.acc_d + rb, *acc_i = a.acc_i + rb;
+    const uint32_t *acc_w = a.acc_w + rb;
+    const uint8_t *labels = a.labels + sb + o;
+    const bool seg = a.p.segmentation_enabled != 0;
+    const bool dbg = a.p.debug_planes != 0;
+
+    const float f = float(cols_i) / (2.f * a.tan_half_fovh);
+    const float inv_f_w = 1.f / f;  // the warp's 1/f (reference FrontEnd.cpp:874), not the pyramid's
+    const float disp_u_i = 0.5f * float(cols_i - 1);
+    const float disp_v_i = 0.5f * float(rows_i - 1);
+    const float epsilon_intensity = 1e-6f, epsilon_depth = 0.005f;
+    const float kz = a.p.kz;
+
+    if (tid < SF_NC) {
+        s.prior_sum[tid] = 0;
+        s.prior_size[tid] = 0;
+        s.prior_nonnull[tid] = 0;
+        s.valid_cnt[tid] = 0;
+    }
+    float max_c = 0.f, max_d = 0.f;
+    int n_valid = 0;
+
+    const int tiles_v = (rows_i + TILE_V - 1) / TILE_V, tiles_u = (cols_i + TILE_U - 1) / TILE_U;
+    for (int tile = 0; tile < tiles_v * tiles_u; tile++) {
+        const int tv0 = (tile % tiles_v) * TILE_V, tu0 = (tile / tiles_v) * TILE_U;
+        __syncthreads();  // previous tile consumed (and the bin initialisation above)
+        for (int e = tid; e < TILE_N; e += SF_NT) {
+            const int lu = e / TILE_LV, lv = e - lu * TILE_LV;
+            const int v = tv0 - 1 + lv, u = tu0 - 1 + lu;
+            float dn = 0.f, in_ = 0.f, dw = 0.f, iw = 0.f;
+            bool inside = (v >= 0 && v < rows_i && u >= 0 && u < cols_i);
+            if (inside) {
+                const int idx = v + u * rows_i;
+                dn = dnew[idx];
+                in_ = inew[idx];
+                if (first) {  // Warped := Pred  (reference FrontEnd.cpp:1103-1110)
+                    dw = dpred[idx];
+                    iw = ipred[idx];
+                } else {
+                    const uint32_t w = __hip_atomic_load(&acc_w[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (w != 0) {
+                        const long long sd = __hip_atomic_load(&acc_d[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const long long si = __hip_atomic_load(&acc_i[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dw = (float)(((double)sd * (1.0 / 67108864.0)) / (double)w);
+                        iw = (float)(((double)si * (1.0 / 1073741824.0)) / (double)w);
+                    }
+                }
+            }
+            const bool nul = !(inside && (dn != 0.f) && (dw != 0.f));
+            s.t_null[e] = nul ? 1 : 0;
+            s.t_D[e] = nul ? 0.f : 0.5f * (dn + dw);
+            s.t_I[e] = 0.5f * (in_ + iw);
+            s.t_dn[e] = dn;
+            s.t_in[e] = in_;
+            s.t_dw[e] = dw;
+            s.t_iw[e] = iw;
+        }
+        __syncthreads();
+
+        const int lv = (tid & (TILE_V - 1)) + 1, lu = (tid / TILE_V) + 1;
+        const int v = tv0 + lv - 1, u = tu0 + lu - 1;
+        const bool inside = (v < rows_i && u < cols_i);
+        const int e = lv + lu * TILE_LV;
+        const int idx = v + u * rows_i;
+        bool valid = false, nonnull = false;
+        int lab = SF_NC;
+        float ddt_ = 0.f;
+        if (inside) {
+            const float dn = s.t_dn[e], dw = s.t_dw[e];
+            const bool nul = s.t_null[e] != 0;
+            nonnull = !nul;
+            const float dct_ = s.t_in[e] - s.t_iw[e];
+            ddt_ = dn - dw;
+            lab = seg ? (int)labels[idx] : ((dn != 0.f) ? 0 : SF_NC);
+            float d_i = 0.f, x_i = 0.f, y_i = 0.f, xw = 0.f, yw = 0.f;
+            if (first) {
+                xw = xpred[idx];
+                yw = ypred[idx];
+            } else if (dw != 0.f) {
+                xw = (float(u) - disp_u_i) * dw * inv_f_w;
+                yw = (float(v) - disp_v_i) * dw * inv_f_w;
+            }
+            if (!nul) {
+                d_i = s.t_D[e];
+                x_i = 0.5f * (xnew[idx] + xw);
+                y_i = 0.5f * (ynew[idx] + yw);
+            }
+            valid = !nul && (u != 0) && (v != 0) && (u != cols_i - 1) && (v != rows_i - 1);
+            float dcu_ = 0.f, dcv_ = 0.f, ddu_ = 0.f, ddv_ = 0.f, wc = 0.f, wd = 0.f;
+            if (valid) {
+                const int eL = e - TILE_LV, eR = e + TILE_LV, eU = e - 1, eD = e + 1;  // (v,u-1) (v,u+1) (v-1,u) (v+1,u)
+                const float Dc = s.t_D[e], Ic = s.t_I[e];
+                // rx / ry weights of this pixel and of its left / upper neighbour (reference :448-462)
+                const float rx_c = (u < cols_i - 1) ? fabsf(s.t_D[eR] - Dc) + epsilon_depth : 1.f;
+                const float rxi_c = (u < cols_i - 1) ? fabsf(s.t_I[eR] - Ic) + epsilon_intensity : 1.f;
+                const float ry_c = (v < rows_i - 1) ? fabsf(s.t_D[eD] - Dc) + epsilon_depth : 1.f;
+                const float ryi_c = (v < rows_i - 1) ? fabsf(s.t_I[eD] - Ic) + epsilon_intensity : 1.f;
+                const bool nulL = s.t_null[eL] != 0, nulU = s.t_null[eU] != 0;
+                const float rx_l = nulL ? 1.f : fabsf(Dc - s.t_D[eL]) + epsilon_depth;
+                const float rxi_l = nulL ? 1.f : fabsf(Ic - s.t_I[eL]) + epsilon_intensity;
+                const float ry_u = nulU ? 1.f : fabsf(Dc - s.t_D[eU]) + epsilon_depth;
+                const float ryi_u = nulU ? 1.f : fabsf(Ic - s.t_I[eU]) + epsilon_intensity;
+                dcu_ = (rxi_l * (s.t_I[eR] - Ic) + rxi_c * (Ic - s.t_I[eL])) / (rxi_c + rxi_l);
+                ddu_ = (rx_l * (s.t_D[eR] - Dc) + rx_c * (Dc - s.t_D[eL])) / (rx_c + rx_l);
+                dcv_ = (ryi_u * (s.t_I[eD] - Ic) + ryi_c * (Ic - s.t_I[eU])) / (ryi_c + ryi_u);
+                ddv_ = (ry_u * (s.t_D[eD] - Dc) + ry_c * (Dc - s.t_D[eU])) / (ry_c + ry_u);
+                // raw pre-weights (reference :487-502)
+                const float error_l_c = 10.f * (fabsf(dct_) + fabsf(dcu_) + fabsf(dcv_));
+                const float error_l_d = 200.f * (fabsf(ddt_) + fabsf(ddu_) + fabsf(ddv_));
+                wc = sqrtf(1.f / (1.f + error_l_c));
+                wd = sqrtf(1.f / (0.01f + error_l_d));
+                max_c = (wc > max_c) ? wc : max_c;
+                max_d = (wd > max_d) ? wd : max_d;
+                n_valid++;
+            }
+            a.rec[R_D][rb + idx] = d_i;
+            a.rec[R_X][rb + idx] = x_i;
+            a.rec[R_Y][rb + idx] = y_i;
+            a.rec[R_DCU][rb + idx] = dcu_;
+            a.rec[R_DCV][rb + idx] = dcv_;
+            a.rec[R_DCT][rb + idx] = dct_;
+            a.rec[R_DDU][rb + idx] = ddu_;
+            a.rec[R_DDV][rb + idx] = ddv_;
+            a.rec[R_DDT][rb + idx] = ddt_;
+            a.rec[R_WC][rb + idx] = wc;
+            a.rec[R_WD][rb + idx] = wd;
+            a.rec_lab[rb + idx] = valid ? (uint8_t)(seg ? lab : 0) : (uint8_t)SF_INVALID_LABEL;
+            a.rec_null[rb + idx] = nul ? 1 : 0;
+            if (dbg) {
+                const size_t q = sb + o + idx;
+                a.dbg_warped[0][q] = dw;
+                a.dbg_warped[1][q] = s.t_iw[e];
+                a.dbg_warped[2][q] = xw;
+                a.dbg_warped[3][q] = yw;
+                a.dbg_inter[0][q] = d_i;
+                a.dbg_inter[1][q] = s.t_I[e];
+                a.dbg_inter[2][q] = x_i;
+                a.dbg_inter[3][q] = y_i;
+            }
+        }
+        if (seg) {
+            // computeSegPrior (reference SegmentationBackground.cpp:65-81), per-wave aggregation
+            const bool labelled = inside && lab != SF_NC;
+            wave_label_count(labelled, lab, s.prior_size, lane);
+            wave_label_count(labelled && nonnull, lab, s.prior_nonnull, lane);
+            wave_label_add_i64(labelled && nonnull, lab, to_fix(1.f - kz * fabsf(ddt_), FIX_RES, 1.0e6f), s.prior_sum, lane);
+            wave_label_count(valid, lab, s.valid_cnt, lane);
+        }
+    }
+
+    // global max of the raw pre-weights (reference :505-509) and the valid-pixel count
+    max_c = wave_max_f32(max_c);
+    max_d = wave_max_f32(max_d);
+    n_valid = wave_sum_i32(n_valid);
+    if (lane == 0) {
+        s.redf[wave][0] = max_c;
+        s.redf[wave][1] = max_d;
+        s.redi[wave] = n_valid;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float mc = 0.f, md = 0.f;
+        int nv = 0;
+        for (int w = 0; w < SF_NW; w++) {
+            mc = (s.redf[w][0] > mc) ? s.redf[w][0] : mc;
+            md = (s.redf[w][1] > md) ? s.redf[w][1] : md;
+            nv += s.redi[w];
+        }
+        s.n_valid = nv;
+        s.inv_max_c = (nv > 0) ? 1.f / mc : 0.f;
+        s.inv_max_d = (nv > 0) ? 1.f / md : 0.f;
+        if (nv == 0) s.status |= SF_STATUS_EMPTY_LEVEL;
+    }
+    if (seg && tid < SF_NC) {  // reference SegmentationBackground.cpp:84-102
+        const int l = tid;
+        float bp = 0.f, lt = 0.f;
+        if (s.prior_size[l] != 0) {
+            const float ratio = float(s.prior_nonnull[l]) / float(s.prior_size[l]);
+            if (ratio < 0.1f) {
+                lt = 0.1f;
+                bp = -1.f;
+            } else {
+                lt = ratio;
+                const float sum = (float)((double)s.prior_sum[l] * (1.0 / 4294967296.0));
+                bp = std_max(-1.f, std_min(2.f, sum / s.prior_nonnull[l]));
+            }
+        }
+        s.b_prior[l] = bp;
+        s.lambda_t_w[l] = lt;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+//  filterEstimateAndComputeT (reference FrontEnd.cpp:713-772) + est_cov (:689). One lane.
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ void solve_filter_and_update(const KArgs &a, SolveShared &s, int level) {
+    // est_cov = AtA.inverse() * res.squaredNorm()
+    double *Ad = s.dwork, *Ai = s.dwork + 36, *V = s.dwork + 72;
+    for (int i = 0; i < 36; i++) Ad[i] = (double)s.AtA[i];
+    inverse_double_lds(Ad, Ai, 6);
+    for (int i = 0; i < 36; i++) s.est_cov[i] = (float)Ai[i] * s.res_sqnorm;
+
+    float twist[6];
+    for (int i = 0; i < 6; i++) twist[i] = s.Var[i];
+
+    if (a.p.use_motion_filter) {
+        bool finite = true;
+        double *S = Ad;  // reuse
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j <= i; j++) {
+                const double v = (double)s.est_cov[i * 6 + j];
+                if (!isfinite(v)) finite = false;
+                S[i * 6 + j] = v;
+                S[j * 6 + i] = v;
+            }
+        if (!finite) {  // "Eigensolver couldn't find a solution. Pose is not updated"
+            s.status |= SF_STATUS_EIG_SKIPPED;
+            return;
+        }
+        jacobi_eig6_lds(S, V);  // S diagonal = eigenvalues
+        float kai_loc_sub[6], lt[6];
+        log_twist_cm(s.T, lt);
+        for (int i = 0; i < 6; i++) kai_loc_sub[i] = s.twist_old[i] - lt[i];
+        const float e_l = (float)exp(-(double)level);
+        const float cf = a.p.previous_speed_eig_weight * e_l, df = a.p.previous_speed_const_weight * e_l;
+        double kai_b_fil[6];
+        for (int i = 0; i < 6; i++) {
+            double kb_ = 0, kbo = 0;
+            for (int r = 0; r < 6; r++) {
+                kb_ += V[r * 6 + i] * (double)twist[r];
+                kbo += V[r * 6 + i] * (double)kai_loc_sub[r];
+            }
+            const double wgt = (double)cf * S[i * 6 + i] + (double)df;
+            kai_b_fil[i] = (kb_ + wgt * kbo) / (1.0 + wgt);
+        }
+        for (int r = 0; r < 6; r++) {
+            double acc = 0;
+            for (int i = 0; i < 6; i++) acc += V[r * 6 + i] * kai_b_fil[i];
+            twist[r] = (float)acc;
+        }
+    }
+
+    double xi[6], E[16];
+    for (int i = 0; i < 6; i++) xi[i] = (double)twist[i];
+    se3_exp_d(xi, E);
+    float Ef[16], Tn[16];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) Ef[r + 4 * c] = (float)E[r * 4 + c];
+    for (int i = 0; i < 6; i++) s.twist_level[i] = twist[i];
+    mul4_cm(Ef, s.T, Tn);
+    for (int i = 0; i < 16; i++) s.T[i] = Tn[i];
+    float tw[6];
+    log_twist_cm(s.T, tw);
+    for (int i = 0; i < 6; i++) s.twist[i] = tw[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+//  solveOdometryAndSegmJoint (reference FrontEnd.cpp:513-692), split into separately compiled
+//  pieces so that each streaming pass gets its own register allocation.
+// ---------------------------------------------------------------------------------------------
+struct IrlsCtx {
+    RecPtrs rp;
+    int n;        // pixels of the level
+    int N;        // valid pixels
+    float f_inv;  // reference :537 (it is f)
+    float kph, inv_max_c, inv_max_d;
+};
+
+__device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, const SolveShared &s) {
+    IrlsCtx c;
+    const size_t rb = (size_t)b * a.n0;
+#pragma unroll
+    for (int q = 0; q < R_COUNT; q++) c.rp.p[q] = a.rec[q] + rb;
+    c.rp.lab = a.rec_lab + rb;
+    c.n = a.ln[L];
+    c.N = s.n_valid;
+    c.f_inv = float(a.lcols[L]) / (2.f * a.tan_half_fovh);
+    c.kph = a.p.k_photometric_res;
+    c.inv_max_c = s.inv_max_c;
+    c.inv_max_d = s.inv_max_d;
+    return c;
+}
+
+// initial aver_res = mean |res| with res = -B (reference :588-590): partial sums to s.red[wave][0]
+__device__ __noinline__ void irls_initial_residual(const KArgs &a, int b, int L, SolveShared &s, int tid) {
+    const IrlsCtx c = make_irls_ctx(a, b, L, s);
+    double sabs = 0.0;
+    for (int idx = tid; idx < c.n; idx += SF_NT) {
+        const int lab = c.rp.lab[idx];
+        if (lab == SF_INVALID_LABEL) continue;
+        const float twc = (c.inv_max_c * c.rp.p[R_WC][idx]) * c.kph;
+        const float twd = c.inv_max_d * c.rp.p[R_WD][idx];
+        const float bc = twc * (-c.rp.p[R_DCT][idx]);
+        const float bd = twd * (-c.rp.p[R_DDT][idx]);
+        sabs += (double)fabsf(-bc);
+        sabs += (double)fabsf(-bd);
+    }
+    sabs = wave_sum_f64(sabs);
+    if ((tid & 63) == 0) s.red[tid >> 6][0] = sabs;
+}
+
+// pass 1: Cauchy x b weights, 21+6 normal-equation sums (reference :615-641) -> s.red[wave][0..26]
+__device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, SolveShared &s, int tid) {
+    const IrlsCtx c = make_irls_ctx(a, b, L, s);
+    const float inv_c_Cauchy = 1.f / (a.p.kc_Cauchy * s.aver_res);
+    double acc[27];
+#pragma unroll
+    for (int q = 0; q < 27; q++) acc[q] = 0.0;
+    float Vr[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) Vr[q] = s.Var[q];
+    for (int idx = tid; idx < c.n; idx += SF_NT) {
+        PixRows r;
+        int lab;
+        if (!load_rows(c.rp, idx, c.inv_max_c, c.inv_max_d, c.f_inv, c.kph, r, lab)) continue;
+        const float b_weight = std_max(0.f, std_min(1.f, s.b_segm[lab]));
+#pragma unroll
+        for (int row = 0; row < 2; row++) {
+            const float *ar = row ? r.ad : r.ac;
+            const float br = row ? r.bd : r.bc;
+            float res = -br;
+#pragma unroll
+            for (int q = 0; q < 6; q++) res += Vr[q] * ar[q];
+            const float w = b_weight * sqrtf(1.f / (1.f + sqf(res * inv_c_Cauchy)));
+            double aw[7];
+#pragma unroll
+            for (int q = 0; q < 6; q++) aw[q] = (double)(w * ar[q]);
+            aw[6] = (double)(w * br);
+            acc[0] = fma(aw[0], aw[0], acc[0]);   acc[1] = fma(aw[0], aw[1], acc[1]);
+            acc[2] = fma(aw[0], aw[2], acc[2]);   acc[3] = fma(aw[0], aw[3], acc[3]);
+            acc[4] = fma(aw[0], aw[4], acc[4]);   acc[5] = fma(aw[0], aw[5], acc[5]);
+            acc[6] = fma(aw[1], aw[1], acc[6]);   acc[7] = fma(aw[1], aw[2], acc[7]);
+            acc[8] = fma(aw[1], aw[3], acc[8]);   acc[9] = fma(aw[1], aw[4], acc[9]);
+            acc[10] = fma(aw[1], aw[5], acc[10]); acc[11] = fma(aw[2], aw[2], acc[11]);
+            acc[12] = fma(aw[2], aw[3], acc[12]); acc[13] = fma(aw[2], aw[4], acc[13]);
+            acc[14] = fma(aw[2], aw[5], acc[14]); acc[15] = fma(aw[3], aw[3], acc[15]);
+            acc[16] = fma(aw[3], aw[4], acc[16]); acc[17] = fma(aw[3], aw[5], acc[17]);
+            acc[18] = fma(aw[4], aw[4], acc[18]); acc[19] = fma(aw[4], aw[5], acc[19]);
+            acc[20] = fma(aw[5], aw[5], acc[20]);
+            acc[21] = fma(aw[0], aw[6], acc[21]); acc[22] = fma(aw[1], aw[6], acc[22]);
+            acc[23] = fma(aw[2], aw[6], acc[23]); acc[24] = fma(aw[3], aw[6], acc[24]);
+            acc[25] = fma(aw[4], aw[6], acc[25]); acc[26] = fma(aw[5], aw[6], acc[26]);
+        }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < 27; q++) {
+        const double t = wave_sum_f64(acc[q]);
+        if (lane == 0) s.red[wave][q] = t;
+    }
+}
+
+// wave 0: finish the reduction, AtA / AtB, Var = AtA.ldlt().solve(AtB) (reference :640-642)
+__device__ __noinline__ void irls_solve_normal(SolveShared &s, int lane) {
+    if (lane < 27) {
+        double t = 0.0;
+        for (int w = 0; w < SF_NW; w++) t += s.red[w][lane];
+        s.red[0][lane] = t;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 36) {
+        const int i = lane / 6, j = lane - 6 * i;
+        const int lo = min(i, j), hi = max(i, j);
+        const int q = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);  // upper-triangular packing of pass 1
+        const float v = (float)s.red[0][q];
+        s.AtA[lane] = v;
+        s.M6[i * 7 + j] = v;
+    }
+    if (lane < 6) {
+        const float v = (float)s.red[0][21 + lane];
+        s.AtB[lane] = v;
+        s.y6[lane] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool az = ldlt_factor_wave<6>(s.M6, s.tmp6, s.tr6, lane);
+    ldlt_solve_wave<6>(s.M6, s.tr6, az, s.y6, lane);
+    if (lane < 6) s.Var[lane] = s.y6[lane];
+    if (lane < SF_NC) s.lab_sum[lane] = 0;
+}
+
+// pass 2: residuals with the new solution, per-label sums, ||res||^2 (reference :644-667)
+__device__ __noinline__ void irls_pass2(const KArgs &a, int b, int L, SolveShared &s, int tid) {
+    const IrlsCtx c = make_irls_ctx(a, b, L, s);
+    const int lane = tid & 63, wave = tid >> 6;
+    float Vr[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) Vr[q] = s.Var[q];
+    double sq = 0.0;
+    for (int base = 0; base < c.n; base += SF_NT) {
+        const int idx = base + tid;
+        PixRows r;
+        int lab = 0;
+        bool ok = false;
+        if (idx < c.n) ok = load_rows(c.rp, idx, c.inv_max_c, c.inv_max_d, c.f_inv, c.kph, r, lab);
+        long long fx = 0;
+        if (ok) {
+            float rc = -r.bc, rd = -r.bd;
+#pragma unroll
+            for (int q = 0; q < 6; q++) rc += Vr[q] * r.ac[q];
+#pragma unroll
+            for (int q = 0; q < 6; q++) rd += Vr[q] * r.ad[q];
+            sq = fma((double)rc, (double)rc, sq);
+            sq = fma((double)rd, (double)rd, sq);
+            fx = to_fix(fabsf(rc) + fabsf(rd), FIX_RES, 1.0e6f);
+        }
+        wave_label_add_i64(ok, lab, fx, s.lab_sum, lane);
+    }
+    sq = wave_sum_f64(sq);
+    if (lane == 0) s.red[wave][27] = sq;
+}
+
+// wave 0: build and factorise A_seg^T A_seg once per outer iteration
+// (reference SegmentationBackground.cpp:105-130,143-165)
+__device__ __noinline__ void irls_seg_factor(const KArgs &a, SolveShared &s, int lane) {
+    const float lambda_prior = a.p.lambda_prior;
+    const float weight_reg = 2.f * a.p.lambda_reg;
+    const float w2 = weight_reg * weight_reg, nw2 = weight_reg * (-weight_reg);
+    if (lane < SF_NC) {
+        const int l = lane;
+        const float lt = s.lambda_t_w[l];
+        const float dg = (lt > 0.1f) ? 2.f * lt * lambda_prior : 2.f * lt;
+        s.seg_diag[l] = dg;
+        const unsigned cm = s.conn[l];
+        double dd = (double)(dg * dg);
+        for (int lc = 0; lc < SF_NC; lc++) {
+            const bool con = (lc != l) && ((cm >> lc) & 1u);
+            if (con) dd += (double)w2;
+            if (lc != l) s.M24[l * (SF_NC + 1) + lc] = con ? nw2 : 0.f;
+        }
+        s.M24[l * (SF_NC + 1) + l] = (float)dd;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool az = ldlt_factor_wave<SF_NC>(s.M24, s.tmp24, s.tr24, lane);
+    if (lane == 0) s.seg_allzero = az ? 1 : 0;
+}
+
+// wave 0, after pass 2: averages, solveSegmIteration, convergence test (reference :666-683)
+__device__ __noinline__ void irls_iteration_tail(const KArgs &a, SolveShared &s, int N, int k, int lane) {
+    const bool seg = a.p.segmentation_enabled != 0;
+    if (lane < SF_NC) s.aver_res_label[lane] = (float)((double)s.lab_sum[lane] * (1.0 / 4294967296.0));
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        double t = 0.0;
+        for (int l = 0; l < SF_NC; l++) t += (double)s.aver_res_label[l];
+        s.aver_res_old = s.aver_res;
+        s.aver_res = (float)t / float(2 * N);
+        double q = 0.0;
+        for (int w = 0; w < SF_NW; w++) q += s.red[w][27];
+        s.res_sqnorm = (float)q;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (seg) {
+        // solveSegmIteration (reference SegmentationBackground.cpp:133-174)
+        if (lane < SF_NC) {
+            const int l = lane;
+            const int npl = s.valid_cnt[l] + 1;  // num_pix_label starts at 1 (reference :651)
+            const float arl = s.aver_res_label[l] / float(2 * npl);
+            const float aro = s.aver_res_old;  // the PREVIOUS iteration's overall average (reference :652,672)
+            const float kc = a.p.kc_Cauchy;
+            const float repr_res = std_max(0.001f, aro);
+            const float fixed_term = (float)log((double)(1.f + sqf(s.kb * repr_res / (kc * aro))));
+            const float mult_res = 1.f / (kc * aro);
+            const float lt = s.lambda_t_w[l];
+            float Bseg;
+            if (lt > 0.1f) {
+                const float dataterm = fixed_term - (float)log((double)(1.f + sqf(arl * mult_res)));
+                Bseg = dataterm + 2.f * a.p.lambda_prior * lt * s.b_prior[l];
+            } else {
+                Bseg = 2.f * lt * s.b_prior[l];
+            }
+            s.y24[l] = s.seg_diag[l] * Bseg;
+        }
+        __builtin_amdgcn_wave_barrier();
+        ldlt_solve_wave<SF_NC>(s.M24, s.tr24, s.seg_allzero != 0, s.y24, lane);
+        if (lane < SF_NC) s.b_segm[lane] = std_max(-1.f, std_min(2.f, s.y24[lane]));
+    }
+    if (lane == 0) {
+        float delta = 0.f;
+        for (int c = 0; c < 6; c++) delta = std_max(delta, fabsf(s.prev_sol[c] - s.Var[c]));
+        for (int c = 0; c < 6; c++) s.prev_sol[c] = s.Var[c];
+        s.ctrl = ((delta < a.p.irls_delta_threshold) || (k == a.p.max_iter_irls)) ? 1 : 0;
+        s.n_irls++;
+        s.pixel_iters += N;
+    }
+}
+
+__device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level, int kouter, SolveShared &s, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool seg = a.p.segmentation_enabled != 0;
+    const int N = s.n_valid;
+    sf_outer_trace *tr = (s.n_outer < SF_MAX_OUTER) ? &a.stats[b].outer[s.n_outer] : nullptr;
+
+    // b initialisation (reference :603-607)
+    if (tid < SF_NC) {
+        if (!seg)
+            s.b_segm[tid] = 1.f;
+        else if (level == 0)
+            s.b_segm[tid] = s.b_prior[tid];
+    }
+    if (tid < 6) {
+        s.Var[tid] = 0.f;
+        s.prev_sol[tid] = 0.f;
+    }
+    __syncthreads();
+
+    if (N == 0) {  // defined behaviour for an empty level: nothing moves
+        if (tid < 6) s.twist_level[tid] = 0.f;
+        if (tid == 0 && tr) {
+            tr->level = level; tr->k = kouter; tr->n_valid = 0; tr->irls_iters = 0; tr->aver_res = 0.f;
+            for (int c = 0; c < 6; c++) tr->var[c] = tr->twist_level[c] = 0.f;
+            for (int l = 0; l < SF_NC; l++) tr->b_segm[l] = s.b_segm[l];
+            for (int q = 0; q < 16; q++) tr->T[q] = s.T[q];
+        }
+        __syncthreads();
+        return;
+    }
+
+    irls_initial_residual(a, b, L, s, tid);
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < SF_NW; w++) t += s.red[w][0];
+        s.aver_res = (float)t / float(2 * N);
+    }
+    if (seg && wave == 0) irls_seg_factor(a, s, lane);
+    __syncthreads();
+
+    int iters_done = 0;
+    for (int k = 1; k <= a.p.max_iter_irls; k++) {
+        iters_done = k;
+        irls_pass1(a, b, L, s, tid);
+        __syncthreads();
+        if (wave == 0) irls_solve_normal(s, lane);
+        __syncthreads();
+        irls_pass2(a, b, L, s, tid);
+        __syncthreads();
+        if (wave == 0) irls_iteration_tail(a, s, N, k, lane);
+        __syncthreads();
+        if (s.ctrl) break;
+    }
+
+    if (tid == 0) {
+        if (tr) {
+            tr->level = level; tr->k = kouter; tr->n_valid = N; tr->irls_iters = iters_done;
+            tr->aver_res = s.aver_res;
+            for (int c = 0; c < 6; c++) tr->var[c] = s.Var[c];
+        }
+        solve_filter_and_update(a, s, level);
+        if (tr) {
+            for (int c = 0; c < 6; c++) tr->twist_level[c] = s.twist_level[c];
+            for (int l = 0; l < SF_NC; l++) tr->b_segm[l] = s.b_segm[l];
+            for (int q = 0; q < 16; q++) tr->T[q] = s.T[q];
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+//  the coarse-to-fine loop (reference FrontEnd.cpp:1091-1144)
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ void stage_solve(const KArgs &a, int b, SolveShared &s, int tid) {
+    StreamState &st = a.state[b];
+    if (tid < 16) s.T[tid] = (tid % 5 == 0) ? 1.f : 0.f;  // T_odometry.setIdentity()  (:1091)
+    if (tid < 6) {
+        s.twist_old[tid] = st.twist_old[tid];
+        s.twist[tid] = st.twist[tid];
+        s.twist_level[tid] = st.twist_level[tid];
+    }
+    if (tid < SF_NC) {
+        s.b_segm[tid] = st.b_segm[tid];
+        s.conn[tid] = st.conn[tid];
+        s.b_prior[tid] = st.b_prior[tid];
+        s.lambda_t_w[tid] = st.lambda_t_w[tid];
+    }
+    if (tid == 0) {
+        s.kb = st.kb;
+        s.status = 0;
+        s.n_irls = 0;
+        s.n_outer = 0;
+        s.pixel_iters = 0;
+    }
+    __syncthreads();
+
+    int last_L = 0;
+    for (int i = 0; i < a.levels; i++) {
+        for (int k = 0; k < a.p.max_iter_per_level; k++) {
+            const int L = a.levels - i - 1;  // image_level
+            last_L = L;
+            const bool first = (i == 0) && (k == 0);
+            if (!first) solve_warp(a, b, L, s, tid);
+            solve_linearise(a, b, L, first, s, tid);
+            solve_irls(a, b, L, i, k, s, tid);
+            if (tid == 0) {
+                s.n_outer++;
+                double s2 = 0.0;
+                for (int c = 0; c < 6; c++) s2 += (double)s.twist_level[c] * (double)s.twist_level[c];
+                const float nrm = sqrtf((float)s2);
+                s.ctrl = (nrm < 0.04f) ? 1 : 0;  // reference :1130
+            }
+            __syncthreads();
+            const int brk = s.ctrl;
+            __syncthreads();
+            if (brk) break;
+        }
+    }
+
+    // twist_odometry_old = R_inc^-1 * twist_odometry (reference :1139-1144)
+    if (tid == 0) {
+        double *R = s.dwork, *Ri = s.dwork + 16;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) R[r * 3 + c] = (double)s.T[r + 4 * c];
+        inverse_double_lds(R, Ri, 3);
+        float Rif[9];
+        for (int q = 0; q < 9; q++) Rif[q] = (float)Ri[q];
+        for (int half = 0; half < 2; half++)
+            for (int r = 0; r < 3; r++) {
+                float acc = Rif[r * 3 + 0] * s.twist[half * 3 + 0];
+                acc += Rif[r * 3 + 1] * s.twist[half * 3 + 1];
+                acc += Rif[r * 3 + 2] * s.twist[half * 3 + 2];
+                s.twist_old[half * 3 + r] = acc;
+            }
+        sf_frame_stats &fs = a.stats[b];
+        fs.n_outer = s.n_outer;
+        fs.n_irls = s.n_irls;
+        fs.pixel_iters = s.pixel_iters;
+        fs.status = s.status;
+        st.last_level = last_L;
+        st.inv_max_c = s.inv_max_c;
+        st.inv_max_d = s.inv_max_d;
+        if (!a.p.segmentation_enabled) fs.kmeans_iters = 0;
+    }
+    __syncthreads();
+    if (tid < 16) st.T[tid] = s.T[tid];
+    if (tid < 6) {
+        st.twist_old[tid] = s.twist_old[tid];
+        st.twist[tid] = s.twist[tid];
+        st.twist_level[tid] = s.twist_level[tid];
+    }
+    if (tid < 36) st.est_cov[tid] = s.est_cov[tid];
+    if (tid < SF_NC) {
+        st.b_segm[tid] = s.b_segm[tid];
+        st.b_prior[tid] = s.b_prior[tid];
+        st.lambda_t_w[tid] = s.lambda_t_w[tid];
+    }
+    __syncthreads();
+}

@@ -206,10 +206,18 @@ int SF_FN(batch)(const sf_handle *h);
 
 /* ---- measurement support ------------------------------------------------------------------ */
 
-/* Time `calls` repetitions of sf_process_frame(im_count) with HIP events recorded on the handle's
- * stream (events bracket the whole timed region; inputs must already be resident). Returns the
- * elapsed milliseconds of the region. */
+/* Time sf_process_frame(im_count), sf_process_frame(im_count + 1), ... (`calls` of them) with HIP
+ * events recorded on the handle's stream (the events bracket the whole region; inputs must already
+ * be resident). Returns the elapsed milliseconds of the region. */
 int SF_FN(timed_process_frames)(sf_handle *h, int im_count, int calls, float *elapsed_ms);
+/* Totals since sf_create over all streams (accumulated on the device, read without disturbing a
+ * sequence of launches): frames solved, IRLS loop bodies, outer iterations, valid-pixel IRLS iterations. */
+int SF_FN(get_counters)(sf_handle *h, int64_t *frames, int64_t *n_irls, int64_t *n_outer, int64_t *pixel_iters);
+/* In-kernel stage timers: ticks (100 MHz wall clock, lane 0 of each workgroup) summed over all
+ * streams since sf_create. Slots: 0 pyramid(old) 1 pyramid(new) 2 k-means 3 warp 4 linearise
+ * 5 IRLS setup 6 IRLS pass 1 7 6x6 solve 8 IRLS pass 2 9 b-solve/convergence 10 filter/update
+ * 11 residuals-vs-history 12 segm image + history push 13 total. */
+int SF_FN(get_stage_profile)(sf_handle *h, int64_t ticks[16]);
 /* Elapsed ms of the most recent solver kernel launch (HIP events around that launch). */
 int SF_FN(last_solver_kernel_ms)(sf_handle *h, float *ms);
 

@@ -17,7 +17,7 @@ struct sf_handle {
     int rows, cols, batch;
     sf_params params;
     std::vector<std::unique_ptr<sfo::StaticFusion>> s;
-    int last_level = -1;  // image level of the last outer iteration (for get_lin_plane)
+    long long cum_frames = 0, cum_irls = 0, cum_outer = 0, cum_pix = 0;
     float last_ms = 0.f;
 };
 
@@ -202,7 +202,13 @@ int sfo_kmeans(sf_handle *h) {
 int sfo_run_solver(sf_handle *h, int create_image_pyr) {
     if (!h) return fail(SF_ERR_ARG, "null");
     auto t0 = std::chrono::steady_clock::now();
-    for (auto &s : h->s) s->runSolver(create_image_pyr != 0);
+    for (auto &s : h->s) {
+        s->runSolver(create_image_pyr != 0);
+        h->cum_frames += 1;
+        h->cum_irls += s->stats.n_irls;
+        h->cum_outer += s->stats.n_outer;
+        h->cum_pix += s->stats.pixel_iters;
+    }
     h->last_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SF_OK;
 }
@@ -362,9 +368,22 @@ int sfo_batch(const sf_handle *h) { return h ? h->batch : 0; }
 int sfo_timed_process_frames(sf_handle *h, int im_count, int calls, float *elapsed_ms) {
     if (!h || calls < 1) return fail(SF_ERR_ARG, "bad argument");
     auto t0 = std::chrono::steady_clock::now();
-    for (int c = 0; c < calls; c++) sfo_process_frame(h, im_count);
+    for (int c = 0; c < calls; c++) sfo_process_frame(h, im_count + c);
     if (elapsed_ms)
         *elapsed_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return SF_OK;
+}
+int sfo_get_counters(sf_handle *h, int64_t *frames, int64_t *n_irls, int64_t *n_outer, int64_t *pixel_iters) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    if (frames) *frames = h->cum_frames;
+    if (n_irls) *n_irls = h->cum_irls;
+    if (n_outer) *n_outer = h->cum_outer;
+    if (pixel_iters) *pixel_iters = h->cum_pix;
+    return SF_OK;
+}
+int sfo_get_stage_profile(sf_handle *h, int64_t ticks[16]) {
+    if (!h || !ticks) return fail(SF_ERR_ARG, "null");
+    for (int q = 0; q < 16; q++) ticks[q] = 0;  // the oracle keeps no stage timers
     return SF_OK;
 }
 int sfo_last_solver_kernel_ms(sf_handle *h, float *ms) {

@@ -12,7 +12,7 @@ from ._capi import Api, Solver, SfParams, SfFrameStats, SfError  # noqa: F401
 from . import _capi as capi  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(_HERE, "csrc", "libsf_hip.so")
+LIB = os.environ.get("SF_HIP_LIB", os.path.join(_HERE, "csrc", "libsf_hip.so"))  # override: A/B builds
 
 _api = None
 

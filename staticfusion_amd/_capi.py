@@ -114,6 +114,8 @@ SIGNATURES = {
     "level_cols": (C.c_int, [_H, C.c_int]),
     "batch": (C.c_int, [_H]),
     "timed_process_frames": (C.c_int, [_H, C.c_int, C.c_int, _fp]),
+    "get_counters": (C.c_int, [_H] + [C.POINTER(C.c_int64)] * 4),
+    "get_stage_profile": (C.c_int, [_H, C.POINTER(C.c_int64)]),
     "last_solver_kernel_ms": (C.c_int, [_H, _fp]),
 }
 
@@ -308,6 +310,21 @@ class Solver:
             )
         )
         return T.reshape(B, 4, 4).transpose(0, 2, 1).copy(), n_irls, n_outer, pix
+
+    def counters(self):
+        """(frames, n_irls, n_outer, pixel_iters) totals since creation, over all streams"""
+        v = [C.c_int64() for _ in range(4)]
+        self.api.check(self.api.get_counters(self.h, *[C.byref(x) for x in v]))
+        return tuple(int(x.value) for x in v)
+
+    STAGES = ["pyr_old", "pyr_new", "kmeans", "warp", "linearise", "irls_setup", "pass1", "solve6", "pass2",
+              "b_solve", "filter", "residuals", "segm_hist", "total"]
+
+    def stage_profile(self):
+        """dict stage -> seconds (lane-0 wall clock summed over streams since creation)"""
+        t = (C.c_int64 * 16)()
+        self.api.check(self.api.get_stage_profile(self.h, t))
+        return {n: t[i] * 1e-8 for i, n in enumerate(self.STAGES)}
 
     def timed_process_frames(self, im_count, calls):
         ms = C.c_float()

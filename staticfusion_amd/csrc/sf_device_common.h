@@ -20,6 +20,12 @@
 #define SF_NC SF_NUM_CLUSTERS
 #define SF_INVALID_LABEL 255
 
+// in-kernel stage timers (wall_clock64, 100 MHz), accumulated per stream
+enum {
+    PF_PYR_OLD = 0, PF_PYR_NEW, PF_KMEANS, PF_WARP, PF_LINEARISE, PF_IRLS_INIT, PF_PASS1, PF_SOLVE6, PF_PASS2,
+    PF_TAIL, PF_FILTER, PF_RESIDUALS, PF_SEGM_HIST, PF_TOTAL, SF_PROF_SLOTS = 16
+};
+
 // record planes written by the linearisation and streamed by the IRLS passes
 enum { R_D = 0, R_X, R_Y, R_DCU, R_DCV, R_DCT, R_DDU, R_DDV, R_DDT, R_WC, R_WD, R_COUNT };
 
@@ -56,6 +62,8 @@ struct StreamState {
     float kb;
     int32_t last_level;             // image level of the last executed outer iteration
     float inv_max_c, inv_max_d;     // 1/max of the raw pre-weights of that iteration
+    long long cum_frames, cum_irls, cum_outer, cum_pixel_iters;  // totals since sf_create
+    long long prof[SF_PROF_SLOTS];  // cumulative 100 MHz ticks per stage (lane 0 of the workgroup)
 };
 
 // Geometry, parameters and buffer table of a handle: lives in device memory, read through

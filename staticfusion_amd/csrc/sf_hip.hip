@@ -36,17 +36,45 @@ __global__ __launch_bounds__(SF_NT, 4) void sf_frame_kernel(const KArgs *__restr
     for (;;) {
         if (tid == 0) s_next = atomicAdd(a.queue, 1);
         __syncthreads();
-        const int b = s_next;
+        const int b = __builtin_amdgcn_readfirstlane(s_next);  // provably wave-uniform: scalar branches around the barriers
         __syncthreads();
         if (b >= a.batch) break;
-        if (stage_mask & ST_PYR_OLD) stage_pyramid(a, b, true, tid);
-        if (stage_mask & ST_PYR_NEW) stage_pyramid(a, b, false, tid);
-        if (stage_mask & ST_KMEANS) stage_kmeans(a, b, sh.km, tid);
-        if (stage_mask & ST_SOLVE) stage_solve(a, b, sh.sv, tid);
-        if (stage_mask & ST_RESIDUALS) stage_residuals(a, b, im_count, sh.rs, tid);
+        long long t0 = 0, t1 = 0;
+        long long *prof = a.state[b].prof;
+#ifdef SF_NO_STAGE_TIMED
+#define STAGE_TIMED(slot, call) call
+#else
+#define STAGE_TIMED(slot, call)               \
+    do {                                      \
+        call;                                 \
+        if (tid == 0) {                       \
+            t1 = wall_clock64();              \
+            prof[slot] += t1 - t0;            \
+            t0 = t1;                          \
+        }                                     \
+    } while (0)
+#endif
+        const long long t_begin = wall_clock64();
+        t0 = t_begin;
+        if (stage_mask & ST_PYR_OLD) STAGE_TIMED(PF_PYR_OLD, stage_pyramid(a, b, true, tid));
+        if (stage_mask & ST_PYR_NEW) STAGE_TIMED(PF_PYR_NEW, stage_pyramid(a, b, false, tid));
+        if (stage_mask & ST_KMEANS) STAGE_TIMED(PF_KMEANS, stage_kmeans(a, b, sh.km, tid));
+        if (stage_mask & ST_SOLVE) {
+            stage_solve(a, b, sh.sv, tid);
+            t0 = wall_clock64();
+        }
+        if (stage_mask & ST_RESIDUALS) STAGE_TIMED(PF_RESIDUALS, stage_residuals(a, b, im_count, sh.rs, tid));
         __syncthreads();
         if (stage_mask & ST_SEGM_IMAGE) stage_segm_image(a, b, tid);
         if (stage_mask & ST_PUSH_HISTORY) stage_push_history(a, b, im_count, tid);
+        if (tid == 0) {
+            t1 = wall_clock64();
+            prof[PF_SEGM_HIST] += t1 - t0;
+            prof[PF_TOTAL] += t1 - t_begin;
+        }
+        // NOTE: the loop body must END with a barrier. With a lane-0-only block here the compiler
+        // fuses it with the lane-0-only queue pop at the loop top into an outer loop, and the other
+        // lanes of wave 0 then spin on the barrier of the inner loop forever (observed hang).
         __syncthreads();
     }
 }
@@ -540,12 +568,38 @@ int sf_timed_process_frames(sf_handle *h, int im_count, int calls, float *elapse
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     for (int c = 0; c < calls; c++)
-        if (int e = sf_process_frame(h, im_count)) return e;
+        if (int e = sf_process_frame(h, im_count + c)) return e;
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev1));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     if (elapsed_ms) *elapsed_ms = ms;
+    return SF_OK;
+}
+int sf_get_counters(sf_handle *h, int64_t *frames, int64_t *n_irls, int64_t *n_outer, int64_t *pixel_iters) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    std::vector<StreamState> st(h->k.batch);
+    if (int e = d2h(h, st.data(), h->k.state, st.size() * sizeof(StreamState))) return e;
+    long long f = 0, i = 0, o = 0, p = 0;
+    for (auto &s : st) {
+        f += s.cum_frames;
+        i += s.cum_irls;
+        o += s.cum_outer;
+        p += s.cum_pixel_iters;
+    }
+    if (frames) *frames = f;
+    if (n_irls) *n_irls = i;
+    if (n_outer) *n_outer = o;
+    if (pixel_iters) *pixel_iters = p;
+    return SF_OK;
+}
+int sf_get_stage_profile(sf_handle *h, int64_t ticks[16]) {
+    if (!h || !ticks) return fail(SF_ERR_ARG, "null");
+    std::vector<StreamState> st(h->k.batch);
+    if (int e = d2h(h, st.data(), h->k.state, st.size() * sizeof(StreamState))) return e;
+    for (int q = 0; q < 16; q++) ticks[q] = 0;
+    for (auto &s : st)
+        for (int q = 0; q < SF_PROF_SLOTS; q++) ticks[q] += s.prof[q];
     return SF_OK;
 }
 int sf_last_solver_kernel_ms(sf_handle *h, float *ms) {

@@ -277,7 +277,7 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, in
         }
         __syncthreads();
         if (tid < 3 * SF_NC) s.cent_a[tid] = s.cent_b[tid];
-        const int stop = s.stop;
+        const int stop = __builtin_amdgcn_readfirstlane(s.stop);
         __syncthreads();
         if (stop) break;
     }

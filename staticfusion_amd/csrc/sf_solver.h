@@ -61,7 +61,21 @@ struct SolveShared {
     int tr24[SF_NC];
     int seg_allzero;
     double dwork[36 * 3 + 32];
+    long long prof[SF_PROF_SLOTS], t_last;
 };
+
+#ifdef SF_NO_PROF_MARK
+#define PROF_MARK(s, tid, slot) do {} while (0)
+#else
+#define PROF_MARK(s, tid, slot)                         \
+    do {                                                \
+        if ((tid) == 0) {                               \
+            const long long now_ = wall_clock64();      \
+            (s).prof[slot] += now_ - (s).t_last;        \
+            (s).t_last = now_;                          \
+        }                                               \
+    } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 //  Jacobian rows of one pixel (reference FrontEnd.cpp:544-585). Expressions keep the reference's
@@ -700,8 +714,9 @@ __device__ __noinline__ void irls_iteration_tail(const KArgs &a, SolveShared &s,
 __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level, int kouter, SolveShared &s, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const bool seg = a.p.segmentation_enabled != 0;
-    const int N = s.n_valid;
-    sf_outer_trace *tr = (s.n_outer < SF_MAX_OUTER) ? &a.stats[b].outer[s.n_outer] : nullptr;
+    const int N = __builtin_amdgcn_readfirstlane(s.n_valid);
+    const int n_outer_now = __builtin_amdgcn_readfirstlane(s.n_outer);
+    sf_outer_trace *tr = (n_outer_now < SF_MAX_OUTER) ? &a.stats[b].outer[n_outer_now] : nullptr;
 
     // b initialisation (reference :603-607)
     if (tid < SF_NC) {
@@ -737,19 +752,24 @@ __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level,
     }
     if (seg && wave == 0) irls_seg_factor(a, s, lane);
     __syncthreads();
+    PROF_MARK(s, tid, PF_IRLS_INIT);
 
     int iters_done = 0;
     for (int k = 1; k <= a.p.max_iter_irls; k++) {
         iters_done = k;
         irls_pass1(a, b, L, s, tid);
         __syncthreads();
+        PROF_MARK(s, tid, PF_PASS1);
         if (wave == 0) irls_solve_normal(s, lane);
         __syncthreads();
+        PROF_MARK(s, tid, PF_SOLVE6);
         irls_pass2(a, b, L, s, tid);
         __syncthreads();
+        PROF_MARK(s, tid, PF_PASS2);
         if (wave == 0) irls_iteration_tail(a, s, N, k, lane);
         __syncthreads();
-        if (s.ctrl) break;
+        PROF_MARK(s, tid, PF_TAIL);
+        if (__builtin_amdgcn_readfirstlane(s.ctrl)) break;
     }
 
     if (tid == 0) {
@@ -766,6 +786,7 @@ __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level,
         }
     }
     __syncthreads();
+    PROF_MARK(s, tid, PF_FILTER);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -785,7 +806,9 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, SolveShared &s, 
         s.b_prior[tid] = st.b_prior[tid];
         s.lambda_t_w[tid] = st.lambda_t_w[tid];
     }
+    if (tid < SF_PROF_SLOTS) s.prof[tid] = 0;
     if (tid == 0) {
+        s.t_last = wall_clock64();
         s.kb = st.kb;
         s.status = 0;
         s.n_irls = 0;
@@ -801,7 +824,9 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, SolveShared &s, 
             last_L = L;
             const bool first = (i == 0) && (k == 0);
             if (!first) solve_warp(a, b, L, s, tid);
+            PROF_MARK(s, tid, PF_WARP);
             solve_linearise(a, b, L, first, s, tid);
+            PROF_MARK(s, tid, PF_LINEARISE);
             solve_irls(a, b, L, i, k, s, tid);
             if (tid == 0) {
                 s.n_outer++;
@@ -811,7 +836,7 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, SolveShared &s, 
                 s.ctrl = (nrm < 0.04f) ? 1 : 0;  // reference :1130
             }
             __syncthreads();
-            const int brk = s.ctrl;
+            const int brk = __builtin_amdgcn_readfirstlane(s.ctrl);
             __syncthreads();
             if (brk) break;
         }
@@ -838,6 +863,10 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, SolveShared &s, 
         fs.pixel_iters = s.pixel_iters;
         fs.status = s.status;
         st.last_level = last_L;
+        st.cum_frames += 1;
+        st.cum_irls += s.n_irls;
+        st.cum_outer += s.n_outer;
+        st.cum_pixel_iters += s.pixel_iters;
         st.inv_max_c = s.inv_max_c;
         st.inv_max_d = s.inv_max_d;
         if (!a.p.segmentation_enabled) fs.kmeans_iters = 0;
@@ -850,6 +879,7 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, SolveShared &s, 
         st.twist_level[tid] = s.twist_level[tid];
     }
     if (tid < 36) st.est_cov[tid] = s.est_cov[tid];
+    if (tid >= PF_WARP && tid <= PF_FILTER) st.prof[tid] += s.prof[tid];
     if (tid < SF_NC) {
         st.b_segm[tid] = s.b_segm[tid];
         st.b_prior[tid] = s.b_prior[tid];

@@ -1,0 +1,33 @@
+"""Per-stage time breakdown from the in-kernel timers (100 MHz wall clock, lane 0 of each workgroup)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import argparse
+import staticfusion_amd as sf
+from staticfusion_amd.synth import make_batch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=512)
+ap.add_argument("--workload", default="static")
+ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+api = sf.load()
+p = bench.make_params(api, a.workload)
+pairs = make_batch(8, sphere=(a.workload == "sphere"), distinct=8)
+s = sf.Solver(api, 240, 320, a.batch, p)
+for b in range(a.batch):
+    s.set_current(b, *pairs[b % 8]["new"]); s.set_prediction(b, *pairs[b % 8]["old"])
+print("created", flush=True)
+for im in range(5):
+    s.process_frame(im)
+s.synchronize(); print("primed", flush=True)
+p0 = s.stage_profile(); print("prof ok", flush=True); c0 = s.counters()
+ms = s.timed_process_frames(5, a.steps)
+p1 = s.stage_profile(); c1 = s.counters()
+frames = c1[0] - c0[0]
+print("workload %s batch %d: %.2f ms/step, %.0f frames/s, %.0f it/s" % (a.workload, a.batch, ms / a.steps, frames / (ms * 1e-3), (c1[1] - c0[1]) / (ms * 1e-3)))
+tot = p1["total"] - p0["total"]
+for k in s.STAGES:
+    d = p1[k] - p0[k]
+    print("  %-11s %8.1f us/frame  %5.1f %%" % (k, 1e6 * d / frames, 100 * d / tot))

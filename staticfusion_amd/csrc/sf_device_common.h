@@ -133,6 +133,10 @@ __device__ __forceinline__ int cvt_trunc_x86(float x) {
     return (int)x;
 }
 
+// a value every lane holds identically (read from LDS / memory): move it to an SGPR
+__device__ __forceinline__ float uniform_f(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+__device__ __forceinline__ int uniform_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
 __device__ __forceinline__ float sqf(float x) { return x * x; }
 // std::max / std::min of the reference (argument order matters for NaN)
 __device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }

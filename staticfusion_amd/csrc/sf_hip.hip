@@ -218,6 +218,9 @@ int sf_create(const sf_params *p, int rows, int cols, int batch, int device, sf_
     if (int e = validate_params(p, levels)) return e;
     if ((rows >> (levels - 1)) < 3 || (cols >> (levels - 1)) < 3)
         return fail(SF_ERR_ARG, "unsupported ctf_levels for this resolution");
+    for (int L = 0; L < levels; L++)
+        if (((rows >> L) * (cols >> L)) % 4 != 0)
+            return fail(SF_ERR_ARG, "every pyramid level must hold a multiple of 4 pixels (vectorised record loads)");
 
     sf_handle *h = new sf_handle;
     h->device = device;

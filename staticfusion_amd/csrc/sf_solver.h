@@ -112,19 +112,74 @@ __device__ __forceinline__ void build_rows(float d, float x, float y, float dcu_
     r.bd = twd * (-ddt_);
 }
 
+// Records are read through GLOBAL address-space pointers (global_load_*, not flat_load_*) and
+// SF_VEC consecutive pixels per lane (8- or 16-byte loads: more bytes in flight per wave).
+#ifndef SF_VEC
+#define SF_VEC 2
+#endif
+typedef __attribute__((address_space(1))) const float gcfloat;
+typedef __attribute__((address_space(1))) const uint8_t gcu8;
+typedef float __attribute__((ext_vector_type(2))) vfloat2;
+typedef float __attribute__((ext_vector_type(4))) vfloat4;
+typedef __attribute__((address_space(1))) const vfloat2 gcfloat2;
+typedef __attribute__((address_space(1))) const vfloat4 gcfloat4;
+typedef __attribute__((address_space(1))) const unsigned short gcu16;
+typedef __attribute__((address_space(1))) const unsigned int gcu32;
+
 struct RecPtrs {
-    const float *p[R_COUNT];
-    const uint8_t *lab;
+    gcfloat *p[R_COUNT];
+    gcu8 *lab;
 };
 
-__device__ __forceinline__ bool load_rows(const RecPtrs &rp, int idx, float inv_max_c, float inv_max_d, float f_inv,
-                                          float kph, PixRows &r, int &lab) {
-    lab = rp.lab[idx];
-    if (lab == SF_INVALID_LABEL) return false;
-    build_rows(rp.p[R_D][idx], rp.p[R_X][idx], rp.p[R_Y][idx], rp.p[R_DCU][idx], rp.p[R_DCV][idx], rp.p[R_DCT][idx],
-               rp.p[R_DDU][idx], rp.p[R_DDV][idx], rp.p[R_DDT][idx], inv_max_c * rp.p[R_WC][idx],
-               inv_max_d * rp.p[R_WD][idx], f_inv, kph, r);
-    return true;
+template <int VEC>
+__device__ __forceinline__ void load_plane(gcfloat *p, int idx0, float (&out)[VEC]) {
+    if constexpr (VEC == 1) {
+        out[0] = p[idx0];
+    } else if constexpr (VEC == 2) {
+        const vfloat2 v = *(gcfloat2 *)(p + idx0);
+        out[0] = v.x;
+        out[1] = v.y;
+    } else {
+        const vfloat4 v = *(gcfloat4 *)(p + idx0);
+        out[0] = v.x;
+        out[1] = v.y;
+        out[2] = v.z;
+        out[3] = v.w;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void load_labels(gcu8 *p, int idx0, int (&out)[VEC]) {
+    if constexpr (VEC == 1) {
+        out[0] = p[idx0];
+    } else if constexpr (VEC == 2) {
+        const unsigned v = *(gcu16 *)(p + idx0);
+        out[0] = v & 255u;
+        out[1] = v >> 8;
+    } else {
+        const unsigned v = *(gcu32 *)(p + idx0);
+        out[0] = v & 255u;
+        out[1] = (v >> 8) & 255u;
+        out[2] = (v >> 16) & 255u;
+        out[3] = v >> 24;
+    }
+}
+
+template <int VEC>
+struct RecVec {
+    float v[R_COUNT][VEC];
+    int lab[VEC];
+};
+template <int VEC>
+__device__ __forceinline__ void load_rec(const RecPtrs &rp, int idx0, RecVec<VEC> &r) {
+    load_labels<VEC>(rp.lab, idx0, r.lab);
+#pragma unroll
+    for (int q = 0; q < R_COUNT; q++) load_plane<VEC>(rp.p[q], idx0, r.v[q]);
+}
+template <int VEC>
+__device__ __forceinline__ void rows_of(const RecVec<VEC> &r, int j, float inv_max_c, float inv_max_d, float f_inv,
+                                        float kph, PixRows &out) {
+    build_rows(r.v[R_D][j], r.v[R_X][j], r.v[R_Y][j], r.v[R_DCU][j], r.v[R_DCV][j], r.v[R_DCT][j], r.v[R_DDU][j],
+               r.v[R_DDV][j], r.v[R_DDT][j], inv_max_c * r.v[R_WC][j], inv_max_d * r.v[R_WD][j], f_inv, kph, out);
 }
 
 // res = -B; res += Var(k)*A(k), k = 0..5   (reference FrontEnd.cpp:644-646)
@@ -497,14 +552,14 @@ __device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, c
     IrlsCtx c;
     const size_t rb = (size_t)b * a.n0;
 #pragma unroll
-    for (int q = 0; q < R_COUNT; q++) c.rp.p[q] = a.rec[q] + rb;
-    c.rp.lab = a.rec_lab + rb;
+    for (int q = 0; q < R_COUNT; q++) c.rp.p[q] = (gcfloat *)(a.rec[q] + rb);
+    c.rp.lab = (gcu8 *)(a.rec_lab + rb);
     c.n = a.ln[L];
-    c.N = s.n_valid;
+    c.N = uniform_i(s.n_valid);
     c.f_inv = float(a.lcols[L]) / (2.f * a.tan_half_fovh);
     c.kph = a.p.k_photometric_res;
-    c.inv_max_c = s.inv_max_c;
-    c.inv_max_d = s.inv_max_d;
+    c.inv_max_c = uniform_f(s.inv_max_c);
+    c.inv_max_d = uniform_f(s.inv_max_d);
     return c;
 }
 
@@ -512,15 +567,24 @@ __device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, c
 __device__ __noinline__ void irls_initial_residual(const KArgs &a, int b, int L, SolveShared &s, int tid) {
     const IrlsCtx c = make_irls_ctx(a, b, L, s);
     double sabs = 0.0;
-    for (int idx = tid; idx < c.n; idx += SF_NT) {
-        const int lab = c.rp.lab[idx];
-        if (lab == SF_INVALID_LABEL) continue;
-        const float twc = (c.inv_max_c * c.rp.p[R_WC][idx]) * c.kph;
-        const float twd = c.inv_max_d * c.rp.p[R_WD][idx];
-        const float bc = twc * (-c.rp.p[R_DCT][idx]);
-        const float bd = twd * (-c.rp.p[R_DDT][idx]);
-        sabs += (double)fabsf(-bc);
-        sabs += (double)fabsf(-bd);
+    for (int i0 = tid * SF_VEC; i0 < c.n; i0 += SF_NT * SF_VEC) {
+        int lab[SF_VEC];
+        float wc[SF_VEC], wd[SF_VEC], dct_[SF_VEC], ddt_[SF_VEC];
+        load_labels<SF_VEC>(c.rp.lab, i0, lab);
+        load_plane<SF_VEC>(c.rp.p[R_WC], i0, wc);
+        load_plane<SF_VEC>(c.rp.p[R_WD], i0, wd);
+        load_plane<SF_VEC>(c.rp.p[R_DCT], i0, dct_);
+        load_plane<SF_VEC>(c.rp.p[R_DDT], i0, ddt_);
+#pragma unroll
+        for (int j = 0; j < SF_VEC; j++) {
+            if (lab[j] == SF_INVALID_LABEL) continue;
+            const float twc = (c.inv_max_c * wc[j]) * c.kph;
+            const float twd = c.inv_max_d * wd[j];
+            const float bc = twc * (-dct_[j]);
+            const float bd = twd * (-ddt_[j]);
+            sabs += (double)fabsf(-bc);
+            sabs += (double)fabsf(-bd);
+        }
     }
     sabs = wave_sum_f64(sabs);
     if ((tid & 63) == 0) s.red[tid >> 6][0] = sabs;
@@ -529,44 +593,49 @@ __device__ __noinline__ void irls_initial_residual(const KArgs &a, int b, int L,
 // pass 1: Cauchy x b weights, 21+6 normal-equation sums (reference :615-641) -> s.red[wave][0..26]
 __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, SolveShared &s, int tid) {
     const IrlsCtx c = make_irls_ctx(a, b, L, s);
-    const float inv_c_Cauchy = 1.f / (a.p.kc_Cauchy * s.aver_res);
+    const float inv_c_Cauchy = 1.f / (a.p.kc_Cauchy * uniform_f(s.aver_res));
     double acc[27];
 #pragma unroll
     for (int q = 0; q < 27; q++) acc[q] = 0.0;
     float Vr[6];
 #pragma unroll
-    for (int q = 0; q < 6; q++) Vr[q] = s.Var[q];
-    for (int idx = tid; idx < c.n; idx += SF_NT) {
-        PixRows r;
-        int lab;
-        if (!load_rows(c.rp, idx, c.inv_max_c, c.inv_max_d, c.f_inv, c.kph, r, lab)) continue;
-        const float b_weight = std_max(0.f, std_min(1.f, s.b_segm[lab]));
+    for (int q = 0; q < 6; q++) Vr[q] = uniform_f(s.Var[q]);
+    for (int i0 = tid * SF_VEC; i0 < c.n; i0 += SF_NT * SF_VEC) {
+        RecVec<SF_VEC> rv;
+        load_rec<SF_VEC>(c.rp, i0, rv);
 #pragma unroll
-        for (int row = 0; row < 2; row++) {
-            const float *ar = row ? r.ad : r.ac;
-            const float br = row ? r.bd : r.bc;
-            float res = -br;
+        for (int j = 0; j < SF_VEC; j++) {
+            if (rv.lab[j] == SF_INVALID_LABEL) continue;
+            PixRows r;
+            rows_of<SF_VEC>(rv, j, c.inv_max_c, c.inv_max_d, c.f_inv, c.kph, r);
+            const float b_weight = std_max(0.f, std_min(1.f, s.b_segm[rv.lab[j]]));
 #pragma unroll
-            for (int q = 0; q < 6; q++) res += Vr[q] * ar[q];
-            const float w = b_weight * sqrtf(1.f / (1.f + sqf(res * inv_c_Cauchy)));
-            double aw[7];
+            for (int row = 0; row < 2; row++) {
+                const float *ar = row ? r.ad : r.ac;
+                const float br = row ? r.bd : r.bc;
+                float res = -br;
 #pragma unroll
-            for (int q = 0; q < 6; q++) aw[q] = (double)(w * ar[q]);
-            aw[6] = (double)(w * br);
-            acc[0] = fma(aw[0], aw[0], acc[0]);   acc[1] = fma(aw[0], aw[1], acc[1]);
-            acc[2] = fma(aw[0], aw[2], acc[2]);   acc[3] = fma(aw[0], aw[3], acc[3]);
-            acc[4] = fma(aw[0], aw[4], acc[4]);   acc[5] = fma(aw[0], aw[5], acc[5]);
-            acc[6] = fma(aw[1], aw[1], acc[6]);   acc[7] = fma(aw[1], aw[2], acc[7]);
-            acc[8] = fma(aw[1], aw[3], acc[8]);   acc[9] = fma(aw[1], aw[4], acc[9]);
-            acc[10] = fma(aw[1], aw[5], acc[10]); acc[11] = fma(aw[2], aw[2], acc[11]);
-            acc[12] = fma(aw[2], aw[3], acc[12]); acc[13] = fma(aw[2], aw[4], acc[13]);
-            acc[14] = fma(aw[2], aw[5], acc[14]); acc[15] = fma(aw[3], aw[3], acc[15]);
-            acc[16] = fma(aw[3], aw[4], acc[16]); acc[17] = fma(aw[3], aw[5], acc[17]);
-            acc[18] = fma(aw[4], aw[4], acc[18]); acc[19] = fma(aw[4], aw[5], acc[19]);
-            acc[20] = fma(aw[5], aw[5], acc[20]);
-            acc[21] = fma(aw[0], aw[6], acc[21]); acc[22] = fma(aw[1], aw[6], acc[22]);
-            acc[23] = fma(aw[2], aw[6], acc[23]); acc[24] = fma(aw[3], aw[6], acc[24]);
-            acc[25] = fma(aw[4], aw[6], acc[25]); acc[26] = fma(aw[5], aw[6], acc[26]);
+                for (int q = 0; q < 6; q++) res += Vr[q] * ar[q];
+                const float w = b_weight * sqrtf(1.f / (1.f + sqf(res * inv_c_Cauchy)));
+                double aw[7];
+#pragma unroll
+                for (int q = 0; q < 6; q++) aw[q] = (double)(w * ar[q]);
+                aw[6] = (double)(w * br);
+                acc[0] = fma(aw[0], aw[0], acc[0]);   acc[1] = fma(aw[0], aw[1], acc[1]);
+                acc[2] = fma(aw[0], aw[2], acc[2]);   acc[3] = fma(aw[0], aw[3], acc[3]);
+                acc[4] = fma(aw[0], aw[4], acc[4]);   acc[5] = fma(aw[0], aw[5], acc[5]);
+                acc[6] = fma(aw[1], aw[1], acc[6]);   acc[7] = fma(aw[1], aw[2], acc[7]);
+                acc[8] = fma(aw[1], aw[3], acc[8]);   acc[9] = fma(aw[1], aw[4], acc[9]);
+                acc[10] = fma(aw[1], aw[5], acc[10]); acc[11] = fma(aw[2], aw[2], acc[11]);
+                acc[12] = fma(aw[2], aw[3], acc[12]); acc[13] = fma(aw[2], aw[4], acc[13]);
+                acc[14] = fma(aw[2], aw[5], acc[14]); acc[15] = fma(aw[3], aw[3], acc[15]);
+                acc[16] = fma(aw[3], aw[4], acc[16]); acc[17] = fma(aw[3], aw[5], acc[17]);
+                acc[18] = fma(aw[4], aw[4], acc[18]); acc[19] = fma(aw[4], aw[5], acc[19]);
+                acc[20] = fma(aw[5], aw[5], acc[20]);
+                acc[21] = fma(aw[0], aw[6], acc[21]); acc[22] = fma(aw[1], aw[6], acc[22]);
+                acc[23] = fma(aw[2], aw[6], acc[23]); acc[24] = fma(aw[3], aw[6], acc[24]);
+                acc[25] = fma(aw[4], aw[6], acc[25]); acc[26] = fma(aw[5], aw[6], acc[26]);
+            }
         }
     }
     const int lane = tid & 63, wave = tid >> 6;
@@ -611,26 +680,33 @@ __device__ __noinline__ void irls_pass2(const KArgs &a, int b, int L, SolveShare
     const int lane = tid & 63, wave = tid >> 6;
     float Vr[6];
 #pragma unroll
-    for (int q = 0; q < 6; q++) Vr[q] = s.Var[q];
+    for (int q = 0; q < 6; q++) Vr[q] = uniform_f(s.Var[q]);
     double sq = 0.0;
-    for (int base = 0; base < c.n; base += SF_NT) {
-        const int idx = base + tid;
-        PixRows r;
-        int lab = 0;
-        bool ok = false;
-        if (idx < c.n) ok = load_rows(c.rp, idx, c.inv_max_c, c.inv_max_d, c.f_inv, c.kph, r, lab);
-        long long fx = 0;
-        if (ok) {
-            float rc = -r.bc, rd = -r.bd;
+    for (int base = 0; base < c.n; base += SF_NT * SF_VEC) {
+        const int i0 = base + tid * SF_VEC;
+        RecVec<SF_VEC> rv;
+        const bool in = i0 < c.n;
+        if (in) load_rec<SF_VEC>(c.rp, i0, rv);
 #pragma unroll
-            for (int q = 0; q < 6; q++) rc += Vr[q] * r.ac[q];
+        for (int j = 0; j < SF_VEC; j++) {
+            const bool ok = in && rv.lab[j] != SF_INVALID_LABEL;
+            long long fx = 0;
+            int lab = 0;
+            if (ok) {
+                PixRows r;
+                rows_of<SF_VEC>(rv, j, c.inv_max_c, c.inv_max_d, c.f_inv, c.kph, r);
+                lab = rv.lab[j];
+                float rc = -r.bc, rd = -r.bd;
 #pragma unroll
-            for (int q = 0; q < 6; q++) rd += Vr[q] * r.ad[q];
-            sq = fma((double)rc, (double)rc, sq);
-            sq = fma((double)rd, (double)rd, sq);
-            fx = to_fix(fabsf(rc) + fabsf(rd), FIX_RES, 1.0e6f);
+                for (int q = 0; q < 6; q++) rc += Vr[q] * r.ac[q];
+#pragma unroll
+                for (int q = 0; q < 6; q++) rd += Vr[q] * r.ad[q];
+                sq = fma((double)rc, (double)rc, sq);
+                sq = fma((double)rd, (double)rd, sq);
+                fx = to_fix(fabsf(rc) + fabsf(rd), FIX_RES, 1.0e6f);
+            }
+            wave_label_add_i64(ok, lab, fx, s.lab_sum, lane);
         }
-        wave_label_add_i64(ok, lab, fx, s.lab_sum, lane);
     }
     sq = wave_sum_f64(sq);
     if (lane == 0) s.red[wave][27] = sq;

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for one workload: kernel-trace stats + HBM byte counters
+# (separate --pmc passes, as MI355X_MICROARCH.md prescribes). Run ON THE GPU BOX via gpurun.
+# usage: tools/rocprof_collect.sh <tag> <workload> <batch>
+set -u
+TAG=$1; WL=$2; B=$3
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_$TAG
+rm -rf $OUT; mkdir -p $OUT
+CMD="python tools/prof_run.py --workload $WL --batch $B --steps 3"
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $CMD > $OUT/fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write -- $CMD > $OUT/write.log 2>&1
+find $OUT -name "*.csv" | head -20

@@ -218,6 +218,11 @@ int SF_FN(get_counters)(sf_handle *h, int64_t *frames, int64_t *n_irls, int64_t 
  * 5 IRLS setup 6 IRLS pass 1 7 6x6 solve 8 IRLS pass 2 9 b-solve/convergence 10 filter/update
  * 11 residuals-vs-history 12 segm image + history push 13 total. */
 int SF_FN(get_stage_profile)(sf_handle *h, int64_t ticks[16]);
+/* The IRLS streaming passes in isolation: `reps` executions of pass `which` (1 = weights + normal
+ * equations, 2 = residuals + label sums) over the level-0 records of every stream left by the last
+ * solve, one launch of sf_irls_pass_kernel. variant 0 = product code; 1 = loads only; 2 = no
+ * accumulation (ablations). Elapsed HIP-event milliseconds of the launch. Not part of a solve. */
+int SF_FN(microbench_pass)(sf_handle *h, int which, int variant, int reps, float *elapsed_ms);
 /* Elapsed ms of the most recent solver kernel launch (HIP events around that launch). */
 int SF_FN(last_solver_kernel_ms)(sf_handle *h, float *ms);
 

@@ -386,6 +386,7 @@ int sfo_get_stage_profile(sf_handle *h, int64_t ticks[16]) {
     for (int q = 0; q < 16; q++) ticks[q] = 0;  // the oracle keeps no stage timers
     return SF_OK;
 }
+int sfo_microbench_pass(sf_handle *, int, int, int, float *) { return fail(SF_ERR_STATE, "not available in the CPU oracle"); }
 int sfo_last_solver_kernel_ms(sf_handle *h, float *ms) {
     if (!h || !ms) return fail(SF_ERR_ARG, "null");
     *ms = h->last_ms;

@@ -116,6 +116,7 @@ SIGNATURES = {
     "timed_process_frames": (C.c_int, [_H, C.c_int, C.c_int, _fp]),
     "get_counters": (C.c_int, [_H] + [C.POINTER(C.c_int64)] * 4),
     "get_stage_profile": (C.c_int, [_H, C.POINTER(C.c_int64)]),
+    "microbench_pass": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, _fp]),
     "last_solver_kernel_ms": (C.c_int, [_H, _fp]),
 }
 
@@ -325,6 +326,11 @@ class Solver:
         t = (C.c_int64 * 16)()
         self.api.check(self.api.get_stage_profile(self.h, t))
         return {n: t[i] * 1e-8 for i, n in enumerate(self.STAGES)}
+
+    def microbench_pass(self, which, variant, reps):
+        ms = C.c_float()
+        self.api.check(self.api.microbench_pass(self.h, which, variant, reps, C.byref(ms)))
+        return ms.value
 
     def timed_process_frames(self, im_count, calls):
         ms = C.c_float()

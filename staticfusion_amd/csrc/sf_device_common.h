@@ -26,8 +26,12 @@ enum {
     PF_TAIL, PF_FILTER, PF_RESIDUALS, PF_SEGM_HIST, PF_TOTAL, SF_PROF_SLOTS = 16
 };
 
-// record planes written by the linearisation and streamed by the IRLS passes
-enum { R_D = 0, R_X, R_Y, R_DCU, R_DCV, R_DCT, R_DDU, R_DDV, R_DDT, R_WC, R_WD, R_COUNT };
+// record planes written by the linearisation and streamed by the IRLS passes.  Only what cannot be
+// recomputed per pixel is stored: the warped depth, the four stencil gradients and the intensity
+// difference (24 B) + one label byte; the passes also read the NEW depth from the pyramid (4 B).
+// Inter depth / x / y, ddt and both pre-weights are recomputed with the reference's float
+// expressions (bit-identical), which cuts the streamed bytes from 45 to 29 per pixel and pass.
+enum { R_DW = 0, R_DCU, R_DCV, R_DCT, R_DDU, R_DDV, R_COUNT };
 
 // stage mask bits of the frame kernel
 enum {

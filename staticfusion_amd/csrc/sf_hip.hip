@@ -79,6 +79,31 @@ __global__ __launch_bounds__(SF_NT, 4) void sf_frame_kernel(const KArgs *__restr
     }
 }
 
+// the IRLS passes alone (measurement support; never part of a solve)
+__global__ __launch_bounds__(SF_NT, 4) void sf_irls_pass_kernel(const KArgs *__restrict__ ka, int which, int variant, int reps) {
+    __shared__ FrameShared sh;
+    __shared__ int s_next;
+    const KArgs &a = *ka;
+    const int tid = threadIdx.x;
+    for (;;) {
+        if (tid == 0) s_next = atomicAdd(a.queue, 1);
+        __syncthreads();
+        const int b = __builtin_amdgcn_readfirstlane(s_next);
+        __syncthreads();
+        if (b >= a.batch) break;
+        if (which == 1) {
+            if (variant == 0) microbench_pass<1, 0>(a, b, reps, sh.sv, tid);
+            if (variant == 1) microbench_pass<1, 1>(a, b, reps, sh.sv, tid);
+            if (variant == 2) microbench_pass<1, 2>(a, b, reps, sh.sv, tid);
+        } else {
+            if (variant == 0) microbench_pass<2, 0>(a, b, reps, sh.sv, tid);
+            if (variant == 1) microbench_pass<2, 1>(a, b, reps, sh.sv, tid);
+            if (variant == 2) microbench_pass<2, 2>(a, b, reps, sh.sv, tid);
+        }
+        __syncthreads();
+    }
+}
+
 // =============================================================================================
 //  host side
 // =============================================================================================
@@ -548,16 +573,48 @@ int sf_get_lin_plane(sf_handle *h, int stream, int which, float *out, int *rows,
     if (!out) return SF_OK;
     const size_t n = h->k.ln[L], o = (size_t)stream * h->k.n0;
     if (which == SF_LIN_NULL) {
+        if (!h->k.p.debug_planes) return fail(SF_ERR_STATE, "the Null plane needs params.debug_planes = 1");
         std::vector<uint8_t> tmp(n);
         if (int e = d2h(h, tmp.data(), h->k.rec_null + o, n)) return e;
         for (size_t q = 0; q < n; q++) out[q] = tmp[q] ? 1.f : 0.f;
         return SF_OK;
     }
-    static const int plane_of[SF_LIN_COUNT] = {R_DCU, R_DCV, R_DCT, R_DDU, R_DDV, R_DDT, R_WC, R_WD, -1};
-    if (int e = d2h(h, out, h->k.rec[plane_of[which]] + o, sizeof(float) * n)) return e;
-    if (which == SF_LIN_WC || which == SF_LIN_WD) {  // weights_c = inv_max_c*weights_c (reference :505-509)
-        const float inv_max = (which == SF_LIN_WC) ? st.inv_max_c : st.inv_max_d;
-        for (size_t q = 0; q < n; q++) out[q] = inv_max * out[q];
+    // dcu..ddv and dct are stored; ddt and the pre-weights are recomputed exactly as the kernels do
+    std::vector<float> dn(n), dw(n);
+    if (int e = d2h(h, dn.data(), h->k.pyr_new[0] + (size_t)stream * h->k.n_tot + h->k.loff[L], sizeof(float) * n)) return e;
+    if (int e = d2h(h, dw.data(), h->k.rec[R_DW] + o, sizeof(float) * n)) return e;
+    auto fetch = [&](int plane, std::vector<float> &v) { v.resize(n); return d2h(h, v.data(), h->k.rec[plane] + o, sizeof(float) * n); };
+    std::vector<uint8_t> lab(n);
+    if (int e = d2h(h, lab.data(), h->k.rec_lab + o, n)) return e;
+    switch (which) {
+        case SF_LIN_DCU: return d2h(h, out, h->k.rec[R_DCU] + o, sizeof(float) * n);
+        case SF_LIN_DCV: return d2h(h, out, h->k.rec[R_DCV] + o, sizeof(float) * n);
+        case SF_LIN_DCT: return d2h(h, out, h->k.rec[R_DCT] + o, sizeof(float) * n);
+        case SF_LIN_DDU: return d2h(h, out, h->k.rec[R_DDU] + o, sizeof(float) * n);
+        case SF_LIN_DDV: return d2h(h, out, h->k.rec[R_DDV] + o, sizeof(float) * n);
+        case SF_LIN_DDT:
+            for (size_t q = 0; q < n; q++) out[q] = dn[q] - dw[q];
+            return SF_OK;
+        default: break;
+    }
+    std::vector<float> t, gu, gv;
+    const bool colour = (which == SF_LIN_WC);
+    if (int e = fetch(colour ? R_DCU : R_DDU, gu)) return e;
+    if (int e = fetch(colour ? R_DCV : R_DDV, gv)) return e;
+    if (colour) {
+        if (int e = fetch(R_DCT, t)) return e;
+    } else {
+        t.resize(n);
+        for (size_t q = 0; q < n; q++) t[q] = dn[q] - dw[q];
+    }
+    for (size_t q = 0; q < n; q++) {
+        float w = 0.f;
+        if (lab[q] != SF_INVALID_LABEL) {  // weights are 0 outside validPixels (reference :483-484)
+            const float err = (colour ? 10.f : 200.f) * (std::fabs(t[q]) + std::fabs(gu[q]) + std::fabs(gv[q]));
+            w = std::sqrt(1.f / ((colour ? 1.f : 0.01f) + err));
+            w = (colour ? st.inv_max_c : st.inv_max_d) * w;
+        }
+        out[q] = w;
     }
     return SF_OK;
 }
@@ -603,6 +660,21 @@ int sf_get_stage_profile(sf_handle *h, int64_t ticks[16]) {
     for (int q = 0; q < 16; q++) ticks[q] = 0;
     for (auto &s : st)
         for (int q = 0; q < SF_PROF_SLOTS; q++) ticks[q] += s.prof[q];
+    return SF_OK;
+}
+int sf_microbench_pass(sf_handle *h, int which, int variant, int reps, float *elapsed_ms) {
+    if (!h || (which != 1 && which != 2) || variant < 0 || variant > 2 || reps < 1) return fail(SF_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemsetAsync(h->k.queue, 0, sizeof(int), h->stream));
+    const int grid = std::min(h->k.batch, h->max_blocks);
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(sf_irls_pass_kernel, dim3(grid), dim3(SF_NT), 0, h->stream, (const KArgs *)h->d_args, which, variant, reps);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (elapsed_ms) *elapsed_ms = ms;
     return SF_OK;
 }
 int sf_last_solver_kernel_ms(sf_handle *h, float *ms) {

@@ -52,7 +52,7 @@ struct SolveShared {
     // IRLS
     float AtA[36], AtB[6], Var[6], prev_sol[6];
     float aver_res, aver_res_old, inv_max_c, inv_max_d, res_sqnorm;
-    int n_valid, ctrl, status, n_irls, n_outer;
+    int n_valid, ctrl, status, n_irls, n_outer, first;
     long long pixel_iters;
     // small solves
     float M6[6 * 7], tmp6[6], y6[6];
@@ -128,6 +128,7 @@ typedef __attribute__((address_space(1))) const unsigned int gcu32;
 
 struct RecPtrs {
     gcfloat *p[R_COUNT];
+    gcfloat *dnew;  // NEW depth of the level (pyramid plane)
     gcu8 *lab;
 };
 
@@ -167,19 +168,63 @@ __device__ __forceinline__ void load_labels(gcu8 *p, int idx0, int (&out)[VEC]) 
 template <int VEC>
 struct RecVec {
     float v[R_COUNT][VEC];
+    float dn[VEC];
     int lab[VEC];
 };
 template <int VEC>
 __device__ __forceinline__ void load_rec(const RecPtrs &rp, int idx0, RecVec<VEC> &r) {
     load_labels<VEC>(rp.lab, idx0, r.lab);
+    load_plane<VEC>(rp.dnew, idx0, r.dn);
 #pragma unroll
     for (int q = 0; q < R_COUNT; q++) load_plane<VEC>(rp.p[q], idx0, r.v[q]);
 }
+
+// Per-level constants needed to rebuild a pixel's rows from its compact record.
+struct LevelGeom {
+    int rows_i;
+    float inv_rows;   // 1/rows_i, to split a flat index into (v, u)
+    float disp_u_i, disp_v_i;
+    float inv_f_pyr;  // 2 tan(fovh/2) / cols_i        (pyramid xx/yy, reference FrontEnd.cpp:378)
+    float inv_f_w;    // 1 / (cols_i / (2 tan(fovh/2)))  (warp xx/yy,    reference FrontEnd.cpp:874)
+    float f_inv;      // cols_i / (2 tan(fovh/2))       (reference :537; it is f)
+    float kph, inv_max_c, inv_max_d;
+    int first;        // Warped := Pred iteration: xxWarped / yyWarped use the pyramid formula
+};
+
+// The two Jacobian rows of pixel `idx` from its record. Every expression below repeats, with the
+// same association, what the linearisation / the reference computes for this pixel
+// (calculateCoord :403-407, warp :883-884, pyramid :385-386, derivatives :478, weights :494-501).
+__device__ __forceinline__ void rows_from_record(const LevelGeom &g, int idx, float dn, float dw, float dcu_, float dcv_,
+                                                 float dct_, float ddu_, float ddv_, PixRows &out) {
+    int u = (int)((float)idx * g.inv_rows);
+    if (u * g.rows_i > idx) u--;
+    if ((u + 1) * g.rows_i <= idx) u++;
+    const int v = idx - u * g.rows_i;
+    const float fu = float(u), fv = float(v);
+    const float xn = (g.inv_f_pyr * (fu - g.disp_u_i)) * dn;
+    const float yn = (g.inv_f_pyr * (fv - g.disp_v_i)) * dn;
+    float xw, yw;
+    if (g.first) {
+        xw = (g.inv_f_pyr * (fu - g.disp_u_i)) * dw;
+        yw = (g.inv_f_pyr * (fv - g.disp_v_i)) * dw;
+    } else {
+        xw = (fu - g.disp_u_i) * dw * g.inv_f_w;
+        yw = (fv - g.disp_v_i) * dw * g.inv_f_w;
+    }
+    const float d_i = 0.5f * (dn + dw);
+    const float x_i = 0.5f * (xn + xw);
+    const float y_i = 0.5f * (yn + yw);
+    const float ddt_ = dn - dw;
+    const float error_l_c = 10.f * (fabsf(dct_) + fabsf(dcu_) + fabsf(dcv_));
+    const float error_l_d = 200.f * (fabsf(ddt_) + fabsf(ddu_) + fabsf(ddv_));
+    const float wc = sqrtf(1.f / (1.f + error_l_c));
+    const float wd = sqrtf(1.f / (0.01f + error_l_d));
+    build_rows(d_i, x_i, y_i, dcu_, dcv_, dct_, ddu_, ddv_, ddt_, g.inv_max_c * wc, g.inv_max_d * wd, g.f_inv, g.kph, out);
+}
 template <int VEC>
-__device__ __forceinline__ void rows_of(const RecVec<VEC> &r, int j, float inv_max_c, float inv_max_d, float f_inv,
-                                        float kph, PixRows &out) {
-    build_rows(r.v[R_D][j], r.v[R_X][j], r.v[R_Y][j], r.v[R_DCU][j], r.v[R_DCV][j], r.v[R_DCT][j], r.v[R_DDU][j],
-               r.v[R_DDV][j], r.v[R_DDT][j], inv_max_c * r.v[R_WC][j], inv_max_d * r.v[R_WD][j], f_inv, kph, out);
+__device__ __forceinline__ void rows_of(const RecVec<VEC> &r, int j, int idx0, const LevelGeom &g, PixRows &out) {
+    rows_from_record(g, idx0 + j, r.dn[j], r.v[R_DW][j], r.v[R_DCU][j], r.v[R_DCV][j], r.v[R_DCT][j], r.v[R_DDU][j],
+                     r.v[R_DDV][j], out);
 }
 
 // res = -B; res += Var(k)*A(k), k = 0..5   (reference FrontEnd.cpp:644-646)
@@ -284,6 +329,7 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
     const uint8_t *labels = a.labels + sb + o;
     const bool seg = a.p.segmentation_enabled != 0;
     const bool dbg = a.p.debug_planes != 0;
+    if (tid == 0) s.first = first ? 1 : 0;
 
     const float f = float(cols_i) / (2.f * a.tan_half_fovh);
     const float inv_f_w = 1.f / f;  // the warp's 1/f (reference FrontEnd.cpp:874), not the pyramid's
@@ -394,20 +440,15 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                 max_d = (wd > max_d) ? wd : max_d;
                 n_valid++;
             }
-            a.rec[R_D][rb + idx] = d_i;
-            a.rec[R_X][rb + idx] = x_i;
-            a.rec[R_Y][rb + idx] = y_i;
+            a.rec[R_DW][rb + idx] = dw;
             a.rec[R_DCU][rb + idx] = dcu_;
             a.rec[R_DCV][rb + idx] = dcv_;
             a.rec[R_DCT][rb + idx] = dct_;
             a.rec[R_DDU][rb + idx] = ddu_;
             a.rec[R_DDV][rb + idx] = ddv_;
-            a.rec[R_DDT][rb + idx] = ddt_;
-            a.rec[R_WC][rb + idx] = wc;
-            a.rec[R_WD][rb + idx] = wd;
             a.rec_lab[rb + idx] = valid ? (uint8_t)(seg ? lab : 0) : (uint8_t)SF_INVALID_LABEL;
-            a.rec_null[rb + idx] = nul ? 1 : 0;
             if (dbg) {
+                a.rec_null[rb + idx] = nul ? 1 : 0;
                 const size_t q = sb + o + idx;
                 a.dbg_warped[0][q] = dw;
                 a.dbg_warped[1][q] = s.t_iw[e];
@@ -536,16 +577,28 @@ __device__ __noinline__ void solve_filter_and_update(const KArgs &a, SolveShared
     for (int i = 0; i < 6; i++) s.twist[i] = tw[i];
 }
 
+// A pixel that is not in validPixels gets a harmless stand-in record (finite rows) and weight 0,
+// so the streaming loops are branch-free: no exec-mask juggling around the 27 accumulators.
+template <int VEC>
+__device__ __forceinline__ bool sanitize(RecVec<VEC> &r, int j) {
+    const bool ok = r.lab[j] != SF_INVALID_LABEL;
+    r.dn[j] = ok ? r.dn[j] : 1.f;
+    r.v[R_DW][j] = ok ? r.v[R_DW][j] : 1.f;
+#pragma unroll
+    for (int q = R_DCU; q < R_COUNT; q++) r.v[q][j] = ok ? r.v[q][j] : 0.f;
+    r.lab[j] = ok ? r.lab[j] : 0;
+    return ok;
+}
+
 // ---------------------------------------------------------------------------------------------
 //  solveOdometryAndSegmJoint (reference FrontEnd.cpp:513-692), split into separately compiled
 //  pieces so that each streaming pass gets its own register allocation.
 // ---------------------------------------------------------------------------------------------
 struct IrlsCtx {
     RecPtrs rp;
-    int n;        // pixels of the level
-    int N;        // valid pixels
-    float f_inv;  // reference :537 (it is f)
-    float kph, inv_max_c, inv_max_d;
+    LevelGeom g;
+    int n;  // pixels of the level
+    int N;  // valid pixels
 };
 
 __device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, const SolveShared &s) {
@@ -553,13 +606,23 @@ __device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, c
     const size_t rb = (size_t)b * a.n0;
 #pragma unroll
     for (int q = 0; q < R_COUNT; q++) c.rp.p[q] = (gcfloat *)(a.rec[q] + rb);
+    c.rp.dnew = (gcfloat *)(a.pyr_new[0] + (size_t)b * a.n_tot + a.loff[L]);
     c.rp.lab = (gcu8 *)(a.rec_lab + rb);
     c.n = a.ln[L];
     c.N = uniform_i(s.n_valid);
-    c.f_inv = float(a.lcols[L]) / (2.f * a.tan_half_fovh);
-    c.kph = a.p.k_photometric_res;
-    c.inv_max_c = uniform_f(s.inv_max_c);
-    c.inv_max_d = uniform_f(s.inv_max_d);
+    const int rows_i = a.lrows[L], cols_i = a.lcols[L];
+    const float f = float(cols_i) / (2.f * a.tan_half_fovh);
+    c.g.rows_i = rows_i;
+    c.g.inv_rows = 1.f / float(rows_i);
+    c.g.disp_u_i = 0.5f * float(cols_i - 1);
+    c.g.disp_v_i = 0.5f * float(rows_i - 1);
+    c.g.inv_f_pyr = 2.f * a.tan_half_fovh / float(cols_i);
+    c.g.inv_f_w = 1.f / f;
+    c.g.f_inv = f;
+    c.g.kph = a.p.k_photometric_res;
+    c.g.inv_max_c = uniform_f(s.inv_max_c);
+    c.g.inv_max_d = uniform_f(s.inv_max_d);
+    c.g.first = uniform_i(s.first);
     return c;
 }
 
@@ -568,22 +631,15 @@ __device__ __noinline__ void irls_initial_residual(const KArgs &a, int b, int L,
     const IrlsCtx c = make_irls_ctx(a, b, L, s);
     double sabs = 0.0;
     for (int i0 = tid * SF_VEC; i0 < c.n; i0 += SF_NT * SF_VEC) {
-        int lab[SF_VEC];
-        float wc[SF_VEC], wd[SF_VEC], dct_[SF_VEC], ddt_[SF_VEC];
-        load_labels<SF_VEC>(c.rp.lab, i0, lab);
-        load_plane<SF_VEC>(c.rp.p[R_WC], i0, wc);
-        load_plane<SF_VEC>(c.rp.p[R_WD], i0, wd);
-        load_plane<SF_VEC>(c.rp.p[R_DCT], i0, dct_);
-        load_plane<SF_VEC>(c.rp.p[R_DDT], i0, ddt_);
+        RecVec<SF_VEC> rv;
+        load_rec<SF_VEC>(c.rp, i0, rv);
 #pragma unroll
         for (int j = 0; j < SF_VEC; j++) {
-            if (lab[j] == SF_INVALID_LABEL) continue;
-            const float twc = (c.inv_max_c * wc[j]) * c.kph;
-            const float twd = c.inv_max_d * wd[j];
-            const float bc = twc * (-dct_[j]);
-            const float bd = twd * (-ddt_[j]);
-            sabs += (double)fabsf(-bc);
-            sabs += (double)fabsf(-bd);
+            const bool ok = sanitize<SF_VEC>(rv, j);
+            PixRows r;
+            rows_of<SF_VEC>(rv, j, i0, c.g, r);
+            sabs += ok ? (double)fabsf(-r.bc) : 0.0;
+            sabs += ok ? (double)fabsf(-r.bd) : 0.0;
         }
     }
     sabs = wave_sum_f64(sabs);
@@ -591,6 +647,10 @@ __device__ __noinline__ void irls_initial_residual(const KArgs &a, int b, int L,
 }
 
 // pass 1: Cauchy x b weights, 21+6 normal-equation sums (reference :615-641) -> s.red[wave][0..26]
+// VAR: 0 = product code; 1 = loads only; 2 = rows + weights, no fp64 accumulation (ablation builds
+// for tools/pass_microbench.py; the product always instantiates VAR 0)
+// pass 1: Cauchy x b weights, 21+6 normal-equation sums (reference :615-641) -> s.red[wave][0..26]
+template <int VAR>
 __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, SolveShared &s, int tid) {
     const IrlsCtx c = make_irls_ctx(a, b, L, s);
     const float inv_c_Cauchy = 1.f / (a.p.kc_Cauchy * uniform_f(s.aver_res));
@@ -605,10 +665,17 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, SolveShare
         load_rec<SF_VEC>(c.rp, i0, rv);
 #pragma unroll
         for (int j = 0; j < SF_VEC; j++) {
-            if (rv.lab[j] == SF_INVALID_LABEL) continue;
+            const bool ok = sanitize<SF_VEC>(rv, j);
+            if constexpr (VAR == 1) {
+                float t = rv.dn[j];
+#pragma unroll
+                for (int q = 0; q < R_COUNT; q++) t += rv.v[q][j];
+                acc[0] += (double)t;
+                continue;
+            }
             PixRows r;
-            rows_of<SF_VEC>(rv, j, c.inv_max_c, c.inv_max_d, c.f_inv, c.kph, r);
-            const float b_weight = std_max(0.f, std_min(1.f, s.b_segm[rv.lab[j]]));
+            rows_of<SF_VEC>(rv, j, i0, c.g, r);
+            const float b_weight = ok ? std_max(0.f, std_min(1.f, s.b_segm[rv.lab[j]])) : 0.f;
 #pragma unroll
             for (int row = 0; row < 2; row++) {
                 const float *ar = row ? r.ad : r.ac;
@@ -621,6 +688,10 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, SolveShare
 #pragma unroll
                 for (int q = 0; q < 6; q++) aw[q] = (double)(w * ar[q]);
                 aw[6] = (double)(w * br);
+                if constexpr (VAR == 2) {
+                    acc[0] += ((aw[0] + aw[1]) + (aw[2] + aw[3])) + ((aw[4] + aw[5]) + aw[6]);
+                    continue;
+                }
                 acc[0] = fma(aw[0], aw[0], acc[0]);   acc[1] = fma(aw[0], aw[1], acc[1]);
                 acc[2] = fma(aw[0], aw[2], acc[2]);   acc[3] = fma(aw[0], aw[3], acc[3]);
                 acc[4] = fma(aw[0], aw[4], acc[4]);   acc[5] = fma(aw[0], aw[5], acc[5]);
@@ -674,7 +745,21 @@ __device__ __noinline__ void irls_solve_normal(SolveShared &s, int lane) {
     if (lane < SF_NC) s.lab_sum[lane] = 0;
 }
 
-// pass 2: residuals with the new solution, per-label sums, ||res||^2 (reference :644-667)
+// non-negative float (< 2^20) -> Q32.32 fixed point without the emulated float->int64 conversion
+__device__ __forceinline__ unsigned long long to_fix32_pos(float x) {
+    float y = x;
+    if (!(y < 1.0e6f)) y = 1.0e6f;  // also catches NaN
+    const unsigned hi = (unsigned)y;              // floor
+    const float frac = y - (float)hi;              // exact
+    const unsigned lo = (unsigned)(frac * 4294967296.f);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// pass 2: residuals with the new solution, per-label sums, ||res||^2 (reference :644-667).
+// Per-label sums: each lane keeps a running fixed-point sum for the label of its last pixel and
+// flushes it to the workgroup bins (LDS integer atomics: order-independent) only when the label
+// changes -- labels are spatially coherent, so flushes are rare.
+template <int VAR>
 __device__ __noinline__ void irls_pass2(const KArgs &a, int b, int L, SolveShared &s, int tid) {
     const IrlsCtx c = make_irls_ctx(a, b, L, s);
     const int lane = tid & 63, wave = tid >> 6;
@@ -682,32 +767,47 @@ __device__ __noinline__ void irls_pass2(const KArgs &a, int b, int L, SolveShare
 #pragma unroll
     for (int q = 0; q < 6; q++) Vr[q] = uniform_f(s.Var[q]);
     double sq = 0.0;
-    for (int base = 0; base < c.n; base += SF_NT * SF_VEC) {
-        const int i0 = base + tid * SF_VEC;
+    int cur_lab = 0;
+    unsigned long long cur_sum = 0;
+    for (int i0 = tid * SF_VEC; i0 < c.n; i0 += SF_NT * SF_VEC) {
         RecVec<SF_VEC> rv;
-        const bool in = i0 < c.n;
-        if (in) load_rec<SF_VEC>(c.rp, i0, rv);
+        load_rec<SF_VEC>(c.rp, i0, rv);
 #pragma unroll
         for (int j = 0; j < SF_VEC; j++) {
-            const bool ok = in && rv.lab[j] != SF_INVALID_LABEL;
-            long long fx = 0;
-            int lab = 0;
-            if (ok) {
-                PixRows r;
-                rows_of<SF_VEC>(rv, j, c.inv_max_c, c.inv_max_d, c.f_inv, c.kph, r);
-                lab = rv.lab[j];
-                float rc = -r.bc, rd = -r.bd;
+            const bool ok = sanitize<SF_VEC>(rv, j);
+            if constexpr (VAR == 1) {
+                float t = rv.dn[j];
 #pragma unroll
-                for (int q = 0; q < 6; q++) rc += Vr[q] * r.ac[q];
-#pragma unroll
-                for (int q = 0; q < 6; q++) rd += Vr[q] * r.ad[q];
-                sq = fma((double)rc, (double)rc, sq);
-                sq = fma((double)rd, (double)rd, sq);
-                fx = to_fix(fabsf(rc) + fabsf(rd), FIX_RES, 1.0e6f);
+                for (int q = 0; q < R_COUNT; q++) t += rv.v[q][j];
+                sq += (double)t;
+                continue;
             }
-            wave_label_add_i64(ok, lab, fx, s.lab_sum, lane);
+            PixRows r;
+            rows_of<SF_VEC>(rv, j, i0, c.g, r);
+            float rc = -r.bc, rd = -r.bd;
+#pragma unroll
+            for (int q = 0; q < 6; q++) rc += Vr[q] * r.ac[q];
+#pragma unroll
+            for (int q = 0; q < 6; q++) rd += Vr[q] * r.ad[q];
+            rc = ok ? rc : 0.f;
+            rd = ok ? rd : 0.f;
+            sq = fma((double)rc, (double)rc, sq);
+            sq = fma((double)rd, (double)rd, sq);
+            const unsigned long long fx = to_fix32_pos(fabsf(rc) + fabsf(rd));
+            if constexpr (VAR == 2) {
+                sq += (double)(unsigned)(fx >> 32);
+                continue;
+            }
+            const int lab = ok ? rv.lab[j] : cur_lab;
+            if (lab != cur_lab) {
+                if (cur_sum) atomicAdd((unsigned long long *)&s.lab_sum[cur_lab], cur_sum);
+                cur_lab = lab;
+                cur_sum = 0;
+            }
+            cur_sum += fx;
         }
     }
+    if (cur_sum) atomicAdd((unsigned long long *)&s.lab_sum[cur_lab], cur_sum);
     sq = wave_sum_f64(sq);
     if (lane == 0) s.red[wave][27] = sq;
 }
@@ -833,13 +933,13 @@ __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level,
     int iters_done = 0;
     for (int k = 1; k <= a.p.max_iter_irls; k++) {
         iters_done = k;
-        irls_pass1(a, b, L, s, tid);
+        irls_pass1<0>(a, b, L, s, tid);
         __syncthreads();
         PROF_MARK(s, tid, PF_PASS1);
         if (wave == 0) irls_solve_normal(s, lane);
         __syncthreads();
         PROF_MARK(s, tid, PF_SOLVE6);
-        irls_pass2(a, b, L, s, tid);
+        irls_pass2<0>(a, b, L, s, tid);
         __syncthreads();
         PROF_MARK(s, tid, PF_PASS2);
         if (wave == 0) irls_iteration_tail(a, s, N, k, lane);
@@ -962,4 +1062,32 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, SolveShared &s, 
         st.lambda_t_w[tid] = s.lambda_t_w[tid];
     }
     __syncthreads();
+}
+
+
+// ---------------------------------------------------------------------------------------------
+//  measurement support: the two IRLS streaming passes in isolation, over the level-0 records the
+//  last solve left behind (tools/pass_microbench.py, sf_microbench_pass)
+// ---------------------------------------------------------------------------------------------
+template <int WHICH, int VAR>
+__device__ void microbench_pass(const KArgs &a, int b, int reps, SolveShared &s, int tid) {
+    const StreamState &st = a.state[b];
+    if (tid < SF_NC) s.b_segm[tid] = a.p.segmentation_enabled ? st.b_segm[tid] : 1.f;
+    if (tid < 6) s.Var[tid] = st.twist_level[tid];
+    if (tid == 0) {
+        s.inv_max_c = st.inv_max_c;
+        s.inv_max_d = st.inv_max_d;
+        s.aver_res = 0.002f;
+        s.first = 0;
+        s.n_valid = a.ln[0];
+    }
+    if (tid < SF_NC) s.lab_sum[tid] = 0;
+    __syncthreads();
+    for (int r = 0; r < reps; r++) {
+        if (WHICH == 1)
+            irls_pass1<VAR>(a, b, 0, s, tid);
+        else
+            irls_pass2<VAR>(a, b, 0, s, tid);
+        __syncthreads();
+    }
 }

@@ -79,6 +79,19 @@ def algorithmic_bytes(stats_list, levels_n, n_l1, seg, with_residuals):
     return total
 
 
+def reduce_over_ranks(dist, device, elapsed, iters, frames):
+    """MAX of the elapsed time, SUM of the counters over ranks (dist is None for one process)."""
+    if dist is None:
+        return elapsed, iters, frames
+    import torch
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    c = torch.tensor([float(iters), float(frames)], dtype=torch.float64, device=device)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(c[0].item()), float(c[1].item())
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -173,16 +186,7 @@ def main():
     im += 1
     stats_last = [solver.stats(b) for b in range(min(B, args.distinct))]
 
-    t_max = elapsed
-    iters_all = iters_total
-    frames_all = B * args.steps
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_max = float(t.item())
-        c = torch.tensor([iters_total, B * args.steps], dtype=torch.float64, device="cuda")
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        iters_all, frames_all = float(c[0].item()), float(c[1].item())
+    t_max, iters_all, frames_all = reduce_over_ranks(dist, torch.device("cuda", local_rank), elapsed, iters_total, B * args.steps)
 
     if rank == 0:
         levels_n = [solver.level_shape(L)[0] * solver.level_shape(L)[1] for L in range(solver.levels)]

@@ -155,6 +155,9 @@ int SF_FN(set_prediction_device)(sf_handle *h, const void *d_depth, const void *
 /* The bootstrap `depthCurrent.swap(depthPrediction)` (StaticFusion-imagesequenceassoc.cpp:105-108):
  * prediction := current, for every stream. */
 int SF_FN(current_to_prediction)(sf_handle *h);
+/* State injection for buildSegmImage (SegmentationBackground.cpp:176-197): clusterAllocation[0]
+ * (rows*cols int32, column-major), b_segm (24), perClusterAverageResidual (24). Any pointer may be NULL. */
+int SF_FN(set_segm_state)(sf_handle *h, int stream, const int32_t *labels0, const float *b_segm, const float *cluster_res);
 /* twist_odometry_old (carried motion-filter state, FrontEnd.cpp:1141-1144); rarely needed. */
 int SF_FN(set_twist_old)(sf_handle *h, int stream, const float twist[6]);
 

@@ -179,6 +179,19 @@ int sfo_current_to_prediction(sf_handle *h) {
     }
     return SF_OK;
 }
+int sfo_set_segm_state(sf_handle *h, int stream, const int32_t *labels0, const float *b_segm, const float *cluster_res) {
+    if (int e = check_stream(h, stream)) return e;
+    auto &s = *h->s[stream];
+    if (labels0) {
+        for (size_t q = 0; q < s.clusterAllocation[0].size(); q++) {
+            if (labels0[q] < 0 || labels0[q] > SF_NUM_CLUSTERS) return fail(SF_ERR_ARG, "label out of range");
+            s.clusterAllocation[0].d[q] = labels0[q];
+        }
+    }
+    if (b_segm) std::memcpy(s.b_segm, b_segm, SF_NUM_CLUSTERS * sizeof(float));
+    if (cluster_res) std::memcpy(s.perClusterAverageResidual, cluster_res, SF_NUM_CLUSTERS * sizeof(float));
+    return SF_OK;
+}
 int sfo_set_twist_old(sf_handle *h, int stream, const float twist[6]) {
     if (int e = check_stream(h, stream)) return e;
     for (int i = 0; i < 6; i++) h->s[stream]->twist_odometry_old[i] = twist[i];

@@ -89,6 +89,7 @@ SIGNATURES = {
     "set_current_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "set_prediction_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "current_to_prediction": (C.c_int, [_H]),
+    "set_segm_state": (C.c_int, [_H, C.c_int, _ip, _fp, _fp]),
     "set_twist_old": (C.c_int, [_H, C.c_int, _fp]),
     "build_pyramid": (C.c_int, [_H, C.c_int]),
     "kmeans": (C.c_int, [_H]),
@@ -207,6 +208,16 @@ class Solver:
 
     def current_to_prediction(self):
         self.api.check(self.api.current_to_prediction(self.h))
+
+    def set_segm_state(self, stream, labels0=None, b_segm=None, cluster_res=None):
+        lab = None if labels0 is None else np.ascontiguousarray(np.asarray(labels0, dtype=np.int32).T)
+        bb = None if b_segm is None else np.ascontiguousarray(b_segm, dtype=np.float32)
+        cr = None if cluster_res is None else np.ascontiguousarray(cluster_res, dtype=np.float32)
+        self.api.check(self.api.set_segm_state(
+            self.h, stream,
+            None if lab is None else lab.ctypes.data_as(_ip),
+            None if bb is None else bb.ctypes.data_as(_fp),
+            None if cr is None else cr.ctypes.data_as(_fp)))
 
     def set_twist_old(self, stream, twist):
         t = np.ascontiguousarray(twist, dtype=np.float32)

@@ -435,6 +435,24 @@ int sf_current_to_prediction(sf_handle *h) {
                                  h->stream));
     return SF_OK;
 }
+int sf_set_segm_state(sf_handle *h, int stream, const int32_t *labels0, const float *b_segm, const float *cluster_res) {
+    if (int e = check_stream(h, stream)) return e;
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<uint8_t> lab;
+    if (labels0) {
+        lab.resize(h->k.n0);
+        for (int q = 0; q < h->k.n0; q++) {
+            if (labels0[q] < 0 || labels0[q] > SF_NC) return fail(SF_ERR_ARG, "label out of range");
+            lab[q] = (uint8_t)labels0[q];
+        }
+        HIP_TRY(hipMemcpyAsync(h->k.labels + (size_t)stream * h->k.n_tot, lab.data(), lab.size(), hipMemcpyHostToDevice, h->stream));
+    }
+    if (b_segm) HIP_TRY(hipMemcpyAsync(h->k.state[stream].b_segm, b_segm, SF_NC * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (cluster_res)
+        HIP_TRY(hipMemcpyAsync(h->k.state[stream].cluster_res, cluster_res, SF_NC * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SF_OK;
+}
 int sf_set_twist_old(sf_handle *h, int stream, const float twist[6]) {
     if (int e = check_stream(h, stream)) return e;
     HIP_TRY(hipSetDevice(h->device));

@@ -1,0 +1,86 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs an MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ora():
+    """The CPU oracle (oracle/liboracle.so), built on demand with gcc."""
+    from oracle import binding
+
+    binding.build()
+    return binding.load()
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product library. No fallback: a missing extension or GPU is a test ERROR, not a skip."""
+    import staticfusion_amd as sf
+
+    return sf.load()
+
+
+def _pairs():
+    from staticfusion_amd.synth import make_pair
+
+    cache = {}
+
+    def get(seed=11, sphere=False, rows=120, cols=160, xi=None):
+        key = (seed, sphere, rows, cols, None if xi is None else tuple(xi))
+        if key not in cache:
+            kw = {} if xi is None else {"xi": xi}
+            cache[key] = make_pair(seed=seed, sphere=sphere, out_rows=rows, out_cols=cols, **kw)
+        return cache[key]
+
+    return get
+
+
+@pytest.fixture(scope="session")
+def pair():
+    return _pairs()
+
+
+def make_solver(api, rows, cols, params, pair=None, batch=1):
+    import staticfusion_amd as sf
+
+    s = sf.Solver(api, rows, cols, batch, params)
+    if pair is not None:
+        for b in range(batch):
+            s.set_current(b, *pair["new"])
+            s.set_prediction(b, *pair["old"])
+    return s
+
+
+def driver_params(api, kb=1.05, **over):
+    p = api.default_params_struct()
+    p.kb = kb
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def config2_params(api, levels=3, **over):
+    p = api.ctor_params_struct()
+    p.ctf_levels = levels
+    p.segmentation_enabled = 0
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def trace_array(st, field, n=None):
+    n = st.n_outer if n is None else n
+    return np.array([list(getattr(st.outer[i], field)[:]) if hasattr(getattr(st.outer[i], field), "__len__")
+                     else getattr(st.outer[i], field) for i in range(n)])

@@ -1,0 +1,132 @@
+"""CPU-only checks of the boundary and the host logic: the C-ABI library loads and exports every
+symbol include/sf.h declares (no compute calls), the ctypes table matches the header, parameter
+defaults match the reference's driver values, the synthetic generator and the bench's algorithmic
+byte count behave."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "sf.h")).read()
+    return sorted(set(re.findall(r"SF_FN\((\w+)\)\(", txt)))
+
+
+def test_header_matches_ctypes_table():
+    from staticfusion_amd import capi
+
+    assert header_symbols() == sorted(capi.SIGNATURES.keys())
+
+
+def test_hip_library_builds_and_exports_every_symbol():
+    import staticfusion_amd as sf
+
+    if not os.path.exists(sf.LIB):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "staticfusion_amd", "csrc")])
+    lib = ctypes.CDLL(sf.LIB)
+    for name in header_symbols():
+        assert hasattr(lib, "sf_" + name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", sf.LIB]).decode()
+    exported = set(re.findall(r" T (sf_\w+)", out))
+    assert exported == {"sf_" + n for n in header_symbols()}  # nothing undeclared leaks out either
+    # the product must not depend on the oracle in any way
+    needed = subprocess.check_output(["readelf", "-d", sf.LIB]).decode()
+    assert "liboracle" not in needed
+    assert lib.sf_backend is not None
+    lib.sf_backend.restype = ctypes.c_char_p
+    assert lib.sf_backend() == b"hip:gfx950"
+
+
+def test_product_sources_never_touch_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "staticfusion_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".hpp", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_hip_library_fails_loudly_without_gpu():
+    """No CPU fallback: without a device sf_create must fail with SF_ERR_DEVICE (skipped on the GPU box)."""
+    import staticfusion_amd as sf
+
+    api = sf.load()
+    p = api.default_params_struct()
+    h = ctypes.c_void_p()
+    rc = api.create(ctypes.byref(p), 240, 320, 1, 0, ctypes.byref(h))
+    if rc == 0:
+        api.destroy(h)
+        pytest.skip("a GPU is present")
+    assert rc == -2 and b"no CPU fallback" in api.last_error()
+
+
+def test_default_params_are_the_driver_values(ora):
+    """StaticFusion-datasets.cpp:79-94 and FrontEnd.cpp:57-76; both libraries must agree byte for byte."""
+    import staticfusion_amd as sf
+
+    hip = sf.load()
+    for getter in ("default_params_struct", "ctor_params_struct"):
+        a, b = getattr(ora, getter)(), getattr(hip, getter)()
+        assert bytes(a) == bytes(b), getter
+    d = ora.default_params_struct()
+    assert (d.max_iter_per_level, d.max_iter_irls, d.use_motion_filter) == (3, 6, 1)
+    assert d.irls_delta_threshold == pytest.approx(0.0015) and d.lambda_reg == pytest.approx(0.35)
+    assert d.previous_speed_const_weight == pytest.approx(0.1) and d.previous_speed_eig_weight == pytest.approx(2.0)
+    c = ora.ctor_params_struct()
+    assert (c.max_iter_per_level, c.max_iter_irls, c.use_motion_filter) == (2, 10, 0)
+    assert c.kb == pytest.approx(1.25) and c.fovh == pytest.approx(np.pi * 62.5 / 180.0)
+
+
+def test_error_behaviour(ora):
+    import staticfusion_amd as sf
+
+    p = ora.default_params_struct()
+    with pytest.raises(sf.SfError):
+        sf.Solver(ora, 4, 4, 1, p)  # too small
+    p.ctf_levels = 9
+    with pytest.raises(sf.SfError):
+        sf.Solver(ora, 240, 320, 1, p)
+    s = sf.Solver(ora, 60, 80, 2, ora.default_params_struct())
+    with pytest.raises(sf.SfError):
+        s.T(5)  # stream out of range
+    with pytest.raises(sf.SfError):
+        s.residuals_vs_history(3)  # index < 5
+    assert s.levels == 3 and s.level_shape(2) == (15, 20)
+
+
+def test_synthetic_generator_is_deterministic_and_consistent():
+    from staticfusion_amd.synth import LCG64, make_pair, pose_delta, se3_exp
+
+    g = LCG64(1234)
+    assert [g.next_u64() for _ in range(2)] == [(6364136223846793005 * 1234 + 1442695040888963407) % 2**64,
+                                                (6364136223846793005 * ((6364136223846793005 * 1234 + 1442695040888963407) % 2**64)
+                                                 + 1442695040888963407) % 2**64]
+    a, b = make_pair(seed=9, out_rows=60, out_cols=80), make_pair(seed=9, out_rows=60, out_cols=80)
+    assert np.array_equal(a["new"][0], b["new"][0]) and np.array_equal(a["old"][1], b["old"][1])
+    d = a["new"][0]
+    assert d.dtype == np.float32 and d.shape == (60, 80) and 1.5 < d[d > 0].min() and d.max() < 3.6
+    assert np.allclose(np.round(d.astype(np.float64) * 1000), d.astype(np.float64) * 1000, atol=1e-3)  # uint16 mm
+    T = se3_exp([0.01, 0, 0, 0, 0.02, 0])
+    r, t = pose_delta(np.eye(4), T)
+    assert r == pytest.approx(0.02, rel=1e-6) and t == pytest.approx(np.linalg.norm(T[:3, 3]))
+
+
+def test_bench_algorithmic_bytes():
+    import bench
+    from staticfusion_amd import SfFrameStats
+
+    st = SfFrameStats()
+    st.n_outer, st.pixel_iters, st.kmeans_iters = 2, 1000, 3
+    st.outer[0].level, st.outer[0].k = 0, 0  # coarsest, first: no warp
+    st.outer[1].level, st.outer[1].k = 1, 0
+    levels_n = [400, 100]
+    out = bench.algorithmic_bytes([st], levels_n, 100, True, True)
+    assert out["irls"] == 60 * 1000
+    assert out["linearise"] == 88 * (100 + 400) and out["warp"] == 32 * 400
+    assert out["pyramid"] == 2 * 48 * 100 and out["kmeans"] == 20 * 100 * 3
+    assert out["segm_image"] == 8 * 400 and out["residuals"] == 32 * 400

@@ -1,0 +1,253 @@
+"""Parity of the HIP path (libsf_hip.so, through the C ABI) against the CPU oracle and the golden
+fixtures, on MI355X.  Bars (BASELINE.json north_star):
+  * pyramids, K-means centres, cluster labels of every level, connectivity: BIT-EXACT
+  * pose vs the CPU solver: <= 1e-4 rad and <= 1e-4 m per frame (measured ~1e-7)
+  * b values <= 1e-4; the per-pixel static/dynamic decision (b > 0.5) identical
+  * iteration counts (outer, IRLS, K-means) identical
+Cross-pixel sums are accumulated in a different (parallel, fp64 / fixed-point) order on the GPU,
+so reduced quantities agree to rounding, not bitwise; the image warp quantises projections to
+centi-pixels, so a last-bit difference in T can move single pixels of the Warped images.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, config2_params, driver_params, make_solver, trace_array
+from staticfusion_amd import capi
+from staticfusion_amd.synth import DEFAULT_XI, Scene, pose_delta, quantise_and_decimate, se3_exp
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-4  # rad and m, north_star
+
+
+def solve_both(hip, ora, rows, cols, mk_params, pr, seg_image=True):
+    out = []
+    for api in (hip, ora):
+        s = make_solver(api, rows, cols, mk_params(api), pr)
+        s.build_pyramid(True)
+        s.run_solver(True)
+        if seg_image:
+            s.build_segm_image()
+        out.append(s)
+    return out
+
+
+def assert_traces_match(sg, so, tol_twist=2e-6, tol_b=1e-4):
+    a, b = sg.stats(), so.stats()
+    assert (a.n_outer, a.n_irls, a.kmeans_iters, a.status) == (b.n_outer, b.n_irls, b.kmeans_iters, b.status)
+    assert a.pixel_iters == b.pixel_iters
+    for f in ("level", "k", "n_valid", "irls_iters"):
+        assert np.array_equal(trace_array(a, f), trace_array(b, f)), f
+    assert np.allclose(trace_array(a, "aver_res"), trace_array(b, "aver_res"), rtol=2e-4, atol=1e-7)
+    assert np.abs(trace_array(a, "var") - trace_array(b, "var")).max() < tol_twist
+    assert np.abs(trace_array(a, "twist_level") - trace_array(b, "twist_level")).max() < tol_twist
+    assert np.abs(trace_array(a, "T") - trace_array(b, "T")).max() < tol_twist
+    assert np.abs(trace_array(a, "b_segm") - trace_array(b, "b_segm")).max() < tol_b
+
+
+def assert_planes_close(g, o, frac=0.99, tol=5e-5, hard=0.2):
+    """centi-pixel quantisation of the warp can move isolated pixels: all but 1 % within tol."""
+    d = np.abs(g.astype(np.float64) - o.astype(np.float64))
+    assert np.isfinite(d).all()
+    assert (d <= tol).mean() >= frac, ((d <= tol).mean(), d.max())
+    assert d.max() <= hard
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,cols,sphere,seed", [(240, 320, True, 1234), (240, 320, False, 99), (120, 160, True, 7), (60, 80, False, 3)])
+def test_pyramid_kmeans_labels_bit_exact(hip, ora, pair, rows, cols, sphere, seed):
+    pr = pair(seed=seed, sphere=sphere, rows=rows, cols=cols)
+    d_new = pr["new"][0].copy()
+    d_new[rows // 3: rows // 2, cols // 2: cols // 2 + cols // 6] = 0  # invalid region: label 24, zero-centre branch
+    d_new[::17, ::13] = 0                                                 # isolated holes
+    prm = {"new": (d_new, pr["new"][1]), "old": pr["old"]}
+    sg, so = solve_both(hip, ora, rows, cols, lambda a: driver_params(a), prm)
+    for L in range(sg.levels):
+        for pset in (capi.SET_NEW, capi.SET_PRED):
+            for ch in range(4):
+                assert np.array_equal(sg.plane(pset, ch, L), so.plane(pset, ch, L)), (L, pset, ch)
+        assert np.array_equal(sg.labels(L), so.labels(L)), L
+    assert np.array_equal(sg.kmeans_centres(), so.kmeans_centres())
+    assert np.array_equal(sg.connectivity(), so.connectivity())
+    assert sg.stats().kmeans_iters == so.stats().kmeans_iters
+
+
+def test_config1_static_pair_qvga(hip, ora, pair):
+    """BASELINE.json configs[1]: static pair, QVGA, 3 levels, segmentation disabled."""
+    pr = pair(seed=1234, rows=240, cols=320)
+    sg, so = solve_both(hip, ora, 240, 320, lambda a: config2_params(a, levels=3), pr)
+    assert_traces_match(sg, so)
+    rot, trans = pose_delta(so.T(), sg.T())
+    assert rot <= POSE_TOL and trans <= POSE_TOL
+    rot, trans = pose_delta(pr["T_gt"], sg.T())
+    assert rot < 1.5e-3 and trans < 4e-3
+    assert np.array_equal(sg.b(), so.b()) and np.all(sg.b_image() == 1.0)
+
+
+@pytest.mark.parametrize("seed", [1234, 1235, 1240])
+def test_config2_moving_sphere_full_solver(hip, ora, pair, seed):
+    """BASELINE.json configs[2]: moving sphere, K-means(24) + b-field, driver parameters."""
+    pr = pair(seed=seed, sphere=True, rows=240, cols=320)
+    sg, so = solve_both(hip, ora, 240, 320, lambda a: driver_params(a), pr)
+    assert_traces_match(sg, so)
+    rot, trans = pose_delta(so.T(), sg.T())
+    assert rot <= POSE_TOL and trans <= POSE_TOL
+    for L in range(5):
+        assert np.array_equal(sg.labels(L), so.labels(L))
+    assert np.abs(sg.b() - so.b()).max() < 1e-4
+    bg, bo = sg.b_image(), so.b_image()
+    assert np.array_equal(bg > 0.5, bo > 0.5)  # the decision the map uses (reference Shaders/data.vert:180)
+    assert np.abs(bg - bo).max() < 1e-4
+    assert (bg < 0.5).mean() > 1e-3  # the sphere is flagged dynamic
+
+
+def test_linearisation_and_warp_planes(hip, ora, pair):
+    pr = pair(seed=11, sphere=True, rows=240, cols=320)
+    sg, so = solve_both(hip, ora, 240, 320, lambda a: driver_params(a, debug_planes=1), pr)
+    for which in range(capi.LIN_NULL):
+        assert_planes_close(sg.lin_plane(which), so.lin_plane(which))
+    ng, no = sg.lin_plane(capi.LIN_NULL), so.lin_plane(capi.LIN_NULL)
+    assert (ng != no).mean() < 1e-3
+    for L in range(5):
+        for pset in (capi.SET_WARPED, capi.SET_INTER):
+            for ch in range(4):
+                assert_planes_close(sg.plane(pset, ch, L), so.plane(pset, ch, L))
+    # the coarsest level's first iteration uses Warped := Pred: exact
+    for ch in range(4):
+        assert np.array_equal(sg.plane(capi.SET_WARPED, ch, 4), so.plane(capi.SET_WARPED, ch, 4))
+
+
+def test_golden_fixtures_on_the_hip_path(hip):
+    import test_golden
+
+    test_golden.check_pyramid(hip)
+    test_golden.check_linearise_and_first_irls(hip)
+    test_golden.check_lin_planes_single_level(hip)
+    g = np.load(os.path.join(GOLDEN, "segm_image_160x120.npz"))
+    s = make_solver(hip, 120, 160, driver_params(hip))
+    s.set_segm_state(0, g["labels0"], g["b_segm"], g["cluster_res"])
+    s.build_segm_image()
+    assert np.array_equal(s.b_image(), g["b_image"])
+
+
+def test_frame_sequence_with_history(hip, ora):
+    """8 frames through sf_process_frame: carried state (twist_old, b_segm, 5-frame ring), the
+    residual check from frame 5 on, per-frame pose parity."""
+    scene = Scene(seed=77, sphere=True)
+    xi = np.array(DEFAULT_XI) * 0.6
+    frames, T = [], np.eye(4)
+    for k in range(9):
+        frames.append(quantise_and_decimate(*scene.render(T, 640, 480, sphere_offset=(0.02 * k, 0, 0))))
+        T = T @ se3_exp(xi)
+    solvers = [make_solver(api, 240, 320, driver_params(api, kb=1.5)) for api in (hip, ora)]
+    for s in solvers:
+        s.set_current(0, *frames[0])
+        s.current_to_prediction()
+        s.push_history(0)
+    for k in range(1, 9):
+        for s in solvers:
+            s.set_prediction(0, *frames[k - 1])
+            s.set_current(0, *frames[k])
+            s.process_frame(k)
+        sg, so = solvers
+        rot, trans = pose_delta(so.T(), sg.T())
+        assert rot <= POSE_TOL and trans <= POSE_TOL, (k, rot, trans)
+        assert np.abs(sg.twist_old() - so.twist_old()).max() < 1e-5
+        assert np.array_equal(sg.labels(0), so.labels(0))
+        cg, co = sg.cluster_residuals(), so.cluster_residuals()
+        assert np.array_equal(np.isnan(cg), np.isnan(co))
+        assert np.allclose(cg[~np.isnan(cg)], co[~np.isnan(co)], rtol=2e-3, atol=2e-5)
+        bg, bo = sg.b_image(), so.b_image()
+        assert (np.abs(bg - bo) > 1e-3).mean() < 2e-3  # a cluster exactly at the 0.017 threshold may flip
+        a, b = sg.stats(), so.stats()
+        assert (a.n_outer, a.n_irls) == (b.n_outer, b.n_irls), k
+
+
+def test_edge_cases(hip, ora, pair):
+    z = np.zeros((60, 80), np.float32)
+    for api in (hip, ora):
+        s = make_solver(api, 60, 80, driver_params(api), {"new": (z, z), "old": (z, z)})
+        s.build_pyramid(True)
+        s.run_solver(True)
+        s.build_segm_image()
+        assert s.stats().status & capi.STATUS_EMPTY_LEVEL
+        assert np.array_equal(s.T(), np.eye(4, dtype=np.float32))
+        assert np.all(s.labels(0) == 24) and np.all(s.b_image() == 1.0)
+    # identical images: zero motion on both
+    pr = pair(seed=3, rows=60, cols=80)
+    same = {"new": pr["new"], "old": pr["new"]}
+    sg, so = solve_both(hip, ora, 60, 80, lambda a: driver_params(a), same)
+    assert np.abs(sg.T() - np.eye(4)).max() < 1e-6
+    assert_traces_match(sg, so)
+    # half of the new image invalid + large motion (3 outer iterations per level possible)
+    big = pair(seed=8, rows=120, cols=160, xi=tuple(4 * np.array(DEFAULT_XI)))
+    d = big["new"][0].copy()
+    d[:, :70] = 0
+    sg, so = solve_both(hip, ora, 120, 160, lambda a: driver_params(a), {"new": (d, big["new"][1]), "old": big["old"]})
+    assert_traces_match(sg, so, tol_twist=1e-5, tol_b=1e-3)  # stress case: large motion, half the image invalid
+    rot, trans = pose_delta(so.T(), sg.T())
+    assert rot <= POSE_TOL and trans <= POSE_TOL
+
+
+def test_batch_streams_are_independent_and_deterministic(hip, pair):
+    """Full-size property check: 96 streams (3 distinct pairs tiled) in one launch; equal inputs give
+    bit-equal outputs wherever they sit in the batch, run to run, and equal the single-stream result."""
+    prs = [pair(seed=s, sphere=True, rows=240, cols=320) for s in (1234, 1235, 1240)]
+    B = 96
+    p = driver_params(hip)
+    results = []
+    for _ in range(2):
+        s = make_solver(hip, 240, 320, p, batch=B)
+        for b in range(B):
+            s.set_current(b, *prs[b % 3]["new"])
+            s.set_prediction(b, *prs[b % 3]["old"])
+        s.process_frame(0)
+        T, n_irls, n_outer, pix = s.batch_results()
+        bimg = [s.b_image(b) for b in (0, 1, 2, 93, 94, 95)]
+        results.append((T, n_irls, n_outer, pix, bimg))
+        s.close()
+    T, n_irls, n_outer, pix, bimg = results[0]
+    for b in range(B):
+        assert np.array_equal(T[b], T[b % 3]) and n_irls[b] == n_irls[b % 3] and pix[b] == pix[b % 3]
+    assert np.array_equal(results[0][0], results[1][0])  # run-to-run determinism (order-independent sums)
+    for i in range(3):
+        assert np.array_equal(bimg[i], bimg[3 + i])
+    single = make_solver(hip, 240, 320, p, prs[1])
+    single.process_frame(0)
+    assert np.array_equal(single.T(0), T[1])
+    for b in range(3):  # rigid transforms
+        R = T[b][:3, :3].astype(np.float64)
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-5 and abs(np.linalg.det(R) - 1) < 1e-5
+
+
+def test_device_resident_inputs_and_counters(hip, pair):
+    """set_*_device (inputs already in HBM) + the device-side counters used by bench.py."""
+    import ctypes
+
+    pr = pair(seed=5, rows=120, cols=160)
+    B = 4
+    s = make_solver(hip, 120, 160, config2_params(hip, levels=3), pr, batch=B)
+    s.process_frame(0)
+    T_host, n_irls, _, _ = s.batch_results()
+    hiprt = ctypes.CDLL("libamdhip64.so")
+    n = 120 * 160
+    col = lambda a: np.ascontiguousarray(np.tile(np.asarray(a, np.float32).T.ravel(), B))
+    bufs = []
+    for arr in (pr["new"][0], pr["new"][1], pr["old"][0], pr["old"][1]):
+        ptr = ctypes.c_void_p()
+        assert hiprt.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(4 * n * B)) == 0
+        h = col(arr)
+        assert hiprt.hipMemcpy(ptr, h.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(h.nbytes), 1) == 0
+        bufs.append(ptr)
+    s2 = make_solver(hip, 120, 160, config2_params(hip, levels=3), batch=B)
+    hip.check(hip.set_current_device(s2.h, bufs[0], bufs[1]))
+    hip.check(hip.set_prediction_device(s2.h, bufs[2], bufs[3]))
+    s2.process_frame(0)
+    T_dev, n_irls2, _, _ = s2.batch_results()
+    assert np.array_equal(T_host, T_dev) and np.array_equal(n_irls, n_irls2)
+    frames, irls, outer, pix = s2.counters()
+    assert frames == B and irls == int(n_irls2.sum()) and outer == 3 * B and pix > 0
+    for ptr in bufs:
+        hiprt.hipFree(ptr)

@@ -219,8 +219,10 @@ int SF_FN(get_counters)(sf_handle *h, int64_t *frames, int64_t *n_irls, int64_t 
 /* In-kernel stage timers: ticks (100 MHz wall clock, lane 0 of each workgroup) summed over all
  * streams since sf_create. Slots: 0 pyramid(old) 1 pyramid(new) 2 k-means 3 warp 4 linearise
  * 5 IRLS setup 6 IRLS pass 1 7 6x6 solve 8 IRLS pass 2 9 b-solve/convergence 10 filter/update
- * 11 residuals-vs-history 12 segm image + history push 13 total. */
-int SF_FN(get_stage_profile)(sf_handle *h, int64_t ticks[16]);
+ * 11 residuals-vs-history 12 segm image + history push 13 total; 14..20 K-means sub-stages
+ * (init, centre sort, assignment, stable partition, sequential sums, level-0 labels, connectivity +
+ * label pyramid). */
+int SF_FN(get_stage_profile)(sf_handle *h, int64_t ticks[24]);
 /* The IRLS streaming passes in isolation: `reps` executions of pass `which` (1 = weights + normal
  * equations, 2 = residuals + label sums) over the level-0 records of every stream left by the last
  * solve, one launch of sf_irls_pass_kernel. variant 0 = product code; 1 = loads only; 2 = no

@@ -394,9 +394,9 @@ int sfo_get_counters(sf_handle *h, int64_t *frames, int64_t *n_irls, int64_t *n_
     if (pixel_iters) *pixel_iters = h->cum_pix;
     return SF_OK;
 }
-int sfo_get_stage_profile(sf_handle *h, int64_t ticks[16]) {
+int sfo_get_stage_profile(sf_handle *h, int64_t ticks[24]) {
     if (!h || !ticks) return fail(SF_ERR_ARG, "null");
-    for (int q = 0; q < 16; q++) ticks[q] = 0;  // the oracle keeps no stage timers
+    for (int q = 0; q < 24; q++) ticks[q] = 0;  // the oracle keeps no stage timers
     return SF_OK;
 }
 int sfo_microbench_pass(sf_handle *, int, int, int, float *) { return fail(SF_ERR_STATE, "not available in the CPU oracle"); }

@@ -330,11 +330,12 @@ class Solver:
         return tuple(int(x.value) for x in v)
 
     STAGES = ["pyr_old", "pyr_new", "kmeans", "warp", "linearise", "irls_setup", "pass1", "solve6", "pass2",
-              "b_solve", "filter", "residuals", "segm_hist", "total"]
+              "b_solve", "filter", "residuals", "segm_hist", "total", "km_init", "km_sort", "km_assign", "km_partition",
+              "km_sum", "km_label0", "km_conn_pyr"]
 
     def stage_profile(self):
         """dict stage -> seconds (lane-0 wall clock summed over streams since creation)"""
-        t = (C.c_int64 * 16)()
+        t = (C.c_int64 * 24)()
         self.api.check(self.api.get_stage_profile(self.h, t))
         return {n: t[i] * 1e-8 for i, n in enumerate(self.STAGES)}
 

@@ -15,7 +15,10 @@
 
 #include "../../include/sf.h"
 
-#define SF_NT 512          // threads per workgroup
+#ifndef SF_NT
+#define SF_NT 256          // threads per workgroup (4 waves; 4 workgroups resident per CU)
+#endif
+#define SF_BLOCKS_PER_CU (1024 / SF_NT)  // 16 waves per CU at <= 128 VGPRs
 #define SF_NW (SF_NT / 64) // waves per workgroup
 #define SF_NC SF_NUM_CLUSTERS
 #define SF_INVALID_LABEL 255
@@ -23,7 +26,8 @@
 // in-kernel stage timers (wall_clock64, 100 MHz), accumulated per stream
 enum {
     PF_PYR_OLD = 0, PF_PYR_NEW, PF_KMEANS, PF_WARP, PF_LINEARISE, PF_IRLS_INIT, PF_PASS1, PF_SOLVE6, PF_PASS2,
-    PF_TAIL, PF_FILTER, PF_RESIDUALS, PF_SEGM_HIST, PF_TOTAL, SF_PROF_SLOTS = 16
+    PF_TAIL, PF_FILTER, PF_RESIDUALS, PF_SEGM_HIST, PF_TOTAL,
+    PF_KM_INIT, PF_KM_SORT, PF_KM_ASSIGN, PF_KM_PARTITION, PF_KM_SUM, PF_KM_LABEL0, PF_KM_CONN_PYR, SF_PROF_SLOTS = 24
 };
 
 // record planes written by the linearisation and streamed by the IRLS passes.  Only what cannot be
@@ -177,3 +181,47 @@ __device__ __forceinline__ void wave_label_count(bool active, int lab, int *bins
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+//  forward splat of one source pixel (reference FrontEnd.cpp:808-868 / :960-1019): transform with T
+//  (rows 0..2 of the inverse odometry, row-major 3x4), project to centi-pixels, distribute to the
+//  1 or 4 neighbouring target pixels with integer weights.  Integer atomics: order independent.
+// ---------------------------------------------------------------------------------------------
+struct SplatGeom {
+    float T[12];
+    float f, disp_u_i, disp_v_i;
+    int cols_lim, rows_lim, rows_i;
+};
+
+__device__ __forceinline__ void splat_pixel(const SplatGeom &g, float xr, float yr, float z, float intensity_w,
+                                            long long *acc_d, long long *acc_i, uint32_t *acc_w) {
+    const float x_w = g.T[0] * xr + g.T[1] * yr + g.T[2] * z + g.T[3];
+    const float y_w = g.T[4] * xr + g.T[5] * yr + g.T[6] * z + g.T[7];
+    const float depth_w = g.T[8] * xr + g.T[9] * yr + g.T[10] * z + g.T[11];
+    const int uwarp = cvt_trunc_x86(100.f * (g.f * x_w / depth_w + g.disp_u_i));
+    const int vwarp = cvt_trunc_x86(100.f * (g.f * y_w / depth_w + g.disp_v_i));
+    if (!((uwarp >= 0) && (uwarp < g.cols_lim) && (vwarp >= 0) && (vwarp < g.rows_lim))) return;
+    const int uwarp_l = uwarp - uwarp % 100, uwarp_r = uwarp_l + 100;
+    const int vwarp_d = vwarp - vwarp % 100, vwarp_u = vwarp_d + 100;
+    const int delta_r = uwarp_r - uwarp, delta_l = 100 - delta_r;
+    const int delta_u = vwarp_u - vwarp, delta_d = 100 - delta_u;
+    const long long dfix = to_fix(depth_w, FIX_DEPTH, 1000.f);
+    const long long ifix = to_fix(intensity_w, FIX_INTENS, 4.f);
+    auto splat = [&](int v, int u, int w) {
+        const int t = v + u * g.rows_i;
+        atomicAdd((unsigned long long *)&acc_d[t], (unsigned long long)((long long)w * dfix));
+        atomicAdd((unsigned long long *)&acc_i[t], (unsigned long long)((long long)w * ifix));
+        atomicAdd(&acc_w[t], (uint32_t)w);
+    };
+    if (min(delta_r, delta_l) + min(delta_u, delta_d) < 5) {  // within 5 centi-pixels of a pixel centre
+        splat(delta_u > delta_d ? vwarp_d / 100 : vwarp_u / 100, delta_r > delta_l ? uwarp_l / 100 : uwarp_r / 100, 200);
+    } else {
+        const int v_d = vwarp_d / 100, u_l = uwarp_l / 100;
+        splat(v_d + 1, u_l + 1, delta_l + delta_d);
+        splat(v_d + 1, u_l, delta_r + delta_d);
+        splat(v_d, u_l + 1, delta_l + delta_u);
+        splat(v_d, u_l, delta_r + delta_u);
+    }
+}
+
+#define SF_LOAD_BATCH 4  // independent pixels whose loads are issued before any of them is consumed

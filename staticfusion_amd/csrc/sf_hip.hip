@@ -85,16 +85,24 @@ __global__ __launch_bounds__(SF_NT, 4) void sf_irls_pass_kernel(const KArgs *__r
     __shared__ int s_next;
     const KArgs &a = *ka;
     const int tid = threadIdx.x;
+    const long long c0 = clock64(), w0 = wall_clock64();
     for (;;) {
         if (tid == 0) s_next = atomicAdd(a.queue, 1);
         __syncthreads();
         const int b = __builtin_amdgcn_readfirstlane(s_next);
         __syncthreads();
-        if (b >= a.batch) break;
+        if (b >= a.batch) {
+            if (tid == 0 && blockIdx.x == 0) {  // shader clock estimate: s_memtime ticks per 100 MHz tick
+                a.state[0].prof[22] = clock64() - c0;
+                a.state[0].prof[23] = wall_clock64() - w0;
+            }
+            break;
+        }
         if (which == 1) {
             if (variant == 0) microbench_pass<1, 0>(a, b, reps, sh.sv, tid);
             if (variant == 1) microbench_pass<1, 1>(a, b, reps, sh.sv, tid);
             if (variant == 2) microbench_pass<1, 2>(a, b, reps, sh.sv, tid);
+            if (variant == 3) microbench_pass<1, 3>(a, b, reps, sh.sv, tid);
         } else {
             if (variant == 0) microbench_pass<2, 0>(a, b, reps, sh.sv, tid);
             if (variant == 1) microbench_pass<2, 1>(a, b, reps, sh.sv, tid);
@@ -289,7 +297,7 @@ int sf_create(const sf_params *p, int rows, int cols, int batch, int device, sf_
     HIP_OR_FREE(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_OR_FREE(hipGetDeviceProperties(&prop, device));
-    h->max_blocks = prop.multiProcessorCount * 2;
+    h->max_blocks = prop.multiProcessorCount * SF_BLOCKS_PER_CU;
     HIP_OR_FREE(hipStreamCreate(&h->own_stream));
     h->stream = h->own_stream;
     HIP_OR_FREE(hipEventCreate(&h->ev0));
@@ -671,17 +679,17 @@ int sf_get_counters(sf_handle *h, int64_t *frames, int64_t *n_irls, int64_t *n_o
     if (pixel_iters) *pixel_iters = p;
     return SF_OK;
 }
-int sf_get_stage_profile(sf_handle *h, int64_t ticks[16]) {
+int sf_get_stage_profile(sf_handle *h, int64_t ticks[24]) {
     if (!h || !ticks) return fail(SF_ERR_ARG, "null");
     std::vector<StreamState> st(h->k.batch);
     if (int e = d2h(h, st.data(), h->k.state, st.size() * sizeof(StreamState))) return e;
-    for (int q = 0; q < 16; q++) ticks[q] = 0;
+    for (int q = 0; q < 24; q++) ticks[q] = 0;
     for (auto &s : st)
         for (int q = 0; q < SF_PROF_SLOTS; q++) ticks[q] += s.prof[q];
     return SF_OK;
 }
 int sf_microbench_pass(sf_handle *h, int which, int variant, int reps, float *elapsed_ms) {
-    if (!h || (which != 1 && which != 2) || variant < 0 || variant > 2 || reps < 1) return fail(SF_ERR_ARG, "bad argument");
+    if (!h || (which != 1 && which != 2) || variant < 0 || variant > 3 || reps < 1) return fail(SF_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemsetAsync(h->k.queue, 0, sizeof(int), h->stream));
     const int grid = std::min(h->k.batch, h->max_blocks);

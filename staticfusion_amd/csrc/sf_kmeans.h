@@ -85,6 +85,15 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, in
     const float *depth = a.pyr_new[0] + sb, *xx = a.pyr_new[2] + sb, *yy = a.pyr_new[3] + sb;
     uint8_t *labels = a.labels + sb;
     StreamState &st = a.state[b];
+    long long kt = wall_clock64();
+#define KM_MARK(slot)                              \
+    do {                                           \
+        if (tid == 0) {                            \
+            const long long now_ = wall_clock64(); \
+            st.prof[slot] += now_ - kt;            \
+            kt = now_;                             \
+        }                                          \
+    } while (0)
 
     // ------------------------------------------------------------------ initializeKMeans (K1)
     const int rows_km = a.lrows[1], cols_km = a.lcols[1], n1 = a.ln[1], o1 = a.loff[1];
@@ -164,6 +173,7 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, in
     }
     __syncthreads();
 
+    KM_MARK(PF_KM_INIT);
     // ------------------------------------------------------------------ Lloyd iterations (K2)
     float *srt0 = a.km_sorted[0] + (size_t)b * n1, *srt1 = a.km_sorted[1] + (size_t)b * n1,
           *srt2 = a.km_sorted[2] + (size_t)b * n1;
@@ -173,6 +183,7 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, in
     for (int it = 0; it < 9; it++) {
         iters++;
         km_sort_centres(s, tid);
+        KM_MARK(PF_KM_SORT);
 
         // pass A: assignment + member counts of this wave range
         int cnt = 0;  // lane l < 24 holds the count of label l
@@ -199,6 +210,7 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, in
         }
         if (lane < SF_NC) s.wcnt[wave][lane] = cnt;
         __syncthreads();
+        KM_MARK(PF_KM_ASSIGN);
         if (tid < SF_NC) {
             int run = 0;
             for (int w = 0; w < SF_NW; w++) {
@@ -250,6 +262,7 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, in
         }
         __syncthreads();
 
+        KM_MARK(PF_KM_PARTITION);
         // sequential float sums, one (cluster, coordinate) per lane (KMeans.cpp:215-221)
         if (tid < 3 * SF_NC) {
             const int c = tid / 3, r = tid - 3 * c;
@@ -269,6 +282,7 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, in
             s.cent_b[tid] = acc;  // cent_b[r + 3c] with tid = 3c + r
         }
         __syncthreads();
+        KM_MARK(PF_KM_SUM);
         if (tid < 64) {
             float dmax = 0.f;
             for (int q = tid; q < 3 * SF_NC; q += 64) dmax = std_max(dmax, fabsf(s.cent_a[q] - s.cent_b[q]));
@@ -302,6 +316,7 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, in
     }
     if (tid < SF_NC) s.conn[tid] = 1u << tid;
     __syncthreads();
+    KM_MARK(PF_KM_LABEL0);
 
     // ------------------------------------------------------------------ computeRegionConnectivity (K3)
     {
@@ -358,4 +373,6 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, in
         }
     }
     __syncthreads();
+    KM_MARK(PF_KM_CONN_PYR);
+#undef KM_MARK
 }

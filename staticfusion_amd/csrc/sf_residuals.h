@@ -55,50 +55,35 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, R
     __syncthreads();
 
     const float inv_f_i = 2.f * a.tan_half_fovh / float(cols);
-    const float disp_u_i = 0.5f * (cols - 1);
-    const float disp_v_i = 0.5f * (rows - 1);
-    const float f = float(cols) / (2.f * a.tan_half_fovh);
-    const int cols_lim = 100 * (cols - 1);
-    const int rows_lim = 100 * (rows - 1);
-    float T[12];
+    SplatGeom g;
+    g.f = float(cols) / (2.f * a.tan_half_fovh);
+    g.disp_u_i = 0.5f * (cols - 1);
+    g.disp_v_i = 0.5f * (rows - 1);
+    g.cols_lim = 100 * (cols - 1);
+    g.rows_lim = 100 * (rows - 1);
+    g.rows_i = rows;
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) T[r * 4 + c] = s.Tinv[r + 4 * c];
+        for (int c = 0; c < 4; c++) g.T[r * 4 + c] = uniform_f(s.Tinv[r + 4 * c]);
 
-    for (int idx = tid; idx < n; idx += SF_NT) {
-        const float z = dbuf[idx];
-        if (!(z != 0.f && dcur[idx] != 0.f)) continue;
-        const int u = idx / rows, v = idx - u * rows;
-        const float xb = (inv_f_i * (float(u) - disp_u_i)) * z;  // xxBuffer / yyBuffer (:922-926)
-        const float yb = (inv_f_i * (float(v) - disp_v_i)) * z;
-        const float intensity_w = ibuf[idx];
-        const float x_w = T[0] * xb + T[1] * yb + T[2] * z + T[3];
-        const float y_w = T[4] * xb + T[5] * yb + T[6] * z + T[7];
-        const float depth_w = T[8] * xb + T[9] * yb + T[10] * z + T[11];
-        const int uwarp = cvt_trunc_x86(100.f * (f * x_w / depth_w + disp_u_i));
-        const int vwarp = cvt_trunc_x86(100.f * (f * y_w / depth_w + disp_v_i));
-        if (!((uwarp >= 0) && (uwarp < cols_lim) && (vwarp >= 0) && (vwarp < rows_lim))) continue;
-        const int uwarp_l = uwarp - uwarp % 100, uwarp_r = uwarp_l + 100;
-        const int vwarp_d = vwarp - vwarp % 100, vwarp_u = vwarp_d + 100;
-        const int delta_r = uwarp_r - uwarp, delta_l = 100 - delta_r;
-        const int delta_u = vwarp_u - vwarp, delta_d = 100 - delta_u;
-        const long long dfix = to_fix(depth_w, FIX_DEPTH, 1000.f);
-        const long long ifix = to_fix(intensity_w, FIX_INTENS, 4.f);
-        auto splat = [&](int vv, int uu, int w) {
-            const int t = vv + uu * rows;
-            atomicAdd((unsigned long long *)&acc_d[t], (unsigned long long)((long long)w * dfix));
-            atomicAdd((unsigned long long *)&acc_i[t], (unsigned long long)((long long)w * ifix));
-            atomicAdd(&acc_w[t], (uint32_t)w);
-        };
-        if (min(delta_r, delta_l) + min(delta_u, delta_d) < 5) {
-            splat(delta_u > delta_d ? vwarp_d / 100 : vwarp_u / 100, delta_r > delta_l ? uwarp_l / 100 : uwarp_r / 100, 200);
-        } else {
-            const int v_d = vwarp_d / 100, u_l = uwarp_l / 100;
-            splat(v_d + 1, u_l + 1, delta_l + delta_d);
-            splat(v_d + 1, u_l, delta_r + delta_d);
-            splat(v_d, u_l + 1, delta_l + delta_u);
-            splat(v_d, u_l, delta_r + delta_u);
+    for (int base = tid; base < n; base += SF_NT * SF_LOAD_BATCH) {
+        float z[SF_LOAD_BATCH], iw[SF_LOAD_BATCH], dc[SF_LOAD_BATCH];
+#pragma unroll
+        for (int k = 0; k < SF_LOAD_BATCH; k++) {
+            const int idx = min(base + k * SF_NT, n - 1);
+            z[k] = dbuf[idx];
+            iw[k] = ibuf[idx];
+            dc[k] = dcur[idx];
+        }
+#pragma unroll
+        for (int k = 0; k < SF_LOAD_BATCH; k++) {
+            const int idx = base + k * SF_NT;
+            if (!(idx < n && z[k] != 0.f && dc[k] != 0.f)) continue;
+            const int u = idx / rows, v = idx - u * rows;
+            const float xb = (inv_f_i * (float(u) - g.disp_u_i)) * z[k];  // xxBuffer / yyBuffer (:922-926)
+            const float yb = (inv_f_i * (float(v) - g.disp_v_i)) * z[k];
+            splat_pixel(g, xb, yb, z[k], iw[k], acc_d, acc_i, acc_w);
         }
     }
     __syncthreads();

@@ -24,7 +24,7 @@
 #include "sf_smallmath.h"
 
 #define TILE_V 64
-#define TILE_U 8
+#define TILE_U (SF_NT / TILE_V)
 #define TILE_LV (TILE_V + 2)
 #define TILE_LU (TILE_U + 2)
 #define TILE_N (TILE_LV * TILE_LU)
@@ -81,17 +81,31 @@ struct SolveShared {
 //  Jacobian rows of one pixel (reference FrontEnd.cpp:544-585). Expressions keep the reference's
 //  association; the build uses -ffp-contract=off.
 // ---------------------------------------------------------------------------------------------
-struct PixRows {
-    float ac[6], bc, ad[6], bd;
-};
+// T is float (one pixel) or vfloat2 (a pixel pair: the f32 arithmetic then compiles to packed
+// v_pk_mul/add/fma_f32, two pixels per VALU instruction, same IEEE results per component).
+typedef float __attribute__((ext_vector_type(2))) vfloat2;
+typedef float __attribute__((ext_vector_type(4))) vfloat4;
 
-__device__ __forceinline__ void build_rows(float d, float x, float y, float dcu_, float dcv_, float dct_, float ddu_,
-                                           float ddv_, float ddt_, float wc_norm, float wd_norm, float f_inv,
-                                           float k_photometric_res, PixRows &r) {
-    const float inv_d = 1.f / d;
-    const float dycomp_c = dcu_ * f_inv * inv_d;
-    const float dzcomp_c = dcv_ * f_inv * inv_d;
-    const float twc = wc_norm * k_photometric_res;
+__device__ __forceinline__ float vabs(float x) { return fabsf(x); }
+__device__ __forceinline__ vfloat2 vabs(vfloat2 x) { return vfloat2{fabsf(x.x), fabsf(x.y)}; }
+__device__ __forceinline__ float vsqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ vfloat2 vsqrt(vfloat2 x) { return vfloat2{sqrtf(x.x), sqrtf(x.y)}; }
+__device__ __forceinline__ float vrcp1(float x) { return 1.f / x; }
+__device__ __forceinline__ vfloat2 vrcp1(vfloat2 x) { return vfloat2{1.f / x.x, 1.f / x.y}; }  // IEEE division per component
+
+template <class T>
+struct PixRowsT {
+    T ac[6], bc, ad[6], bd;
+};
+typedef PixRowsT<float> PixRows;
+
+template <class T>
+__device__ __forceinline__ void build_rows(T d, T x, T y, T dcu_, T dcv_, T dct_, T ddu_, T ddv_, T ddt_, T wc_norm,
+                                           T wd_norm, float f_inv, float k_photometric_res, PixRowsT<T> &r) {
+    const T inv_d = vrcp1(d);
+    const T dycomp_c = dcu_ * f_inv * inv_d;
+    const T dzcomp_c = dcv_ * f_inv * inv_d;
+    const T twc = wc_norm * k_photometric_res;
     r.ac[0] = twc * (-dycomp_c);
     r.ac[1] = twc * (-dzcomp_c);
     r.ac[2] = twc * (dycomp_c * x * inv_d + dzcomp_c * y * inv_d);
@@ -100,9 +114,9 @@ __device__ __forceinline__ void build_rows(float d, float x, float y, float dcu_
     r.ac[5] = twc * (dycomp_c * y - dzcomp_c * x);
     r.bc = twc * (-dct_);
 
-    const float dycomp_d = ddu_ * f_inv * inv_d;
-    const float dzcomp_d = ddv_ * f_inv * inv_d;
-    const float twd = wd_norm;
+    const T dycomp_d = ddu_ * f_inv * inv_d;
+    const T dzcomp_d = ddv_ * f_inv * inv_d;
+    const T twd = wd_norm;
     r.ad[0] = twd * (-dycomp_d);
     r.ad[1] = twd * (-dzcomp_d);
     r.ad[2] = twd * (1.f + dycomp_d * x * inv_d + dzcomp_d * y * inv_d);
@@ -114,13 +128,9 @@ __device__ __forceinline__ void build_rows(float d, float x, float y, float dcu_
 
 // Records are read through GLOBAL address-space pointers (global_load_*, not flat_load_*) and
 // SF_VEC consecutive pixels per lane (8- or 16-byte loads: more bytes in flight per wave).
-#ifndef SF_VEC
-#define SF_VEC 2
-#endif
+#define SF_VEC 2  // pixels per lane and iteration in the streaming passes (pixel pairs -> packed f32 math)
 typedef __attribute__((address_space(1))) const float gcfloat;
 typedef __attribute__((address_space(1))) const uint8_t gcu8;
-typedef float __attribute__((ext_vector_type(2))) vfloat2;
-typedef float __attribute__((ext_vector_type(4))) vfloat4;
 typedef __attribute__((address_space(1))) const vfloat2 gcfloat2;
 typedef __attribute__((address_space(1))) const vfloat4 gcfloat4;
 typedef __attribute__((address_space(1))) const unsigned short gcu16;
@@ -191,19 +201,24 @@ struct LevelGeom {
     int first;        // Warped := Pred iteration: xxWarped / yyWarped use the pyramid formula
 };
 
-// The two Jacobian rows of pixel `idx` from its record. Every expression below repeats, with the
-// same association, what the linearisation / the reference computes for this pixel
-// (calculateCoord :403-407, warp :883-884, pyramid :385-386, derivatives :478, weights :494-501).
-__device__ __forceinline__ void rows_from_record(const LevelGeom &g, int idx, float dn, float dw, float dcu_, float dcv_,
-                                                 float dct_, float ddu_, float ddv_, PixRows &out) {
+// split a flat column-major index into (column u, row v)
+__device__ __forceinline__ void split_index(const LevelGeom &g, int idx, float &fu, float &fv) {
     int u = (int)((float)idx * g.inv_rows);
     if (u * g.rows_i > idx) u--;
     if ((u + 1) * g.rows_i <= idx) u++;
-    const int v = idx - u * g.rows_i;
-    const float fu = float(u), fv = float(v);
-    const float xn = (g.inv_f_pyr * (fu - g.disp_u_i)) * dn;
-    const float yn = (g.inv_f_pyr * (fv - g.disp_v_i)) * dn;
-    float xw, yw;
+    fu = float(u);
+    fv = float(idx - u * g.rows_i);
+}
+
+// The two Jacobian rows of a pixel (or pixel pair) from its record. Every expression below repeats,
+// with the same association, what the linearisation / the reference computes for this pixel
+// (calculateCoord :403-407, warp :883-884, pyramid :385-386, derivatives :478, weights :494-501).
+template <class T>
+__device__ __forceinline__ void rows_from_record(const LevelGeom &g, T fu, T fv, T dn, T dw, T dcu_, T dcv_, T dct_,
+                                                 T ddu_, T ddv_, PixRowsT<T> &out) {
+    const T xn = (g.inv_f_pyr * (fu - g.disp_u_i)) * dn;
+    const T yn = (g.inv_f_pyr * (fv - g.disp_v_i)) * dn;
+    T xw, yw;
     if (g.first) {
         xw = (g.inv_f_pyr * (fu - g.disp_u_i)) * dw;
         yw = (g.inv_f_pyr * (fv - g.disp_v_i)) * dw;
@@ -211,20 +226,25 @@ __device__ __forceinline__ void rows_from_record(const LevelGeom &g, int idx, fl
         xw = (fu - g.disp_u_i) * dw * g.inv_f_w;
         yw = (fv - g.disp_v_i) * dw * g.inv_f_w;
     }
-    const float d_i = 0.5f * (dn + dw);
-    const float x_i = 0.5f * (xn + xw);
-    const float y_i = 0.5f * (yn + yw);
-    const float ddt_ = dn - dw;
-    const float error_l_c = 10.f * (fabsf(dct_) + fabsf(dcu_) + fabsf(dcv_));
-    const float error_l_d = 200.f * (fabsf(ddt_) + fabsf(ddu_) + fabsf(ddv_));
-    const float wc = sqrtf(1.f / (1.f + error_l_c));
-    const float wd = sqrtf(1.f / (0.01f + error_l_d));
-    build_rows(d_i, x_i, y_i, dcu_, dcv_, dct_, ddu_, ddv_, ddt_, g.inv_max_c * wc, g.inv_max_d * wd, g.f_inv, g.kph, out);
+    const T d_i = 0.5f * (dn + dw);
+    const T x_i = 0.5f * (xn + xw);
+    const T y_i = 0.5f * (yn + yw);
+    const T ddt_ = dn - dw;
+    const T error_l_c = 10.f * (vabs(dct_) + vabs(dcu_) + vabs(dcv_));
+    const T error_l_d = 200.f * (vabs(ddt_) + vabs(ddu_) + vabs(ddv_));
+    const T wc = vsqrt(vrcp1(1.f + error_l_c));
+    const T wd = vsqrt(vrcp1(0.01f + error_l_d));
+    build_rows<T>(d_i, x_i, y_i, dcu_, dcv_, dct_, ddu_, ddv_, ddt_, g.inv_max_c * wc, g.inv_max_d * wd, g.f_inv, g.kph, out);
 }
-template <int VEC>
-__device__ __forceinline__ void rows_of(const RecVec<VEC> &r, int j, int idx0, const LevelGeom &g, PixRows &out) {
-    rows_from_record(g, idx0 + j, r.dn[j], r.v[R_DW][j], r.v[R_DCU][j], r.v[R_DCV][j], r.v[R_DCT][j], r.v[R_DDU][j],
-                     r.v[R_DDV][j], out);
+__device__ __forceinline__ vfloat2 pair_of(const float (&v)[2]) { return vfloat2{v[0], v[1]}; }
+
+// rows of the pixel pair (idx0, idx0 + 1) held in a RecVec<2>
+__device__ __forceinline__ void rows_of_pair(const RecVec<2> &r, int idx0, const LevelGeom &g, PixRowsT<vfloat2> &out) {
+    float fu0, fv0, fu1, fv1;
+    split_index(g, idx0, fu0, fv0);
+    split_index(g, idx0 + 1, fu1, fv1);
+    rows_from_record<vfloat2>(g, vfloat2{fu0, fu1}, vfloat2{fv0, fv1}, pair_of(r.dn), pair_of(r.v[R_DW]), pair_of(r.v[R_DCU]),
+                              pair_of(r.v[R_DCV]), pair_of(r.v[R_DCT]), pair_of(r.v[R_DDU]), pair_of(r.v[R_DDV]), out);
 }
 
 // res = -B; res += Var(k)*A(k), k = 0..5   (reference FrontEnd.cpp:644-646)
@@ -256,59 +276,32 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, SolveShare
     }
     __syncthreads();
 
-    const float f = float(cols_i) / (2.f * a.tan_half_fovh);
-    const float disp_u_i = 0.5f * float(cols_i - 1);
-    const float disp_v_i = 0.5f * float(rows_i - 1);
-    const int cols_lim = 100 * (cols_i - 1);
-    const int rows_lim = 100 * (rows_i - 1);
-    float T[12];
+    SplatGeom g;
+    g.f = float(cols_i) / (2.f * a.tan_half_fovh);
+    g.disp_u_i = 0.5f * float(cols_i - 1);
+    g.disp_v_i = 0.5f * float(rows_i - 1);
+    g.cols_lim = 100 * (cols_i - 1);
+    g.rows_lim = 100 * (rows_i - 1);
+    g.rows_i = rows_i;
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) T[r * 4 + c] = s.Tinv[r + 4 * c];
+        for (int c = 0; c < 4; c++) g.T[r * 4 + c] = uniform_f(s.Tinv[r + 4 * c]);
 
-    for (int idx = tid; idx < n; idx += SF_NT) {
-        const float z = dpred[idx];
-        if (z == 0.f) continue;
-        const float intensity_w = ipred[idx];
-        const float xr = xpred[idx], yr = ypred[idx];
-        const float x_w = T[0] * xr + T[1] * yr + T[2] * z + T[3];
-        const float y_w = T[4] * xr + T[5] * yr + T[6] * z + T[7];
-        const float depth_w = T[8] * xr + T[9] * yr + T[10] * z + T[11];
-
-        const int uwarp = cvt_trunc_x86(100.f * (f * x_w / depth_w + disp_u_i));
-        const int vwarp = cvt_trunc_x86(100.f * (f * y_w / depth_w + disp_v_i));
-        if (!((uwarp >= 0) && (uwarp < cols_lim) && (vwarp >= 0) && (vwarp < rows_lim))) continue;
-
-        const int uwarp_l = uwarp - uwarp % 100;
-        const int uwarp_r = uwarp_l + 100;
-        const int vwarp_d = vwarp - vwarp % 100;
-        const int vwarp_u = vwarp_d + 100;
-        const int delta_r = uwarp_r - uwarp;
-        const int delta_l = 100 - delta_r;
-        const int delta_u = vwarp_u - vwarp;
-        const int delta_d = 100 - delta_u;
-
-        const long long dfix = to_fix(depth_w, FIX_DEPTH, 1000.f);
-        const long long ifix = to_fix(intensity_w, FIX_INTENS, 4.f);
-        auto splat = [&](int v, int u, int w) {
-            const int t = v + u * rows_i;
-            atomicAdd((unsigned long long *)&acc_d[t], (unsigned long long)((long long)w * dfix));
-            atomicAdd((unsigned long long *)&acc_i[t], (unsigned long long)((long long)w * ifix));
-            atomicAdd(&acc_w[t], (uint32_t)w);
-        };
-        if (min(delta_r, delta_l) + min(delta_u, delta_d) < 5) {
-            const int ind_u = delta_r > delta_l ? uwarp_l / 100 : uwarp_r / 100;
-            const int ind_v = delta_u > delta_d ? vwarp_d / 100 : vwarp_u / 100;
-            splat(ind_v, ind_u, 200);
-        } else {
-            const int v_d = vwarp_d / 100, u_l = uwarp_l / 100;
-            const int v_u = v_d + 1, u_r = u_l + 1;
-            splat(v_u, u_r, delta_l + delta_d);
-            splat(v_u, u_l, delta_r + delta_d);
-            splat(v_d, u_r, delta_l + delta_u);
-            splat(v_d, u_l, delta_r + delta_u);
+    // SF_LOAD_BATCH pixels per lane and trip: all 16 loads are in flight before the first is used
+    for (int base = tid; base < n; base += SF_NT * SF_LOAD_BATCH) {
+        float z[SF_LOAD_BATCH], iw[SF_LOAD_BATCH], xr[SF_LOAD_BATCH], yr[SF_LOAD_BATCH];
+#pragma unroll
+        for (int k = 0; k < SF_LOAD_BATCH; k++) {
+            const int idx = min(base + k * SF_NT, n - 1);
+            z[k] = dpred[idx];
+            iw[k] = ipred[idx];
+            xr[k] = xpred[idx];
+            yr[k] = ypred[idx];
         }
+#pragma unroll
+        for (int k = 0; k < SF_LOAD_BATCH; k++)
+            if (base + k * SF_NT < n && z[k] != 0.f) splat_pixel(g, xr[k], yr[k], z[k], iw[k], acc_d, acc_i, acc_w);
     }
     __syncthreads();  // all atomics of this workgroup performed at L2
 }
@@ -577,6 +570,80 @@ __device__ __noinline__ void solve_filter_and_update(const KArgs &a, SolveShared
     for (int i = 0; i < 6; i++) s.twist[i] = tw[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+//  Factored form of the two Jacobian rows (SF_FACTORED_IRLS, default).  With
+//     g1 = [-1, 0, x/d, xy/d, -(x^2/d + d),  y],  g2 = [0, -1, y/d, y^2/d + d, -xy/d, -x],  g3 = [0, 0, 1, y, -x, 0]
+//  the reference's rows (FrontEnd.cpp:552-585) are  a_c = pc g1 + qc g2,  a_d = twd g3 + pd g1 + qd g2,
+//  b_c = -bct, b_d = -bdt  with pc = twc dcu f/d, qc = twc dcv f/d, pd = twd ddu f/d, qd = twd ddv f/d,
+//  bct = twc dct, bdt = twd ddt.  Residuals then need three 6-term dot products with the solution instead
+//  of twelve row entries, and the weighted rows of pass 1 are built from (w pc, w qc, ...) directly.
+//  Same mathematics, different rounding association than the reference's expression order (~1e-7
+//  relative on a row entry); the pre-weights, 1/d and the Cauchy weights stay IEEE-exact.
+//  -DSF_FACTORED_IRLS=0 builds the passes with the reference's expression order instead.
+// ---------------------------------------------------------------------------------------------
+#ifndef SF_FACTORED_IRLS
+#define SF_FACTORED_IRLS 1
+#endif
+
+__device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ vfloat2 vfma(vfloat2 a, vfloat2 b, vfloat2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ vfloat2 vfma(float a, vfloat2 b, vfloat2 c) { return __builtin_elementwise_fma(vfloat2{a, a}, b, c); }
+__device__ __forceinline__ vfloat2 vfma(vfloat2 a, float b, vfloat2 c) { return __builtin_elementwise_fma(a, vfloat2{b, b}, c); }
+__device__ __forceinline__ vfloat2 vfma(vfloat2 a, vfloat2 b, float c) { return __builtin_elementwise_fma(a, b, vfloat2{c, c}); }
+__device__ __forceinline__ vfloat2 vfma(vfloat2 a, float b, float c) { return __builtin_elementwise_fma(a, vfloat2{b, b}, vfloat2{c, c}); }
+
+template <class T>
+struct PixFact {
+    T x, y, xd, yd, xyd, xxd, yyd;  // geometry: x, y, x/d, y/d, xy/d, x^2/d + d, y^2/d + d
+    T pc, qc, pd, qd, twd, bct, bdt;
+};
+
+template <class T>
+__device__ __forceinline__ void fact_from_record(const LevelGeom &g, T fu, T fv, T dn, T dw, T dcu_, T dcv_, T dct_, T ddu_,
+                                                 T ddv_, PixFact<T> &o) {
+    const T xn = (g.inv_f_pyr * (fu - g.disp_u_i)) * dn;
+    const T yn = (g.inv_f_pyr * (fv - g.disp_v_i)) * dn;
+    T xw, yw;
+    if (g.first) {
+        xw = (g.inv_f_pyr * (fu - g.disp_u_i)) * dw;
+        yw = (g.inv_f_pyr * (fv - g.disp_v_i)) * dw;
+    } else {
+        xw = (fu - g.disp_u_i) * dw * g.inv_f_w;
+        yw = (fv - g.disp_v_i) * dw * g.inv_f_w;
+    }
+    const T d = 0.5f * (dn + dw);
+    o.x = 0.5f * (xn + xw);
+    o.y = 0.5f * (yn + yw);
+    const T ddt_ = dn - dw;
+    const T error_l_c = 10.f * (vabs(dct_) + vabs(dcu_) + vabs(dcv_));
+    const T error_l_d = 200.f * (vabs(ddt_) + vabs(ddu_) + vabs(ddv_));
+    const T twc = (g.inv_max_c * vsqrt(vrcp1(1.f + error_l_c))) * g.kph;
+    o.twd = g.inv_max_d * vsqrt(vrcp1(0.01f + error_l_d));
+    const T inv_d = vrcp1(d);
+    const T fd = g.f_inv * inv_d;
+    o.pc = twc * (dcu_ * fd);
+    o.qc = twc * (dcv_ * fd);
+    o.pd = o.twd * (ddu_ * fd);
+    o.qd = o.twd * (ddv_ * fd);
+    o.bct = twc * dct_;
+    o.bdt = o.twd * ddt_;
+    o.xd = o.x * inv_d;
+    o.yd = o.y * inv_d;
+    o.xyd = o.xd * o.y;
+    o.xxd = vfma(o.xd, o.x, d);
+    o.yyd = vfma(o.yd, o.y, d);
+}
+
+// residuals res = A Var - B of both rows through s1 = g1.Var, s2 = g2.Var, s3 = g3.Var
+template <class T>
+__device__ __forceinline__ void fact_residuals(const PixFact<T> &p, const float (&V)[6], T &res_c, T &res_d) {
+    const T s1 = vfma(p.y, V[5], vfma(-p.xxd, V[4], vfma(p.xyd, V[3], vfma(p.xd, V[2], -V[0]))));
+    const T s2 = vfma(-p.x, V[5], vfma(-p.xyd, V[4], vfma(p.yyd, V[3], vfma(p.yd, V[2], -V[1]))));
+    const T s3 = vfma(-p.x, V[4], vfma(p.y, V[3], V[2]));
+    res_c = vfma(p.pc, s1, vfma(p.qc, s2, p.bct));
+    res_d = vfma(p.pd, s1, vfma(p.qd, s2, vfma(p.twd, s3, p.bdt)));
+}
+
 // A pixel that is not in validPixels gets a harmless stand-in record (finite rows) and weight 0,
 // so the streaming loops are branch-free: no exec-mask juggling around the 27 accumulators.
 template <int VEC>
@@ -630,17 +697,29 @@ __device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, c
 __device__ __noinline__ void irls_initial_residual(const KArgs &a, int b, int L, SolveShared &s, int tid) {
     const IrlsCtx c = make_irls_ctx(a, b, L, s);
     double sabs = 0.0;
-    for (int i0 = tid * SF_VEC; i0 < c.n; i0 += SF_NT * SF_VEC) {
-        RecVec<SF_VEC> rv;
-        load_rec<SF_VEC>(c.rp, i0, rv);
-#pragma unroll
-        for (int j = 0; j < SF_VEC; j++) {
-            const bool ok = sanitize<SF_VEC>(rv, j);
-            PixRows r;
-            rows_of<SF_VEC>(rv, j, i0, c.g, r);
-            sabs += ok ? (double)fabsf(-r.bc) : 0.0;
-            sabs += ok ? (double)fabsf(-r.bd) : 0.0;
-        }
+    for (int i0 = tid * 2; i0 < c.n; i0 += SF_NT * 2) {
+        RecVec<2> rv;
+        load_rec<2>(c.rp, i0, rv);
+        const bool ok0 = sanitize<2>(rv, 0), ok1 = sanitize<2>(rv, 1);
+#if SF_FACTORED_IRLS
+        float fu0, fv0, fu1, fv1;
+        split_index(c.g, i0, fu0, fv0);
+        split_index(c.g, i0 + 1, fu1, fv1);
+        PixFact<vfloat2> p;
+        fact_from_record<vfloat2>(c.g, vfloat2{fu0, fu1}, vfloat2{fv0, fv1}, pair_of(rv.dn), pair_of(rv.v[R_DW]), pair_of(rv.v[R_DCU]),
+                                  pair_of(rv.v[R_DCV]), pair_of(rv.v[R_DCT]), pair_of(rv.v[R_DDU]), pair_of(rv.v[R_DDV]), p);
+        sabs += ok0 ? (double)fabsf(p.bct.x) : 0.0;
+        sabs += ok0 ? (double)fabsf(p.bdt.x) : 0.0;
+        sabs += ok1 ? (double)fabsf(p.bct.y) : 0.0;
+        sabs += ok1 ? (double)fabsf(p.bdt.y) : 0.0;
+#else
+        PixRowsT<vfloat2> r;
+        rows_of_pair(rv, i0, c.g, r);
+        sabs += ok0 ? (double)fabsf(-r.bc.x) : 0.0;
+        sabs += ok0 ? (double)fabsf(-r.bd.x) : 0.0;
+        sabs += ok1 ? (double)fabsf(-r.bc.y) : 0.0;
+        sabs += ok1 ? (double)fabsf(-r.bd.y) : 0.0;
+#endif
     }
     sabs = wave_sum_f64(sabs);
     if ((tid & 63) == 0) s.red[tid >> 6][0] = sabs;
@@ -655,41 +734,100 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, SolveShare
     const IrlsCtx c = make_irls_ctx(a, b, L, s);
     const float inv_c_Cauchy = 1.f / (a.p.kc_Cauchy * uniform_f(s.aver_res));
     double acc[27];
+    float accf[27];
 #pragma unroll
-    for (int q = 0; q < 27; q++) acc[q] = 0.0;
+    for (int q = 0; q < 27; q++) {
+        acc[q] = 0.0;
+        accf[q] = 0.f;
+    }
     float Vr[6];
 #pragma unroll
     for (int q = 0; q < 6; q++) Vr[q] = uniform_f(s.Var[q]);
-    for (int i0 = tid * SF_VEC; i0 < c.n; i0 += SF_NT * SF_VEC) {
-        RecVec<SF_VEC> rv;
-        load_rec<SF_VEC>(c.rp, i0, rv);
+    for (int i0 = tid * 2; i0 < c.n; i0 += SF_NT * 2) {
+        RecVec<2> rv;
+        load_rec<2>(c.rp, i0, rv);
+        const bool ok0 = sanitize<2>(rv, 0), ok1 = sanitize<2>(rv, 1);
+        if constexpr (VAR == 1) {
+            float t = rv.dn[0] + rv.dn[1];
 #pragma unroll
-        for (int j = 0; j < SF_VEC; j++) {
-            const bool ok = sanitize<SF_VEC>(rv, j);
-            if constexpr (VAR == 1) {
-                float t = rv.dn[j];
+            for (int q = 0; q < R_COUNT; q++) t += rv.v[q][0] + rv.v[q][1];
+            acc[0] += (double)t;
+            continue;
+        }
+        // one pixel at a time: the 27 fp64 accumulators leave no room for the rows of a pixel pair
 #pragma unroll
-                for (int q = 0; q < R_COUNT; q++) t += rv.v[q][j];
-                acc[0] += (double)t;
-                continue;
-            }
-            PixRows r;
-            rows_of<SF_VEC>(rv, j, i0, c.g, r);
+        for (int j = 0; j < 2; j++) {
+            const bool ok = j ? ok1 : ok0;
+            float fu, fv;
+            split_index(c.g, i0 + j, fu, fv);
             const float b_weight = ok ? std_max(0.f, std_min(1.f, s.b_segm[rv.lab[j]])) : 0.f;
+            float awf[2][7];
+#if SF_FACTORED_IRLS
+            {
+                PixFact<float> p;
+                fact_from_record<float>(c.g, fu, fv, rv.dn[j], rv.v[R_DW][j], rv.v[R_DCU][j], rv.v[R_DCV][j], rv.v[R_DCT][j],
+                                        rv.v[R_DDU][j], rv.v[R_DDV][j], p);
+                float res_c, res_d;
+                fact_residuals<float>(p, Vr, res_c, res_d);
+                const float w_c = b_weight * sqrtf(1.f / (1.f + sqf(res_c * inv_c_Cauchy)));
+                const float w_d = b_weight * sqrtf(1.f / (1.f + sqf(res_d * inv_c_Cauchy)));
+                const float P = w_c * p.pc, Q = w_c * p.qc;
+                awf[0][0] = -P;
+                awf[0][1] = -Q;
+                awf[0][2] = fmaf(P, p.xd, Q * p.yd);
+                awf[0][3] = fmaf(P, p.xyd, Q * p.yyd);
+                awf[0][4] = -fmaf(P, p.xxd, Q * p.xyd);
+                awf[0][5] = fmaf(P, p.y, -(Q * p.x));
+                awf[0][6] = -(w_c * p.bct);
+                const float W = w_d * p.twd, Pd = w_d * p.pd, Qd = w_d * p.qd;
+                awf[1][0] = -Pd;
+                awf[1][1] = -Qd;
+                awf[1][2] = fmaf(Pd, p.xd, fmaf(Qd, p.yd, W));
+                awf[1][3] = fmaf(Pd, p.xyd, fmaf(Qd, p.yyd, W * p.y));
+                awf[1][4] = -fmaf(Pd, p.xxd, fmaf(Qd, p.xyd, W * p.x));
+                awf[1][5] = fmaf(Pd, p.y, -(Qd * p.x));
+                awf[1][6] = -(w_d * p.bdt);
+            }
+#else
+            {
+                PixRows r;
+                rows_from_record<float>(c.g, fu, fv, rv.dn[j], rv.v[R_DW][j], rv.v[R_DCU][j], rv.v[R_DCV][j], rv.v[R_DCT][j],
+                                        rv.v[R_DDU][j], rv.v[R_DDV][j], r);
+#pragma unroll
+                for (int row = 0; row < 2; row++) {
+                    const float *ar = row ? r.ad : r.ac;
+                    const float br = row ? r.bd : r.bc;
+                    float res = -br;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) res += Vr[q] * ar[q];
+                    const float w = b_weight * sqrtf(1.f / (1.f + sqf(res * inv_c_Cauchy)));
+#pragma unroll
+                    for (int q = 0; q < 6; q++) awf[row][q] = w * ar[q];
+                    awf[row][6] = w * br;
+                }
+            }
+#endif
 #pragma unroll
             for (int row = 0; row < 2; row++) {
-                const float *ar = row ? r.ad : r.ac;
-                const float br = row ? r.bd : r.bc;
-                float res = -br;
-#pragma unroll
-                for (int q = 0; q < 6; q++) res += Vr[q] * ar[q];
-                const float w = b_weight * sqrtf(1.f / (1.f + sqf(res * inv_c_Cauchy)));
                 double aw[7];
 #pragma unroll
-                for (int q = 0; q < 6; q++) aw[q] = (double)(w * ar[q]);
-                aw[6] = (double)(w * br);
+                for (int q = 0; q < 7; q++) aw[q] = (double)awf[row][q];
                 if constexpr (VAR == 2) {
                     acc[0] += ((aw[0] + aw[1]) + (aw[2] + aw[3])) + ((aw[4] + aw[5]) + aw[6]);
+                    continue;
+                }
+                if constexpr (VAR == 3) {  // ablation: fp32 accumulation (NOT the product's numerics)
+                    const float *f = awf[row];
+                    int q = 0;
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+#pragma unroll
+                        for (int jj = i; jj < 6; jj++) {
+                            accf[q] = fmaf(f[i], f[jj], accf[q]);
+                            q++;
+                        }
+#pragma unroll
+                    for (int i = 0; i < 6; i++) accf[21 + i] = fmaf(f[i], f[6], accf[21 + i]);
                     continue;
                 }
                 acc[0] = fma(aw[0], aw[0], acc[0]);   acc[1] = fma(aw[0], aw[1], acc[1]);
@@ -710,6 +848,10 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, SolveShare
         }
     }
     const int lane = tid & 63, wave = tid >> 6;
+    if constexpr (VAR == 3) {
+#pragma unroll
+        for (int q = 0; q < 27; q++) acc[q] = (double)accf[q];
+    }
 #pragma unroll
     for (int q = 0; q < 27; q++) {
         const double t = wave_sum_f64(acc[q]);
@@ -769,36 +911,54 @@ __device__ __noinline__ void irls_pass2(const KArgs &a, int b, int L, SolveShare
     double sq = 0.0;
     int cur_lab = 0;
     unsigned long long cur_sum = 0;
-    for (int i0 = tid * SF_VEC; i0 < c.n; i0 += SF_NT * SF_VEC) {
-        RecVec<SF_VEC> rv;
-        load_rec<SF_VEC>(c.rp, i0, rv);
+    for (int i0 = tid * 2; i0 < c.n; i0 += SF_NT * 2) {
+        RecVec<2> rv;
+        load_rec<2>(c.rp, i0, rv);
+        const bool ok0 = sanitize<2>(rv, 0), ok1 = sanitize<2>(rv, 1);
+        if constexpr (VAR == 1) {
+            float t = rv.dn[0] + rv.dn[1];
 #pragma unroll
-        for (int j = 0; j < SF_VEC; j++) {
-            const bool ok = sanitize<SF_VEC>(rv, j);
-            if constexpr (VAR == 1) {
-                float t = rv.dn[j];
-#pragma unroll
-                for (int q = 0; q < R_COUNT; q++) t += rv.v[q][j];
-                sq += (double)t;
-                continue;
-            }
-            PixRows r;
-            rows_of<SF_VEC>(rv, j, i0, c.g, r);
-            float rc = -r.bc, rd = -r.bd;
+            for (int q = 0; q < R_COUNT; q++) t += rv.v[q][0] + rv.v[q][1];
+            sq += (double)t;
+            continue;
+        }
+        vfloat2 rc, rd;
+#if SF_FACTORED_IRLS
+        {
+            float fu0, fv0, fu1, fv1;
+            split_index(c.g, i0, fu0, fv0);
+            split_index(c.g, i0 + 1, fu1, fv1);
+            PixFact<vfloat2> p;
+            fact_from_record<vfloat2>(c.g, vfloat2{fu0, fu1}, vfloat2{fv0, fv1}, pair_of(rv.dn), pair_of(rv.v[R_DW]),
+                                      pair_of(rv.v[R_DCU]), pair_of(rv.v[R_DCV]), pair_of(rv.v[R_DCT]), pair_of(rv.v[R_DDU]),
+                                      pair_of(rv.v[R_DDV]), p);
+            fact_residuals<vfloat2>(p, Vr, rc, rd);
+        }
+#else
+        {
+            PixRowsT<vfloat2> r;
+            rows_of_pair(rv, i0, c.g, r);
+            rc = -r.bc;
+            rd = -r.bd;
 #pragma unroll
             for (int q = 0; q < 6; q++) rc += Vr[q] * r.ac[q];
 #pragma unroll
             for (int q = 0; q < 6; q++) rd += Vr[q] * r.ad[q];
-            rc = ok ? rc : 0.f;
-            rd = ok ? rd : 0.f;
-            sq = fma((double)rc, (double)rc, sq);
-            sq = fma((double)rd, (double)rd, sq);
-            const unsigned long long fx = to_fix32_pos(fabsf(rc) + fabsf(rd));
+        }
+#endif
+#pragma unroll
+        for (int px = 0; px < 2; px++) {
+            const bool ok = px ? ok1 : ok0;
+            const float rcs = ok ? (px ? rc.y : rc.x) : 0.f;
+            const float rds = ok ? (px ? rd.y : rd.x) : 0.f;
+            sq = fma((double)rcs, (double)rcs, sq);
+            sq = fma((double)rds, (double)rds, sq);
+            const unsigned long long fx = to_fix32_pos(fabsf(rcs) + fabsf(rds));
             if constexpr (VAR == 2) {
                 sq += (double)(unsigned)(fx >> 32);
                 continue;
             }
-            const int lab = ok ? rv.lab[j] : cur_lab;
+            const int lab = ok ? rv.lab[px] : cur_lab;
             if (lab != cur_lab) {
                 if (cur_sum) atomicAdd((unsigned long long *)&s.lab_sum[cur_lab], cur_sum);
                 cur_lab = lab;

@@ -20,9 +20,16 @@ for b in range(a.batch):
 s.process_frame(0); s.synchronize()
 npx = 240 * 320
 for which in (1, 2):
-    for variant, name in ((0, "product"), (1, "loads only"), (2, "no accumulation")):
+    for variant, name in ((0, "product"), (1, "loads only"), (2, "no accumulation"), (3, "fp32 accumulation")):
+        if which == 2 and variant == 3:
+            continue
         s.microbench_pass(which, variant, 2)
         ms = s.microbench_pass(which, variant, a.reps)
         px = a.batch * a.reps * npx
         print("pass %d %-16s %8.3f ms  %6.2f Gpx/s  streamed(29 B/px) %7.1f GB/s  algorithmic(30 B/px/pass) %7.1f GB/s" % (
             which, name, ms, px / ms / 1e6, 29.0 * px / ms / 1e6, 30.0 * px / ms / 1e6))
+import ctypes as C
+t = (C.c_int64 * 24)()
+api.check(api.get_stage_profile(s.h, t))
+if t[23] > 0:
+    print("shader clock during the last pass launch: %.0f MHz (s_memtime ticks %d / 100 MHz ticks %d)" % (100.0 * t[22] / t[23], t[22], t[23]))

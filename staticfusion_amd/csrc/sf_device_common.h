@@ -225,3 +225,131 @@ __device__ __forceinline__ void splat_pixel(const SplatGeom &g, float xr, float 
 }
 
 #define SF_LOAD_BATCH 4  // independent pixels whose loads are issued before any of them is consumed
+
+// ---------------------------------------------------------------------------------------------
+//  Tiled splat: the level is walked in source tiles of SPLAT_TV x SPLAT_TU pixels.  The targets of
+//  a tile fall into a small window of the warped image (a rigid warp is locally a shift), which is
+//  accumulated in LDS with integer ds_add atomics and then added to the global accumulators once
+//  per touched cell: ~3x fewer, fully coalesced global atomics than one global atomic triple per
+//  bilinear tap.  Targets outside the window (strong local stretch) take the global path directly.
+//  Integer sums => the result is independent of both orders.
+// ---------------------------------------------------------------------------------------------
+#define SPLAT_TV 64
+#define SPLAT_TU (2 * SF_NT / 64)
+#define SPLAT_PX ((SPLAT_TV * SPLAT_TU) / SF_NT)  // source pixels per lane and tile
+#define WIN_V (SPLAT_TV + 6)
+#define WIN_U (SPLAT_TU + 6)
+#define WIN_CELLS (WIN_V * WIN_U)
+
+struct SplatWin {
+    long long d[WIN_CELLS];
+    long long i[WIN_CELLS];
+    unsigned w[WIN_CELLS];
+    int vmin, umin;
+};
+
+// Src::load(v, u, idx, z, xr, yr, iw) -> bool valid
+template <class Src>
+__device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int cols_i, const Src &src, long long *acc_d,
+                                            long long *acc_i, uint32_t *acc_w, SplatWin &win, int tid) {
+    const int lane = tid & 63;
+    const int tiles_v = (rows_i + SPLAT_TV - 1) / SPLAT_TV, tiles_u = (cols_i + SPLAT_TU - 1) / SPLAT_TU;
+    for (int tile = 0; tile < tiles_v * tiles_u; tile++) {
+        const int tv0 = (tile % tiles_v) * SPLAT_TV, tu0 = (tile / tiles_v) * SPLAT_TU;
+        // ---- phase 1: clear the window, load + project this lane's source pixels, window origin
+        for (int q = tid; q < WIN_CELLS; q += SF_NT) {
+            win.d[q] = 0;
+            win.i[q] = 0;
+            win.w[q] = 0;
+        }
+        if (tid == 0) {
+            win.vmin = 0x7fffffff;
+            win.umin = 0x7fffffff;
+        }
+        int uw[SPLAT_PX], vw[SPLAT_PX];
+        long long dfix[SPLAT_PX], ifix[SPLAT_PX];
+        bool ok[SPLAT_PX];
+        float z[SPLAT_PX], xr[SPLAT_PX], yr[SPLAT_PX], iw[SPLAT_PX];
+#pragma unroll
+        for (int k = 0; k < SPLAT_PX; k++) {
+            const int v = tv0 + lane, u = tu0 + (tid >> 6) + k * (SF_NT / 64);
+            const bool inside = v < rows_i && u < cols_i;
+            const int idx = inside ? v + u * rows_i : 0;
+            ok[k] = src.load(v, u, idx, z[k], xr[k], yr[k], iw[k]) && inside;
+        }
+        int vmin = 0x7fffffff, umin = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < SPLAT_PX; k++) {
+            const float x_w = g.T[0] * xr[k] + g.T[1] * yr[k] + g.T[2] * z[k] + g.T[3];
+            const float y_w = g.T[4] * xr[k] + g.T[5] * yr[k] + g.T[6] * z[k] + g.T[7];
+            const float depth_w = g.T[8] * xr[k] + g.T[9] * yr[k] + g.T[10] * z[k] + g.T[11];
+            uw[k] = cvt_trunc_x86(100.f * (g.f * x_w / depth_w + g.disp_u_i));
+            vw[k] = cvt_trunc_x86(100.f * (g.f * y_w / depth_w + g.disp_v_i));
+            ok[k] = ok[k] && (uw[k] >= 0) && (uw[k] < g.cols_lim) && (vw[k] >= 0) && (vw[k] < g.rows_lim);
+            dfix[k] = to_fix(depth_w, FIX_DEPTH, 1000.f);
+            ifix[k] = to_fix(iw[k], FIX_INTENS, 4.f);
+            if (ok[k]) {
+                vmin = min(vmin, vw[k] / 100);
+                umin = min(umin, uw[k] / 100);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            vmin = min(vmin, __shfl_down(vmin, o, 64));
+            umin = min(umin, __shfl_down(umin, o, 64));
+        }
+        __syncthreads();  // window cleared, origin initialised
+        if (lane == 0) {
+            atomicMin(&win.vmin, vmin);
+            atomicMin(&win.umin, umin);
+        }
+        __syncthreads();
+        const int wv0 = uniform_i(win.vmin), wu0 = uniform_i(win.umin);
+        // ---- phase 2: splat into the window (LDS atomics), or straight to global if outside
+        auto add = [&](int v, int u, int w, long long df, long long jf) {
+            const int dv = v - wv0, du = u - wu0;
+            if (dv >= 0 && dv < WIN_V && du >= 0 && du < WIN_U) {
+                const int c = dv + du * WIN_V;
+                atomicAdd((unsigned long long *)&win.d[c], (unsigned long long)((long long)w * df));
+                atomicAdd((unsigned long long *)&win.i[c], (unsigned long long)((long long)w * jf));
+                atomicAdd(&win.w[c], (unsigned)w);
+            } else {
+                const int t = v + u * g.rows_i;
+                atomicAdd((unsigned long long *)&acc_d[t], (unsigned long long)((long long)w * df));
+                atomicAdd((unsigned long long *)&acc_i[t], (unsigned long long)((long long)w * jf));
+                atomicAdd(&acc_w[t], (uint32_t)w);
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < SPLAT_PX; k++) {
+            if (!ok[k]) continue;
+            const int uwarp = uw[k], vwarp = vw[k];
+            const int uwarp_l = uwarp - uwarp % 100, uwarp_r = uwarp_l + 100;
+            const int vwarp_d = vwarp - vwarp % 100, vwarp_u = vwarp_d + 100;
+            const int delta_r = uwarp_r - uwarp, delta_l = 100 - delta_r;
+            const int delta_u = vwarp_u - vwarp, delta_d = 100 - delta_u;
+            if (min(delta_r, delta_l) + min(delta_u, delta_d) < 5) {  // within 5 centi-pixels of a pixel centre
+                add(delta_u > delta_d ? vwarp_d / 100 : vwarp_u / 100, delta_r > delta_l ? uwarp_l / 100 : uwarp_r / 100, 200,
+                    dfix[k], ifix[k]);
+            } else {
+                const int v_d = vwarp_d / 100, u_l = uwarp_l / 100;
+                add(v_d + 1, u_l + 1, delta_l + delta_d, dfix[k], ifix[k]);
+                add(v_d + 1, u_l, delta_r + delta_d, dfix[k], ifix[k]);
+                add(v_d, u_l + 1, delta_l + delta_u, dfix[k], ifix[k]);
+                add(v_d, u_l, delta_r + delta_u, dfix[k], ifix[k]);
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: add the touched cells to the global accumulators (consecutive lanes -> consecutive v)
+        for (int q = tid; q < WIN_CELLS; q += SF_NT) {
+            const unsigned w = win.w[q];
+            if (w == 0) continue;
+            const int du = q / WIN_V, dv = q - du * WIN_V;
+            const int t = (wv0 + dv) + (wu0 + du) * g.rows_i;
+            atomicAdd((unsigned long long *)&acc_d[t], (unsigned long long)win.d[q]);
+            atomicAdd((unsigned long long *)&acc_i[t], (unsigned long long)win.i[q]);
+            atomicAdd(&acc_w[t], w);
+        }
+        __syncthreads();  // before the next tile clears the window
+    }
+}

@@ -12,6 +12,7 @@ struct ResShared {
     long long lab_sum[SF_NC];
     int lab_cnt[SF_NC];
     double dwork[32];
+    SplatWin win;
 };
 
 __device__ __forceinline__ int level0_label(const KArgs &a, const uint8_t *labels0, int idx) {
@@ -67,25 +68,19 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, R
 #pragma unroll
         for (int c = 0; c < 4; c++) g.T[r * 4 + c] = uniform_f(s.Tinv[r + 4 * c]);
 
-    for (int base = tid; base < n; base += SF_NT * SF_LOAD_BATCH) {
-        float z[SF_LOAD_BATCH], iw[SF_LOAD_BATCH], dc[SF_LOAD_BATCH];
-#pragma unroll
-        for (int k = 0; k < SF_LOAD_BATCH; k++) {
-            const int idx = min(base + k * SF_NT, n - 1);
-            z[k] = dbuf[idx];
-            iw[k] = ibuf[idx];
-            dc[k] = dcur[idx];
+    struct Src {
+        const float *dbuf, *ibuf, *dcur;
+        float inv_f_i, disp_u_i, disp_v_i;
+        __device__ __forceinline__ bool load(int v, int u, int idx, float &z, float &xr, float &yr, float &iw) const {
+            z = dbuf[idx];
+            iw = ibuf[idx];
+            const float dc = dcur[idx];
+            xr = (inv_f_i * (float(u) - disp_u_i)) * z;  // xxBuffer / yyBuffer (:922-926)
+            yr = (inv_f_i * (float(v) - disp_v_i)) * z;
+            return z != 0.f && dc != 0.f;
         }
-#pragma unroll
-        for (int k = 0; k < SF_LOAD_BATCH; k++) {
-            const int idx = base + k * SF_NT;
-            if (!(idx < n && z[k] != 0.f && dc[k] != 0.f)) continue;
-            const int u = idx / rows, v = idx - u * rows;
-            const float xb = (inv_f_i * (float(u) - g.disp_u_i)) * z[k];  // xxBuffer / yyBuffer (:922-926)
-            const float yb = (inv_f_i * (float(v) - g.disp_v_i)) * z[k];
-            splat_pixel(g, xb, yb, z[k], iw[k], acc_d, acc_i, acc_w);
-        }
-    }
+    } src{dbuf, ibuf, dcur, inv_f_i, g.disp_u_i, g.disp_v_i};
+    tiled_splat(g, rows, cols, src, acc_d, acc_i, acc_w, s.win, tid);
     __syncthreads();
 
     // residuals, cluster-wise (:1036-1068)

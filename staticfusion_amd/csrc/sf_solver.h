@@ -62,6 +62,7 @@ struct SolveShared {
     int seg_allzero;
     double dwork[36 * 3 + 32];
     long long prof[SF_PROF_SLOTS], t_last;
+    SplatWin win;
 };
 
 #ifdef SF_NO_PROF_MARK
@@ -288,21 +289,17 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, SolveShare
 #pragma unroll
         for (int c = 0; c < 4; c++) g.T[r * 4 + c] = uniform_f(s.Tinv[r + 4 * c]);
 
-    // SF_LOAD_BATCH pixels per lane and trip: all 16 loads are in flight before the first is used
-    for (int base = tid; base < n; base += SF_NT * SF_LOAD_BATCH) {
-        float z[SF_LOAD_BATCH], iw[SF_LOAD_BATCH], xr[SF_LOAD_BATCH], yr[SF_LOAD_BATCH];
-#pragma unroll
-        for (int k = 0; k < SF_LOAD_BATCH; k++) {
-            const int idx = min(base + k * SF_NT, n - 1);
-            z[k] = dpred[idx];
-            iw[k] = ipred[idx];
-            xr[k] = xpred[idx];
-            yr[k] = ypred[idx];
+    struct Src {
+        const float *d, *i, *x, *y;
+        __device__ __forceinline__ bool load(int, int, int idx, float &z, float &xr, float &yr, float &iw) const {
+            z = d[idx];
+            iw = i[idx];
+            xr = x[idx];
+            yr = y[idx];
+            return z != 0.f;
         }
-#pragma unroll
-        for (int k = 0; k < SF_LOAD_BATCH; k++)
-            if (base + k * SF_NT < n && z[k] != 0.f) splat_pixel(g, xr[k], yr[k], z[k], iw[k], acc_d, acc_i, acc_w);
-    }
+    } src{dpred, ipred, xpred, ypred};
+    tiled_splat(g, rows_i, cols_i, src, acc_d, acc_i, acc_w, s.win, tid);
     __syncthreads();  // all atomics of this workgroup performed at L2
 }
 

@@ -187,25 +187,35 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, in
 
         // pass A: assignment + member counts of this wave range
         int cnt = 0;  // lane l < 24 holds the count of label l
-        for (int base = w_begin; base < w_end; base += 64) {
-            const int idx = base + lane;
-            bool valid = false;
-            int best = 0;
-            if (idx < w_end) {
-                const float pz = depth[o1 + idx];
-                if (pz != 0.f) {
+        for (int base = w_begin; base < w_end; base += 64 * SF_LOAD_BATCH) {
+            float pz[SF_LOAD_BATCH], px[SF_LOAD_BATCH], py[SF_LOAD_BATCH];
+            int old[SF_LOAD_BATCH];
+#pragma unroll
+            for (int k = 0; k < SF_LOAD_BATCH; k++) {  // all loads of the batch in flight before the first search
+                const int idx = min(base + k * 64 + lane, n1 - 1);
+                pz[k] = depth[o1 + idx];
+                px[k] = xx[o1 + idx];
+                py[k] = yy[o1 + idx];
+                old[k] = labels[o1 + idx];
+            }
+#pragma unroll
+            for (int k = 0; k < SF_LOAD_BATCH; k++) {
+                const int idx = base + k * 64 + lane;
+                bool valid = false;
+                int best = 0;
+                if (idx < w_end && pz[k] != 0.f) {
                     valid = true;
-                    best = km_search(s, labels[o1 + idx], pz, xx[o1 + idx], yy[o1 + idx]);
+                    best = km_search(s, old[k], pz[k], px[k], py[k]);
                     labels[o1 + idx] = (uint8_t)best;
                 }
-            }
-            unsigned long long rem = __ballot(valid);
-            while (rem) {
-                const int src = __ffsll((long long)rem) - 1;
-                const int l = __builtin_amdgcn_readlane(best, src);
-                const unsigned long long m = __ballot(valid && best == l);
-                if (lane == l) cnt += __popcll(m);
-                rem &= ~m;
+                unsigned long long rem = __ballot(valid);
+                while (rem) {
+                    const int src = __ffsll((long long)rem) - 1;
+                    const int l = __builtin_amdgcn_readlane(best, src);
+                    const unsigned long long m = __ballot(valid && best == l);
+                    if (lane == l) cnt += __popcll(m);
+                    rem &= ~m;
+                }
             }
         }
         if (lane < SF_NC) s.wcnt[wave][lane] = cnt;
@@ -232,32 +242,37 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, in
 
         // pass B: stable partition into per-cluster runs
         int running = (lane < SF_NC) ? (s.off[lane] + s.wcnt[wave][lane]) : 0;
-        for (int base = w_begin; base < w_end; base += 64) {
-            const int idx = base + lane;
-            bool valid = false;
-            int lab = 0;
-            float pz = 0.f;
-            if (idx < w_end) {
-                pz = depth[o1 + idx];
-                if (pz != 0.f) {
-                    valid = true;
-                    lab = labels[o1 + idx];
-                }
+        for (int base = w_begin; base < w_end; base += 64 * SF_LOAD_BATCH) {
+            float pz[SF_LOAD_BATCH], px[SF_LOAD_BATCH], py[SF_LOAD_BATCH];
+            int labk[SF_LOAD_BATCH];
+#pragma unroll
+            for (int k = 0; k < SF_LOAD_BATCH; k++) {
+                const int idx = min(base + k * 64 + lane, n1 - 1);
+                pz[k] = depth[o1 + idx];
+                px[k] = xx[o1 + idx];
+                py[k] = yy[o1 + idx];
+                labk[k] = labels[o1 + idx];
             }
-            unsigned long long rem = __ballot(valid);
-            while (rem) {
-                const int src = __ffsll((long long)rem) - 1;
-                const int l = __builtin_amdgcn_readlane(lab, src);
-                const unsigned long long m = __ballot(valid && lab == l);
-                const int start = __builtin_amdgcn_readlane(running, l);
-                if (valid && lab == l) {
-                    const int pos = start + __popcll(m & ((1ull << lane) - 1ull));
-                    srt0[pos] = pz;
-                    srt1[pos] = xx[o1 + idx];
-                    srt2[pos] = yy[o1 + idx];
+#pragma unroll
+            for (int k = 0; k < SF_LOAD_BATCH; k++) {  // ascending pixel order: ranks stay stable
+                const int idx = base + k * 64 + lane;
+                const bool valid = idx < w_end && pz[k] != 0.f;
+                const int lab = valid ? labk[k] : 0;
+                unsigned long long rem = __ballot(valid);
+                while (rem) {
+                    const int src = __ffsll((long long)rem) - 1;
+                    const int l = __builtin_amdgcn_readlane(lab, src);
+                    const unsigned long long m = __ballot(valid && lab == l);
+                    const int start = __builtin_amdgcn_readlane(running, l);
+                    if (valid && lab == l) {
+                        const int pos = start + __popcll(m & ((1ull << lane) - 1ull));
+                        srt0[pos] = pz[k];
+                        srt1[pos] = px[k];
+                        srt2[pos] = py[k];
+                    }
+                    if (lane == l) running += __popcll(m);
+                    rem &= ~m;
                 }
-                if (lane == l) running += __popcll(m);
-                rem &= ~m;
             }
         }
         __syncthreads();
@@ -270,12 +285,12 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, in
             const int n = s.count[c];
             float acc = 0.f;
             int j = 0;
-            for (; j + 4 <= n; j += 4) {
-                const float v0 = src[j], v1 = src[j + 1], v2 = src[j + 2], v3 = src[j + 3];
-                acc += v0;
-                acc += v1;
-                acc += v2;
-                acc += v3;
+            for (; j + 16 <= n; j += 16) {  // 16 loads in flight, then 16 strictly ordered adds
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) v[q] = src[j + q];
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc += v[q];
             }
             for (; j < n; j++) acc += src[j];
             if (n > 0) acc /= float(n);

@@ -141,6 +141,41 @@ __device__ __forceinline__ int cvt_trunc_x86(float x) {
     return (int)x;
 }
 
+// Buffer pointers come out of the KArgs table as generic pointers; every stage casts them to the
+// GLOBAL address space so that loads / stores / atomics compile to global_* instructions (vmcnt only).
+// With flat_* accesses every LDS wait also drains the outstanding global loads, which serialises
+// prefetched loads behind the first LDS access.
+// LDS: the workgroup's shared structs are passed to the (separately compiled) stage functions as
+// references qualified with the LOCAL address space, so that their members are accessed with ds_*
+// instructions (a plain reference is a generic pointer: every access becomes a flat_* instruction
+// that waits on both memory counters).
+#define LDS __attribute__((address_space(3)))
+template <class T>
+__device__ __forceinline__ void lds_add(LDS T *p, T v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <class T>
+__device__ __forceinline__ void lds_min(LDS T *p, T v) {
+    __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <class T>
+__device__ __forceinline__ void lds_or(LDS T *p, T v) {
+    __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <class T>
+using gptr = __attribute__((address_space(1))) T *;
+template <class T>
+__device__ __forceinline__ gptr<T> as_global(T *p) {
+    return (gptr<T>)p;
+}
+__device__ __forceinline__ void gatomic_add(gptr<long long> p, long long v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gatomic_add(gptr<uint32_t> p, uint32_t v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // a value every lane holds identically (read from LDS / memory): move it to an SGPR
 __device__ __forceinline__ float uniform_f(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 __device__ __forceinline__ int uniform_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -158,7 +193,7 @@ __device__ __forceinline__ long long to_fix(float x, float scale, float lim) {
 }
 
 // aggregate a per-lane 64-bit value into bins[label], one LDS atomic per distinct label per wave
-__device__ __forceinline__ void wave_label_add_i64(bool active, int lab, long long v, long long *bins, int lane) {
+__device__ __forceinline__ void wave_label_add_i64(bool active, int lab, long long v, LDS long long *bins, int lane) {
     unsigned long long rem = __ballot(active);
     while (rem) {
         const int src = __ffsll((long long)rem) - 1;
@@ -166,17 +201,17 @@ __device__ __forceinline__ void wave_label_add_i64(bool active, int lab, long lo
         const bool mine = active && lab == l;
         const unsigned long long m = __ballot(mine);
         const long long sum = wave_sum_i64(mine ? v : 0ll);
-        if (lane == 0) atomicAdd((unsigned long long *)&bins[l], (unsigned long long)sum);
+        if (lane == 0) lds_add(bins + l, sum);
         rem &= ~m;
     }
 }
-__device__ __forceinline__ void wave_label_count(bool active, int lab, int *bins, int lane) {
+__device__ __forceinline__ void wave_label_count(bool active, int lab, LDS int *bins, int lane) {
     unsigned long long rem = __ballot(active);
     while (rem) {
         const int src = __ffsll((long long)rem) - 1;
         const int l = __builtin_amdgcn_readlane(lab, src);
         const unsigned long long m = __ballot(active && lab == l);
-        if (lane == 0) atomicAdd(&bins[l], (int)__popcll(m));
+        if (lane == 0) lds_add(bins + l, (int)__popcll(m));
         rem &= ~m;
     }
 }
@@ -193,35 +228,13 @@ struct SplatGeom {
     int cols_lim, rows_lim, rows_i;
 };
 
-__device__ __forceinline__ void splat_pixel(const SplatGeom &g, float xr, float yr, float z, float intensity_w,
-                                            long long *acc_d, long long *acc_i, uint32_t *acc_w) {
-    const float x_w = g.T[0] * xr + g.T[1] * yr + g.T[2] * z + g.T[3];
-    const float y_w = g.T[4] * xr + g.T[5] * yr + g.T[6] * z + g.T[7];
-    const float depth_w = g.T[8] * xr + g.T[9] * yr + g.T[10] * z + g.T[11];
-    const int uwarp = cvt_trunc_x86(100.f * (g.f * x_w / depth_w + g.disp_u_i));
-    const int vwarp = cvt_trunc_x86(100.f * (g.f * y_w / depth_w + g.disp_v_i));
-    if (!((uwarp >= 0) && (uwarp < g.cols_lim) && (vwarp >= 0) && (vwarp < g.rows_lim))) return;
-    const int uwarp_l = uwarp - uwarp % 100, uwarp_r = uwarp_l + 100;
-    const int vwarp_d = vwarp - vwarp % 100, vwarp_u = vwarp_d + 100;
-    const int delta_r = uwarp_r - uwarp, delta_l = 100 - delta_r;
-    const int delta_u = vwarp_u - vwarp, delta_d = 100 - delta_u;
-    const long long dfix = to_fix(depth_w, FIX_DEPTH, 1000.f);
-    const long long ifix = to_fix(intensity_w, FIX_INTENS, 4.f);
-    auto splat = [&](int v, int u, int w) {
-        const int t = v + u * g.rows_i;
-        atomicAdd((unsigned long long *)&acc_d[t], (unsigned long long)((long long)w * dfix));
-        atomicAdd((unsigned long long *)&acc_i[t], (unsigned long long)((long long)w * ifix));
-        atomicAdd(&acc_w[t], (uint32_t)w);
-    };
-    if (min(delta_r, delta_l) + min(delta_u, delta_d) < 5) {  // within 5 centi-pixels of a pixel centre
-        splat(delta_u > delta_d ? vwarp_d / 100 : vwarp_u / 100, delta_r > delta_l ? uwarp_l / 100 : uwarp_r / 100, 200);
-    } else {
-        const int v_d = vwarp_d / 100, u_l = uwarp_l / 100;
-        splat(v_d + 1, u_l + 1, delta_l + delta_d);
-        splat(v_d + 1, u_l, delta_r + delta_d);
-        splat(v_d, u_l + 1, delta_l + delta_u);
-        splat(v_d, u_l, delta_r + delta_u);
-    }
+// depth / intensity of a target pixel from its fixed-point accumulators: sum(w * value) / sum(w).
+// The integer sums are exact; one int64 -> float conversion and one IEEE float division round twice
+// (<= 1 ulp from the exact quotient, the same order as the reference's own float accumulation).
+__device__ __forceinline__ void normalise_acc(long long sd, long long si, unsigned w, float &dw, float &iw) {
+    const float wf = (float)w;
+    dw = ((float)sd * (1.f / 67108864.f)) / wf;
+    iw = ((float)si * (1.f / 1073741824.f)) / wf;
 }
 
 #define SF_LOAD_BATCH 4  // independent pixels whose loads are issued before any of them is consumed
@@ -250,8 +263,8 @@ struct SplatWin {
 
 // Src::load(v, u, idx, z, xr, yr, iw) -> bool valid
 template <class Src>
-__device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int cols_i, const Src &src, long long *acc_d,
-                                            long long *acc_i, uint32_t *acc_w, SplatWin &win, int tid) {
+__device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int cols_i, const Src &src, gptr<long long> acc_d,
+                                            gptr<long long> acc_i, gptr<uint32_t> acc_w, LDS SplatWin &win, int tid) {
     const int lane = tid & 63;
     const int tiles_v = (rows_i + SPLAT_TV - 1) / SPLAT_TV, tiles_u = (cols_i + SPLAT_TU - 1) / SPLAT_TU;
     for (int tile = 0; tile < tiles_v * tiles_u; tile++) {
@@ -300,8 +313,8 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
         }
         __syncthreads();  // window cleared, origin initialised
         if (lane == 0) {
-            atomicMin(&win.vmin, vmin);
-            atomicMin(&win.umin, umin);
+            lds_min(&win.vmin, vmin);
+            lds_min(&win.umin, umin);
         }
         __syncthreads();
         const int wv0 = uniform_i(win.vmin), wu0 = uniform_i(win.umin);
@@ -310,14 +323,14 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
             const int dv = v - wv0, du = u - wu0;
             if (dv >= 0 && dv < WIN_V && du >= 0 && du < WIN_U) {
                 const int c = dv + du * WIN_V;
-                atomicAdd((unsigned long long *)&win.d[c], (unsigned long long)((long long)w * df));
-                atomicAdd((unsigned long long *)&win.i[c], (unsigned long long)((long long)w * jf));
-                atomicAdd(&win.w[c], (unsigned)w);
+                lds_add(&win.d[c], (long long)w * df);
+                lds_add(&win.i[c], (long long)w * jf);
+                lds_add(&win.w[c], (unsigned)w);
             } else {
                 const int t = v + u * g.rows_i;
-                atomicAdd((unsigned long long *)&acc_d[t], (unsigned long long)((long long)w * df));
-                atomicAdd((unsigned long long *)&acc_i[t], (unsigned long long)((long long)w * jf));
-                atomicAdd(&acc_w[t], (uint32_t)w);
+                gatomic_add(acc_d + t, (long long)w * df);
+                gatomic_add(acc_i + t, (long long)w * jf);
+                gatomic_add(acc_w + t, (uint32_t)w);
             }
         };
 #pragma unroll
@@ -346,9 +359,9 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
             if (w == 0) continue;
             const int du = q / WIN_V, dv = q - du * WIN_V;
             const int t = (wv0 + dv) + (wu0 + du) * g.rows_i;
-            atomicAdd((unsigned long long *)&acc_d[t], (unsigned long long)win.d[q]);
-            atomicAdd((unsigned long long *)&acc_i[t], (unsigned long long)win.i[q]);
-            atomicAdd(&acc_w[t], w);
+            gatomic_add(acc_d + t, win.d[q]);
+            gatomic_add(acc_i + t, win.i[q]);
+            gatomic_add(acc_w + t, (uint32_t)w);
         }
         __syncthreads();  // before the next tile clears the window
     }

@@ -58,12 +58,12 @@ __global__ __launch_bounds__(SF_NT, 4) void sf_frame_kernel(const KArgs *__restr
         t0 = t_begin;
         if (stage_mask & ST_PYR_OLD) STAGE_TIMED(PF_PYR_OLD, stage_pyramid(a, b, true, tid));
         if (stage_mask & ST_PYR_NEW) STAGE_TIMED(PF_PYR_NEW, stage_pyramid(a, b, false, tid));
-        if (stage_mask & ST_KMEANS) STAGE_TIMED(PF_KMEANS, stage_kmeans(a, b, sh.km, tid));
+        if (stage_mask & ST_KMEANS) STAGE_TIMED(PF_KMEANS, stage_kmeans(a, b, *(LDS KmShared *)&sh.km, tid));
         if (stage_mask & ST_SOLVE) {
-            stage_solve(a, b, sh.sv, tid);
+            stage_solve(a, b, *(LDS SolveShared *)&sh.sv, tid);
             t0 = wall_clock64();
         }
-        if (stage_mask & ST_RESIDUALS) STAGE_TIMED(PF_RESIDUALS, stage_residuals(a, b, im_count, sh.rs, tid));
+        if (stage_mask & ST_RESIDUALS) STAGE_TIMED(PF_RESIDUALS, stage_residuals(a, b, im_count, *(LDS ResShared *)&sh.rs, tid));
         __syncthreads();
         if (stage_mask & ST_SEGM_IMAGE) stage_segm_image(a, b, tid);
         if (stage_mask & ST_PUSH_HISTORY) stage_push_history(a, b, im_count, tid);
@@ -99,14 +99,14 @@ __global__ __launch_bounds__(SF_NT, 4) void sf_irls_pass_kernel(const KArgs *__r
             break;
         }
         if (which == 1) {
-            if (variant == 0) microbench_pass<1, 0>(a, b, reps, sh.sv, tid);
-            if (variant == 1) microbench_pass<1, 1>(a, b, reps, sh.sv, tid);
-            if (variant == 2) microbench_pass<1, 2>(a, b, reps, sh.sv, tid);
-            if (variant == 3) microbench_pass<1, 3>(a, b, reps, sh.sv, tid);
+            if (variant == 0) microbench_pass<1, 0>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
+            if (variant == 1) microbench_pass<1, 1>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
+            if (variant == 2) microbench_pass<1, 2>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
+            if (variant == 3) microbench_pass<1, 3>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
         } else {
-            if (variant == 0) microbench_pass<2, 0>(a, b, reps, sh.sv, tid);
-            if (variant == 1) microbench_pass<2, 1>(a, b, reps, sh.sv, tid);
-            if (variant == 2) microbench_pass<2, 2>(a, b, reps, sh.sv, tid);
+            if (variant == 0) microbench_pass<2, 0>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
+            if (variant == 1) microbench_pass<2, 1>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
+            if (variant == 2) microbench_pass<2, 2>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
         }
         __syncthreads();
     }

@@ -40,7 +40,7 @@ __device__ __forceinline__ float sqdist3(float a0, float a1, float a2, float b0,
 }
 
 // pairwise centre distances + per-row stable rank sort (KMeans.cpp:172-183)
-__device__ __noinline__ void km_sort_centres(KmShared &s, int tid) {
+__device__ __noinline__ void km_sort_centres(LDS KmShared &s, int tid) {
     for (int q = tid; q < SF_NC * SF_NC; q += SF_NT) {
         const int l = q / SF_NC, li = q - l * SF_NC;
         s.pair_dist[q] = sqdist3(s.cent_a[3 * l], s.cent_a[3 * l + 1], s.cent_a[3 * l + 2], s.cent_a[3 * li],
@@ -62,7 +62,7 @@ __device__ __noinline__ void km_sort_centres(KmShared &s, int tid) {
 }
 
 // pruned nearest-centre search starting from `last` (KMeans.cpp:196-212 and :263-285)
-__device__ __forceinline__ int km_search(const KmShared &s, int last, float pz, float px, float py) {
+__device__ __forceinline__ int km_search(const LDS KmShared &s, int last, float pz, float px, float py) {
     int best = last;
     const float d_last = sqdist3(s.cent_a[3 * last], s.cent_a[3 * last + 1], s.cent_a[3 * last + 2], pz, px, py);
     float best_d = d_last;
@@ -79,11 +79,12 @@ __device__ __forceinline__ int km_search(const KmShared &s, int last, float pz, 
     return best;
 }
 
-__device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, int tid) {
+__device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const size_t sb = (size_t)b * a.n_tot;
-    const float *depth = a.pyr_new[0] + sb, *xx = a.pyr_new[2] + sb, *yy = a.pyr_new[3] + sb;
-    uint8_t *labels = a.labels + sb;
+    const auto depth = as_global((const float *)a.pyr_new[0] + sb), xx = as_global((const float *)a.pyr_new[2] + sb),
+               yy = as_global((const float *)a.pyr_new[3] + sb);
+    const auto labels = as_global(a.labels + sb);
     StreamState &st = a.state[b];
     long long kt = wall_clock64();
 #define KM_MARK(slot)                              \
@@ -132,7 +133,7 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, in
             const unsigned lab = labels[o1 + idx];
             if (lab < SF_NC) {
                 const unsigned bits = __float_as_uint(depth[o1 + idx]);
-                if (pass == 0 || (bits >> (shift + 8)) == s.prefix[lab]) atomicAdd(&s.hist[lab * 256 + ((bits >> shift) & 255u)], 1u);
+                if (pass == 0 || (bits >> (shift + 8)) == s.prefix[lab]) lds_add(&s.hist[lab * 256 + ((bits >> shift) & 255u)], 1u);
             }
         }
         __syncthreads();
@@ -175,8 +176,8 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, in
 
     KM_MARK(PF_KM_INIT);
     // ------------------------------------------------------------------ Lloyd iterations (K2)
-    float *srt0 = a.km_sorted[0] + (size_t)b * n1, *srt1 = a.km_sorted[1] + (size_t)b * n1,
-          *srt2 = a.km_sorted[2] + (size_t)b * n1;
+    const auto srt0 = as_global(a.km_sorted[0] + (size_t)b * n1), srt1 = as_global(a.km_sorted[1] + (size_t)b * n1),
+               srt2 = as_global(a.km_sorted[2] + (size_t)b * n1);
     const int chunk = ((n1 + SF_NW - 1) / SF_NW + 63) & ~63;  // pixels per wave range, multiple of 64
     const int w_begin = wave * chunk, w_end = min(n1, w_begin + chunk);
     int iters = 0;
@@ -281,7 +282,7 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, in
         // sequential float sums, one (cluster, coordinate) per lane (KMeans.cpp:215-221)
         if (tid < 3 * SF_NC) {
             const int c = tid / 3, r = tid - 3 * c;
-            const float *src = (r == 0 ? srt0 : (r == 1 ? srt1 : srt2)) + s.off[c];
+            const gptr<float> src = (r == 0 ? srt0 : (r == 1 ? srt1 : srt2)) + s.off[c];
             const int n = s.count[c];
             float acc = 0.f;
             int j = 0;
@@ -347,15 +348,15 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, KmShared &s, in
             if (la != ld && ld != SF_NC) {
                 const float disty = sqf(dz - depth[idx + 1]) + sqf(yy[idx] - yy[idx + 1]);
                 if (disty < dist2_threshold) {
-                    atomicOr(&s.conn[la], 1u << ld);
-                    atomicOr(&s.conn[ld], 1u << la);
+                    lds_or(&s.conn[la], 1u << ld);
+                    lds_or(&s.conn[ld], 1u << la);
                 }
             }
             if (la != lr && lr != SF_NC) {
                 const float distx = sqf(dz - depth[idx + rows0]) + sqf(xx[idx] - xx[idx + rows0]);
                 if (distx < dist2_threshold) {
-                    atomicOr(&s.conn[la], 1u << lr);
-                    atomicOr(&s.conn[lr], 1u << la);
+                    lds_or(&s.conn[la], 1u << lr);
+                    lds_or(&s.conn[lr], 1u << la);
                 }
             }
         }

@@ -16,22 +16,22 @@ __device__ __forceinline__ float conv_mask(int k) {
 
 __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, bool old_im, int tid) {
     float *const *set = old_im ? a.pyr_pred : a.pyr_new;
-    float *depth = set[0] + (size_t)b * a.n_tot;
-    float *inten = set[1] + (size_t)b * a.n_tot;
-    float *xx = set[2] + (size_t)b * a.n_tot;
-    float *yy = set[3] + (size_t)b * a.n_tot;
+    const auto depth = as_global(set[0] + (size_t)b * a.n_tot);
+    const auto inten = as_global(set[1] + (size_t)b * a.n_tot);
+    const auto xx = as_global(set[2] + (size_t)b * a.n_tot);
+    const auto yy = as_global(set[3] + (size_t)b * a.n_tot);
     const float max_depth_dif = 0.1f;
 
     for (int L = 0; L < a.levels; L++) {
         const int rows_i = a.lrows[L], cols_i = a.lcols[L], n = a.ln[L];
-        float *d_here = depth + a.loff[L], *i_here = inten + a.loff[L];
+        const auto d_here = depth + a.loff[L], i_here = inten + a.loff[L];
         const float inv_f_i = 2.f * a.tan_half_fovh / float(cols_i);
         const float disp_u_i = 0.5f * (cols_i - 1);
         const float disp_v_i = 0.5f * (rows_i - 1);
 
         if (L > 0) {
             __syncthreads();  // level L-1 complete (written by this workgroup)
-            const float *d_prev = depth + a.loff[L - 1], *i_prev = inten + a.loff[L - 1];
+            const auto d_prev = depth + a.loff[L - 1], i_prev = inten + a.loff[L - 1];
             const int rows_p = a.lrows[L - 1];
             for (int idx = tid; idx < n; idx += SF_NT) {
                 const int u = idx / rows_i, v = idx - u * rows_i;

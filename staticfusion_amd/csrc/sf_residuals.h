@@ -15,23 +15,23 @@ struct ResShared {
     SplatWin win;
 };
 
-__device__ __forceinline__ int level0_label(const KArgs &a, const uint8_t *labels0, int idx) {
+__device__ __forceinline__ int level0_label(const KArgs &a, gptr<const uint8_t> labels0, int idx) {
     // without segmentation the reference's clusterAllocation[0] stays at its constructor value 0
     return a.p.segmentation_enabled ? (int)labels0[idx] : 0;
 }
 
-__device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, ResShared &s, int tid) {
+__device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, LDS ResShared &s, int tid) {
     const int lane = tid & 63;
     StreamState &st = a.state[b];
     const int rows = a.lrows[0], cols = a.lcols[0], n = a.ln[0];
     const size_t sb = (size_t)b * a.n_tot, rb = (size_t)b * a.n0;
-    const float *dcur = a.pyr_new[0] + sb, *icur = a.pyr_new[1] + sb;  // depthCurrent / intensityCurrent
-    const uint8_t *labels0 = a.labels + sb;
+    const auto dcur = as_global((const float *)a.pyr_new[0] + sb), icur = as_global((const float *)a.pyr_new[1] + sb);  // depthCurrent / intensityCurrent
+    const auto labels0 = as_global((const uint8_t *)a.labels + sb);
     const int idx_to_warp = (index - SF_HISTORY) % SF_HISTORY;
-    const float *dbuf = a.hist_d + ((size_t)idx_to_warp * a.batch + b) * a.n0;
-    const float *ibuf = a.hist_i + ((size_t)idx_to_warp * a.batch + b) * a.n0;
-    long long *acc_d = a.acc_d + rb, *acc_i = a.acc_i + rb;
-    uint32_t *acc_w = a.acc_w + rb;
+    const auto dbuf = as_global((const float *)a.hist_d + ((size_t)idx_to_warp * a.batch + b) * a.n0);
+    const auto ibuf = as_global((const float *)a.hist_i + ((size_t)idx_to_warp * a.batch + b) * a.n0);
+    const auto acc_d = as_global(a.acc_d + rb), acc_i = as_global(a.acc_i + rb);
+    const auto acc_w = as_global(a.acc_w + rb);
 
     if (tid == 0) {
         // T = prod odomBuffer[(index-4 .. index-1) % 5] * T_odometry, then inverse (:901-909)
@@ -69,7 +69,7 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, R
         for (int c = 0; c < 4; c++) g.T[r * 4 + c] = uniform_f(s.Tinv[r + 4 * c]);
 
     struct Src {
-        const float *dbuf, *ibuf, *dcur;
+        gptr<const float> dbuf, ibuf, dcur;
         float inv_f_i, disp_u_i, disp_v_i;
         __device__ __forceinline__ bool load(int v, int u, int idx, float &z, float &xr, float &yr, float &iw) const {
             z = dbuf[idx];
@@ -91,13 +91,13 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, R
         int lab = 0;
         long long fx = 0;
         if (idx < n) {
-            const uint32_t w = __hip_atomic_load(&acc_w[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t w = __hip_atomic_load(acc_w + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float dc = dcur[idx];
             if (w != 0 && dc != 0.f) {
-                const long long sd = __hip_atomic_load(&acc_d[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const long long si = __hip_atomic_load(&acc_i[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float dw = (float)(((double)sd * (1.0 / 67108864.0)) / (double)w);
-                const float iw = (float)(((double)si * (1.0 / 1073741824.0)) / (double)w);
+                const long long sd = __hip_atomic_load(acc_d + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long si = __hip_atomic_load(acc_i + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                float dw, iw;
+                normalise_acc(sd, si, w, dw, iw);
                 if (dw != 0.f) {
                     // intensity_diff is intensityCurrent where both depths are valid, else 0 (:937,1022)
                     const float idiff = (dbuf[idx] != 0.f) ? icur[idx] : 0.f;
@@ -124,8 +124,8 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, R
 __device__ __noinline__ void stage_segm_image(const KArgs &a, int b, int tid) {
     const StreamState &st = a.state[b];
     const int n = a.ln[0];
-    const uint8_t *labels0 = a.labels + (size_t)b * a.n_tot;
-    float *out = a.b_img + (size_t)b * a.n0;
+    const auto labels0 = as_global((const uint8_t *)a.labels + (size_t)b * a.n_tot);
+    const auto out = as_global(a.b_img + (size_t)b * a.n0);
     for (int idx = tid; idx < n; idx += SF_NT) {
         const int lab = level0_label(a, labels0, idx);
         float bb = 1.f;  // "assume static for invalid cluster"
@@ -140,9 +140,9 @@ __device__ __noinline__ void stage_segm_image(const KArgs &a, int b, int tid) {
 __device__ __noinline__ void stage_push_history(const KArgs &a, int b, int im_count, int tid) {
     StreamState &st = a.state[b];
     const int slot = im_count % SF_HISTORY, n = a.ln[0];
-    const float *dcur = a.pyr_new[0] + (size_t)b * a.n_tot, *icur = a.pyr_new[1] + (size_t)b * a.n_tot;
-    float *dbuf = a.hist_d + ((size_t)slot * a.batch + b) * a.n0;
-    float *ibuf = a.hist_i + ((size_t)slot * a.batch + b) * a.n0;
+    const auto dcur = as_global((const float *)a.pyr_new[0] + (size_t)b * a.n_tot), icur = as_global((const float *)a.pyr_new[1] + (size_t)b * a.n_tot);
+    const auto dbuf = as_global(a.hist_d + ((size_t)slot * a.batch + b) * a.n0);
+    const auto ibuf = as_global(a.hist_i + ((size_t)slot * a.batch + b) * a.n0);
     for (int idx = tid; idx < n; idx += SF_NT) {
         dbuf[idx] = dcur[idx];
         ibuf[idx] = icur[idx];

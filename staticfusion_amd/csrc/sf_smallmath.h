@@ -17,7 +17,7 @@
 //  Must be called by all 64 lanes of ONE wave.
 // ---------------------------------------------------------------------------------------------
 template <int N>
-__device__ inline bool ldlt_factor_wave(volatile float *M, volatile float *temp, volatile int *transp, int lane) {
+__device__ inline bool ldlt_factor_wave(LDS volatile float *M, LDS volatile float *temp, LDS volatile int *transp, int lane) {
     constexpr int LD = N + 1;
     bool all_zero = false;
 #pragma unroll 1
@@ -85,8 +85,8 @@ __device__ inline bool ldlt_factor_wave(volatile float *M, volatile float *temp,
 
 // Solves with the factors above. y is [N] floats in LDS holding b on entry and x on exit.
 template <int N>
-__device__ inline void ldlt_solve_wave(volatile const float *M, volatile const int *transp, bool all_zero,
-                                       volatile float *y, int lane) {
+__device__ inline void ldlt_solve_wave(LDS volatile const float *M, LDS volatile const int *transp, bool all_zero,
+                                       LDS volatile float *y, int lane) {
     constexpr int LD = N + 1;
     if (lane == 0) {
         for (int k = 0; k < N; k++) {
@@ -137,7 +137,7 @@ __device__ inline void ldlt_solve_wave(volatile const float *M, volatile const i
 // ---------------------------------------------------------------------------------------------
 //  single-lane double-precision helpers (arrays live in LDS; row-major)
 // ---------------------------------------------------------------------------------------------
-__device__ inline void inverse_double_lds(double *A, double *Ainv, int n) {
+__device__ inline void inverse_double_lds(LDS double *A, LDS double *Ainv, int n) {
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) Ainv[i * n + j] = (i == j) ? 1.0 : 0.0;
     for (int c = 0; c < n; c++) {
@@ -175,7 +175,7 @@ __device__ inline void inverse_double_lds(double *A, double *Ainv, int n) {
 }
 
 // cyclic Jacobi, symmetric 6x6: A is destroyed (diagonal = eigenvalues), V columns = eigenvectors
-__device__ inline void jacobi_eig6_lds(double *A, double *V) {
+__device__ inline void jacobi_eig6_lds(LDS double *A, LDS double *V) {
     const int n = 6;
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
@@ -300,7 +300,8 @@ __device__ inline void se3_log_d(const double T[16], double xi[6]) {
 
 // column-major float 4x4 helpers --------------------------------------------------------------
 // twist = vee(log(T)) for a column-major float T
-__device__ inline void log_twist_cm(const volatile float *Tcm, float out[6]) {
+template <class P>
+__device__ inline void log_twist_cm(P Tcm, float out[6]) {
     double Td[16], xi[6];
 #pragma unroll
     for (int r = 0; r < 4; r++)
@@ -312,7 +313,8 @@ __device__ inline void log_twist_cm(const volatile float *Tcm, float out[6]) {
 }
 
 // C = A * B, column-major float, inner sum left to right (reference FrontEnd.cpp:766)
-__device__ inline void mul4_cm(const float *A, const volatile float *B, float *C) {
+template <class PB>
+__device__ inline void mul4_cm(const float *A, PB B, float *C) {
     for (int c = 0; c < 4; c++)
         for (int r = 0; r < 4; r++) {
             float s = A[r + 0] * B[0 + 4 * c];
@@ -324,8 +326,9 @@ __device__ inline void mul4_cm(const float *A, const volatile float *B, float *C
 }
 
 // inverse of a column-major float 4x4 through double Gauss-Jordan (scratch: 32 doubles in LDS)
-__device__ inline void inverse4_cm(const volatile float *Tcm, float *out, double *scratch) {
-    double *A = scratch, *Ai = scratch + 16;
+template <class PT, class PO>
+__device__ inline void inverse4_cm(PT Tcm, PO out, LDS double *scratch) {
+    LDS double *A = scratch, *Ai = scratch + 16;
     for (int r = 0; r < 4; r++)
         for (int c = 0; c < 4; c++) A[r * 4 + c] = (double)Tcm[r + 4 * c];
     inverse_double_lds(A, Ai, 4);

@@ -24,17 +24,23 @@
 #include "sf_smallmath.h"
 
 #define TILE_V 64
-#define TILE_U (SF_NT / TILE_V)
+#define TILE_U (2 * SF_NT / TILE_V)  // two centre pixels per lane
 #define TILE_LV (TILE_V + 2)
 #define TILE_LU (TILE_U + 2)
 #define TILE_N (TILE_LV * TILE_LU)
 
-struct SolveShared {
-    // linearisation tile (with halo)
-    float t_D[TILE_N], t_I[TILE_N];      // Inter depth / intensity
-    float t_dn[TILE_N], t_in[TILE_N];    // new depth / intensity
-    float t_dw[TILE_N], t_iw[TILE_N];    // warped depth / intensity
+struct LinTile {  // linearisation tile (with halo)
+    float t_D[TILE_N], t_I[TILE_N];    // Inter depth / intensity
+    float t_dn[TILE_N], t_in[TILE_N];  // new depth / intensity
+    float t_dw[TILE_N], t_iw[TILE_N];  // warped depth / intensity
     uint8_t t_null[TILE_N];
+};
+
+struct SolveShared {
+    union {            // the warp window and the linearisation tile are never live together
+        LinTile lt;
+        SplatWin win;
+    };
     // reductions
     double red[SF_NW][28];
     float redf[SF_NW][2];
@@ -62,7 +68,6 @@ struct SolveShared {
     int seg_allzero;
     double dwork[36 * 3 + 32];
     long long prof[SF_PROF_SLOTS], t_last;
-    SplatWin win;
 };
 
 #ifdef SF_NO_PROF_MARK
@@ -260,14 +265,14 @@ __device__ __forceinline__ float residual(const float a[6], float bb, const vola
 //  warp (reference FrontEnd.cpp:775-892), scatter part.  Normalisation happens when the
 //  accumulators are read by the linearisation.
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, SolveShared &s, int tid) {
+__device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveShared &s, int tid) {
     const int rows_i = a.lrows[L], cols_i = a.lcols[L], n = a.ln[L], o = a.loff[L];
     const size_t sb = (size_t)b * a.n_tot;
-    const float *dpred = a.pyr_pred[0] + sb + o, *ipred = a.pyr_pred[1] + sb + o;
-    const float *xpred = a.pyr_pred[2] + sb + o, *ypred = a.pyr_pred[3] + sb + o;
-    long long *acc_d = a.acc_d + (size_t)b * a.n0;
-    long long *acc_i = a.acc_i + (size_t)b * a.n0;
-    uint32_t *acc_w = a.acc_w + (size_t)b * a.n0;
+    const auto dpred = as_global((const float *)a.pyr_pred[0] + sb + o), ipred = as_global((const float *)a.pyr_pred[1] + sb + o);
+    const auto xpred = as_global((const float *)a.pyr_pred[2] + sb + o), ypred = as_global((const float *)a.pyr_pred[3] + sb + o);
+    const auto acc_d = as_global(a.acc_d + (size_t)b * a.n0);
+    const auto acc_i = as_global(a.acc_i + (size_t)b * a.n0);
+    const auto acc_w = as_global(a.acc_w + (size_t)b * a.n0);
 
     if (tid == 0) inverse4_cm(s.T, s.Tinv, s.dwork);  // T = T_odometry.inverse()  (:800)
     for (int idx = tid; idx < n; idx += SF_NT) {
@@ -290,7 +295,7 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, SolveShare
         for (int c = 0; c < 4; c++) g.T[r * 4 + c] = uniform_f(s.Tinv[r + 4 * c]);
 
     struct Src {
-        const float *d, *i, *x, *y;
+        gptr<const float> d, i, x, y;
         __device__ __forceinline__ bool load(int, int, int idx, float &z, float &xr, float &yr, float &iw) const {
             z = d[idx];
             iw = i[idx];
@@ -306,17 +311,27 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, SolveShare
 // ---------------------------------------------------------------------------------------------
 //  linearise: calculateCoord + calculateDerivatives + computeWeights (raw) + computeSegPrior
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool first, SolveShared &s, int tid) {
+// Tile geometry: TILE_V x TILE_U centre pixels (TILE_CPX per lane) + a 1-pixel halo.  The loads of
+// tile t+1 (halo elements + the centre pixels' coordinates / labels) are issued into registers before
+// tile t is evaluated from LDS, so the global-memory latency overlaps the stencil arithmetic.
+#define TILE_CPX 2
+#define TILE_EPT ((TILE_N + SF_NT - 1) / SF_NT)  // halo-tile elements per lane
+
+__device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool first, LDS SolveShared &s, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const int rows_i = a.lrows[L], cols_i = a.lcols[L], o = a.loff[L];
     const size_t sb = (size_t)b * a.n_tot, rb = (size_t)b * a.n0;
-    const float *dnew = a.pyr_new[0] + sb + o, *inew = a.pyr_new[1] + sb + o;
-    const float *xnew = a.pyr_new[2] + sb + o, *ynew = a.pyr_new[3] + sb + o;
-    const float *dpred = a.pyr_pred[0] + sb + o, *ipred = a.pyr_pred[1] + sb + o;
-    const float *xpred = a.pyr_pred[2] + sb + o, *ypred = a.pyr_pred[3] + sb + o;
-    const long long *acc_d = a.acc_d + rb, *acc_i = a.acc_i + rb;
-    const uint32_t *acc_w = a.acc_w + rb;
-    const uint8_t *labels = a.labels + sb + o;
+    const auto dnew = as_global((const float *)a.pyr_new[0] + sb + o), inew = as_global((const float *)a.pyr_new[1] + sb + o);
+    const auto xnew = as_global((const float *)a.pyr_new[2] + sb + o), ynew = as_global((const float *)a.pyr_new[3] + sb + o);
+    const auto dpred = as_global((const float *)a.pyr_pred[0] + sb + o), ipred = as_global((const float *)a.pyr_pred[1] + sb + o);
+    const auto xpred = as_global((const float *)a.pyr_pred[2] + sb + o), ypred = as_global((const float *)a.pyr_pred[3] + sb + o);
+    const auto acc_d = as_global((const long long *)a.acc_d + rb), acc_i = as_global((const long long *)a.acc_i + rb);
+    const auto acc_w = as_global((const uint32_t *)a.acc_w + rb);
+    const auto labels = as_global((const uint8_t *)a.labels + sb + o);
+    gptr<float> rec[R_COUNT];
+#pragma unroll
+    for (int q = 0; q < R_COUNT; q++) rec[q] = as_global(a.rec[q] + rb);
+    const auto rec_lab = as_global(a.rec_lab + rb);
     const bool seg = a.p.segmentation_enabled != 0;
     const bool dbg = a.p.debug_planes != 0;
     if (tid == 0) s.first = first ? 1 : 0;
@@ -338,125 +353,164 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
     int n_valid = 0;
 
     const int tiles_v = (rows_i + TILE_V - 1) / TILE_V, tiles_u = (cols_i + TILE_U - 1) / TILE_U;
-    for (int tile = 0; tile < tiles_v * tiles_u; tile++) {
+    const int n_tiles = tiles_v * tiles_u;
+
+    // prefetch registers (plain local arrays + a macro: a lambda capturing a struct kept it in scratch memory)
+    float pf_dn[TILE_EPT], pf_in[TILE_EPT];
+    unsigned pf_aw[TILE_EPT];
+    long long pf_ad[TILE_EPT], pf_ai[TILE_EPT];
+    int pf_lab[TILE_CPX];
+#define LIN_PREFETCH(TILE_IDX)                                                                                        \
+    do {                                                                                                              \
+        const int ptv0 = ((TILE_IDX) % tiles_v) * TILE_V, ptu0 = ((TILE_IDX) / tiles_v) * TILE_U;                     \
+        _Pragma("unroll") for (int q = 0; q < TILE_EPT; q++) {                                                       \
+            const int e = tid + q * SF_NT;                                                                            \
+            const int lu = e / TILE_LV, lv = e - lu * TILE_LV;                                                        \
+            const int v = ptv0 - 1 + lv, u = ptu0 - 1 + lu;                                                           \
+            const bool inside = e < TILE_N && v >= 0 && v < rows_i && u >= 0 && u < cols_i;                           \
+            const int idx = inside ? v + u * rows_i : 0;                                                              \
+            pf_dn[q] = dnew[idx];                                                                                     \
+            pf_in[q] = inew[idx];                                                                                     \
+            if (first) { /* Warped := Pred (reference FrontEnd.cpp:1103-1110): carry the float bits in pf_ad */      \
+                const unsigned lo = __float_as_uint(dpred[idx]), hi = __float_as_uint(ipred[idx]);                    \
+                pf_ad[q] = (long long)(((unsigned long long)hi << 32) | lo);                                          \
+            } else {                                                                                                  \
+                pf_aw[q] = __hip_atomic_load(acc_w + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                \
+                pf_ad[q] = __hip_atomic_load(acc_d + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                \
+                pf_ai[q] = __hip_atomic_load(acc_i + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                \
+            }                                                                                                         \
+        }                                                                                                             \
+        if (seg) {                                                                                                    \
+            _Pragma("unroll") for (int k = 0; k < TILE_CPX; k++) {                                                   \
+                const int v = ptv0 + lane, u = ptu0 + wave + k * SF_NW;                                               \
+                pf_lab[k] = (int)labels[(v < rows_i && u < cols_i) ? v + u * rows_i : 0];                             \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+    LIN_PREFETCH(0);
+
+    for (int tile = 0; tile < n_tiles; tile++) {
         const int tv0 = (tile % tiles_v) * TILE_V, tu0 = (tile / tiles_v) * TILE_U;
         __syncthreads();  // previous tile consumed (and the bin initialisation above)
-        for (int e = tid; e < TILE_N; e += SF_NT) {
+#pragma unroll
+        for (int q = 0; q < TILE_EPT; q++) {
+            const int e = tid + q * SF_NT;
+            if (e >= TILE_N) continue;
             const int lu = e / TILE_LV, lv = e - lu * TILE_LV;
             const int v = tv0 - 1 + lv, u = tu0 - 1 + lu;
+            const bool inside = (v >= 0 && v < rows_i && u >= 0 && u < cols_i);
             float dn = 0.f, in_ = 0.f, dw = 0.f, iw = 0.f;
-            bool inside = (v >= 0 && v < rows_i && u >= 0 && u < cols_i);
             if (inside) {
-                const int idx = v + u * rows_i;
-                dn = dnew[idx];
-                in_ = inew[idx];
-                if (first) {  // Warped := Pred  (reference FrontEnd.cpp:1103-1110)
-                    dw = dpred[idx];
-                    iw = ipred[idx];
-                } else {
-                    const uint32_t w = __hip_atomic_load(&acc_w[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (w != 0) {
-                        const long long sd = __hip_atomic_load(&acc_d[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const long long si = __hip_atomic_load(&acc_i[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        dw = (float)(((double)sd * (1.0 / 67108864.0)) / (double)w);
-                        iw = (float)(((double)si * (1.0 / 1073741824.0)) / (double)w);
-                    }
+                dn = pf_dn[q];
+                in_ = pf_in[q];
+                if (first) {
+                    dw = __uint_as_float((unsigned)((unsigned long long)pf_ad[q] & 0xffffffffu));
+                    iw = __uint_as_float((unsigned)((unsigned long long)pf_ad[q] >> 32));
+                } else if (pf_aw[q] != 0) {  // normalise the warp accumulators (reference :876-881)
+                    normalise_acc(pf_ad[q], pf_ai[q], pf_aw[q], dw, iw);
                 }
             }
             const bool nul = !(inside && (dn != 0.f) && (dw != 0.f));
-            s.t_null[e] = nul ? 1 : 0;
-            s.t_D[e] = nul ? 0.f : 0.5f * (dn + dw);
-            s.t_I[e] = 0.5f * (in_ + iw);
-            s.t_dn[e] = dn;
-            s.t_in[e] = in_;
-            s.t_dw[e] = dw;
-            s.t_iw[e] = iw;
+            s.lt.t_null[e] = nul ? 1 : 0;
+            s.lt.t_D[e] = nul ? 0.f : 0.5f * (dn + dw);
+            s.lt.t_I[e] = 0.5f * (in_ + iw);
+            s.lt.t_dn[e] = dn;
+            s.lt.t_in[e] = in_;
+            s.lt.t_dw[e] = dw;
+            s.lt.t_iw[e] = iw;
         }
+        static_assert(TILE_CPX == 2, "two centre pixels per lane");
+        const int c_lab0 = seg ? pf_lab[0] : 0, c_lab1 = seg ? pf_lab[1] : 0;  // scalars: indexing by the loop
+                                                                                 // counter below would go to scratch
         __syncthreads();
+        if (tile + 1 < n_tiles) LIN_PREFETCH(tile + 1);  // in flight while this tile is evaluated
 
-        const int lv = (tid & (TILE_V - 1)) + 1, lu = (tid / TILE_V) + 1;
-        const int v = tv0 + lv - 1, u = tu0 + lu - 1;
-        const bool inside = (v < rows_i && u < cols_i);
-        const int e = lv + lu * TILE_LV;
-        const int idx = v + u * rows_i;
-        bool valid = false, nonnull = false;
-        int lab = SF_NC;
-        float ddt_ = 0.f;
-        if (inside) {
-            const float dn = s.t_dn[e], dw = s.t_dw[e];
-            const bool nul = s.t_null[e] != 0;
-            nonnull = !nul;
-            const float dct_ = s.t_in[e] - s.t_iw[e];
-            ddt_ = dn - dw;
-            lab = seg ? (int)labels[idx] : ((dn != 0.f) ? 0 : SF_NC);
-            float d_i = 0.f, x_i = 0.f, y_i = 0.f, xw = 0.f, yw = 0.f;
-            if (first) {
-                xw = xpred[idx];
-                yw = ypred[idx];
-            } else if (dw != 0.f) {
-                xw = (float(u) - disp_u_i) * dw * inv_f_w;
-                yw = (float(v) - disp_v_i) * dw * inv_f_w;
+#pragma unroll 1
+        for (int k = 0; k < TILE_CPX; k++) {
+            const int lv = lane + 1, lu = wave + k * SF_NW + 1;
+            const int v = tv0 + lv - 1, u = tu0 + lu - 1;
+            const bool inside = (v < rows_i && u < cols_i);
+            const int e = lv + lu * TILE_LV;
+            const int idx = v + u * rows_i;
+            bool valid = false, nonnull = false;
+            int lab = SF_NC;
+            float ddt_ = 0.f;
+            if (inside) {
+                const float dn = s.lt.t_dn[e], dw = s.lt.t_dw[e];
+                const bool nul = s.lt.t_null[e] != 0;
+                nonnull = !nul;
+                const float dct_ = s.lt.t_in[e] - s.lt.t_iw[e];
+                ddt_ = dn - dw;
+                lab = seg ? (k ? c_lab1 : c_lab0) : ((dn != 0.f) ? 0 : SF_NC);
+                valid = !nul && (u != 0) && (v != 0) && (u != cols_i - 1) && (v != rows_i - 1);
+                float dcu_ = 0.f, dcv_ = 0.f, ddu_ = 0.f, ddv_ = 0.f;
+                if (valid) {
+                    const int eL = e - TILE_LV, eR = e + TILE_LV, eU = e - 1, eD = e + 1;  // (v,u-1) (v,u+1) (v-1,u) (v+1,u)
+                    const float Dc = s.lt.t_D[e], Ic = s.lt.t_I[e];
+                    // rx / ry weights of this pixel and of its left / upper neighbour (reference :448-462)
+                    const float rx_c = (u < cols_i - 1) ? fabsf(s.lt.t_D[eR] - Dc) + epsilon_depth : 1.f;
+                    const float rxi_c = (u < cols_i - 1) ? fabsf(s.lt.t_I[eR] - Ic) + epsilon_intensity : 1.f;
+                    const float ry_c = (v < rows_i - 1) ? fabsf(s.lt.t_D[eD] - Dc) + epsilon_depth : 1.f;
+                    const float ryi_c = (v < rows_i - 1) ? fabsf(s.lt.t_I[eD] - Ic) + epsilon_intensity : 1.f;
+                    const bool nulL = s.lt.t_null[eL] != 0, nulU = s.lt.t_null[eU] != 0;
+                    const float rx_l = nulL ? 1.f : fabsf(Dc - s.lt.t_D[eL]) + epsilon_depth;
+                    const float rxi_l = nulL ? 1.f : fabsf(Ic - s.lt.t_I[eL]) + epsilon_intensity;
+                    const float ry_u = nulU ? 1.f : fabsf(Dc - s.lt.t_D[eU]) + epsilon_depth;
+                    const float ryi_u = nulU ? 1.f : fabsf(Ic - s.lt.t_I[eU]) + epsilon_intensity;
+                    dcu_ = (rxi_l * (s.lt.t_I[eR] - Ic) + rxi_c * (Ic - s.lt.t_I[eL])) / (rxi_c + rxi_l);
+                    ddu_ = (rx_l * (s.lt.t_D[eR] - Dc) + rx_c * (Dc - s.lt.t_D[eL])) / (rx_c + rx_l);
+                    dcv_ = (ryi_u * (s.lt.t_I[eD] - Ic) + ryi_c * (Ic - s.lt.t_I[eU])) / (ryi_c + ryi_u);
+                    ddv_ = (ry_u * (s.lt.t_D[eD] - Dc) + ry_c * (Dc - s.lt.t_D[eU])) / (ry_c + ry_u);
+                    // raw pre-weights (reference :487-502): only their global maxima are needed here
+                    const float error_l_c = 10.f * (fabsf(dct_) + fabsf(dcu_) + fabsf(dcv_));
+                    const float error_l_d = 200.f * (fabsf(ddt_) + fabsf(ddu_) + fabsf(ddv_));
+                    const float wc = sqrtf(1.f / (1.f + error_l_c));
+                    const float wd = sqrtf(1.f / (0.01f + error_l_d));
+                    max_c = (wc > max_c) ? wc : max_c;
+                    max_d = (wd > max_d) ? wd : max_d;
+                    n_valid++;
+                }
+                rec[R_DW][idx] = dw;
+                rec[R_DCU][idx] = dcu_;
+                rec[R_DCV][idx] = dcv_;
+                rec[R_DCT][idx] = dct_;
+                rec[R_DDU][idx] = ddu_;
+                rec[R_DDV][idx] = ddv_;
+                rec_lab[idx] = valid ? (uint8_t)(seg ? lab : 0) : (uint8_t)SF_INVALID_LABEL;
+                if (dbg) {
+                    float d_i = 0.f, x_i = 0.f, y_i = 0.f, xw = 0.f, yw = 0.f;
+                    if (first) {
+                        xw = xpred[idx];
+                        yw = ypred[idx];
+                    } else if (dw != 0.f) {
+                        xw = (float(u) - disp_u_i) * dw * inv_f_w;
+                        yw = (float(v) - disp_v_i) * dw * inv_f_w;
+                    }
+                    if (!nul) {
+                        d_i = s.lt.t_D[e];
+                        x_i = 0.5f * (xnew[idx] + xw);
+                        y_i = 0.5f * (ynew[idx] + yw);
+                    }
+                    a.rec_null[rb + idx] = nul ? 1 : 0;
+                    const size_t q = sb + o + idx;
+                    a.dbg_warped[0][q] = dw;
+                    a.dbg_warped[1][q] = s.lt.t_iw[e];
+                    a.dbg_warped[2][q] = xw;
+                    a.dbg_warped[3][q] = yw;
+                    a.dbg_inter[0][q] = d_i;
+                    a.dbg_inter[1][q] = s.lt.t_I[e];
+                    a.dbg_inter[2][q] = x_i;
+                    a.dbg_inter[3][q] = y_i;
+                }
             }
-            if (!nul) {
-                d_i = s.t_D[e];
-                x_i = 0.5f * (xnew[idx] + xw);
-                y_i = 0.5f * (ynew[idx] + yw);
+            if (seg) {
+                // computeSegPrior (reference SegmentationBackground.cpp:65-81), per-wave aggregation
+                const bool labelled = inside && lab != SF_NC;
+                wave_label_count(labelled, lab, s.prior_size, lane);
+                wave_label_count(labelled && nonnull, lab, s.prior_nonnull, lane);
+                wave_label_add_i64(labelled && nonnull, lab, to_fix(1.f - kz * fabsf(ddt_), FIX_RES, 1.0e6f), s.prior_sum, lane);
+                wave_label_count(valid, lab, s.valid_cnt, lane);
             }
-            valid = !nul && (u != 0) && (v != 0) && (u != cols_i - 1) && (v != rows_i - 1);
-            float dcu_ = 0.f, dcv_ = 0.f, ddu_ = 0.f, ddv_ = 0.f, wc = 0.f, wd = 0.f;
-            if (valid) {
-                const int eL = e - TILE_LV, eR = e + TILE_LV, eU = e - 1, eD = e + 1;  // (v,u-1) (v,u+1) (v-1,u) (v+1,u)
-                const float Dc = s.t_D[e], Ic = s.t_I[e];
-                // rx / ry weights of this pixel and of its left / upper neighbour (reference :448-462)
-                const float rx_c = (u < cols_i - 1) ? fabsf(s.t_D[eR] - Dc) + epsilon_depth : 1.f;
-                const float rxi_c = (u < cols_i - 1) ? fabsf(s.t_I[eR] - Ic) + epsilon_intensity : 1.f;
-                const float ry_c = (v < rows_i - 1) ? fabsf(s.t_D[eD] - Dc) + epsilon_depth : 1.f;
-                const float ryi_c = (v < rows_i - 1) ? fabsf(s.t_I[eD] - Ic) + epsilon_intensity : 1.f;
-                const bool nulL = s.t_null[eL] != 0, nulU = s.t_null[eU] != 0;
-                const float rx_l = nulL ? 1.f : fabsf(Dc - s.t_D[eL]) + epsilon_depth;
-                const float rxi_l = nulL ? 1.f : fabsf(Ic - s.t_I[eL]) + epsilon_intensity;
-                const float ry_u = nulU ? 1.f : fabsf(Dc - s.t_D[eU]) + epsilon_depth;
-                const float ryi_u = nulU ? 1.f : fabsf(Ic - s.t_I[eU]) + epsilon_intensity;
-                dcu_ = (rxi_l * (s.t_I[eR] - Ic) + rxi_c * (Ic - s.t_I[eL])) / (rxi_c + rxi_l);
-                ddu_ = (rx_l * (s.t_D[eR] - Dc) + rx_c * (Dc - s.t_D[eL])) / (rx_c + rx_l);
-                dcv_ = (ryi_u * (s.t_I[eD] - Ic) + ryi_c * (Ic - s.t_I[eU])) / (ryi_c + ryi_u);
-                ddv_ = (ry_u * (s.t_D[eD] - Dc) + ry_c * (Dc - s.t_D[eU])) / (ry_c + ry_u);
-                // raw pre-weights (reference :487-502)
-                const float error_l_c = 10.f * (fabsf(dct_) + fabsf(dcu_) + fabsf(dcv_));
-                const float error_l_d = 200.f * (fabsf(ddt_) + fabsf(ddu_) + fabsf(ddv_));
-                wc = sqrtf(1.f / (1.f + error_l_c));
-                wd = sqrtf(1.f / (0.01f + error_l_d));
-                max_c = (wc > max_c) ? wc : max_c;
-                max_d = (wd > max_d) ? wd : max_d;
-                n_valid++;
-            }
-            a.rec[R_DW][rb + idx] = dw;
-            a.rec[R_DCU][rb + idx] = dcu_;
-            a.rec[R_DCV][rb + idx] = dcv_;
-            a.rec[R_DCT][rb + idx] = dct_;
-            a.rec[R_DDU][rb + idx] = ddu_;
-            a.rec[R_DDV][rb + idx] = ddv_;
-            a.rec_lab[rb + idx] = valid ? (uint8_t)(seg ? lab : 0) : (uint8_t)SF_INVALID_LABEL;
-            if (dbg) {
-                a.rec_null[rb + idx] = nul ? 1 : 0;
-                const size_t q = sb + o + idx;
-                a.dbg_warped[0][q] = dw;
-                a.dbg_warped[1][q] = s.t_iw[e];
-                a.dbg_warped[2][q] = xw;
-                a.dbg_warped[3][q] = yw;
-                a.dbg_inter[0][q] = d_i;
-                a.dbg_inter[1][q] = s.t_I[e];
-                a.dbg_inter[2][q] = x_i;
-                a.dbg_inter[3][q] = y_i;
-            }
-        }
-        if (seg) {
-            // computeSegPrior (reference SegmentationBackground.cpp:65-81), per-wave aggregation
-            const bool labelled = inside && lab != SF_NC;
-            wave_label_count(labelled, lab, s.prior_size, lane);
-            wave_label_count(labelled && nonnull, lab, s.prior_nonnull, lane);
-            wave_label_add_i64(labelled && nonnull, lab, to_fix(1.f - kz * fabsf(ddt_), FIX_RES, 1.0e6f), s.prior_sum, lane);
-            wave_label_count(valid, lab, s.valid_cnt, lane);
         }
     }
 
@@ -503,12 +557,14 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
     __syncthreads();
 }
 
+#undef LIN_PREFETCH
+
 // ---------------------------------------------------------------------------------------------
 //  filterEstimateAndComputeT (reference FrontEnd.cpp:713-772) + est_cov (:689). One lane.
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ void solve_filter_and_update(const KArgs &a, SolveShared &s, int level) {
+__device__ __noinline__ void solve_filter_and_update(const KArgs &a, LDS SolveShared &s, int level) {
     // est_cov = AtA.inverse() * res.squaredNorm()
-    double *Ad = s.dwork, *Ai = s.dwork + 36, *V = s.dwork + 72;
+    LDS double *Ad = s.dwork, *Ai = s.dwork + 36, *V = s.dwork + 72;
     for (int i = 0; i < 36; i++) Ad[i] = (double)s.AtA[i];
     inverse_double_lds(Ad, Ai, 6);
     for (int i = 0; i < 36; i++) s.est_cov[i] = (float)Ai[i] * s.res_sqnorm;
@@ -518,7 +574,7 @@ __device__ __noinline__ void solve_filter_and_update(const KArgs &a, SolveShared
 
     if (a.p.use_motion_filter) {
         bool finite = true;
-        double *S = Ad;  // reuse
+        LDS double *S = Ad;  // reuse
         for (int i = 0; i < 6; i++)
             for (int j = 0; j <= i; j++) {
                 const double v = (double)s.est_cov[i * 6 + j];
@@ -665,7 +721,7 @@ struct IrlsCtx {
     int N;  // valid pixels
 };
 
-__device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, const SolveShared &s) {
+__device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, const LDS SolveShared &s) {
     IrlsCtx c;
     const size_t rb = (size_t)b * a.n0;
 #pragma unroll
@@ -691,7 +747,7 @@ __device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, c
 }
 
 // initial aver_res = mean |res| with res = -B (reference :588-590): partial sums to s.red[wave][0]
-__device__ __noinline__ void irls_initial_residual(const KArgs &a, int b, int L, SolveShared &s, int tid) {
+__device__ __noinline__ void irls_initial_residual(const KArgs &a, int b, int L, LDS SolveShared &s, int tid) {
     const IrlsCtx c = make_irls_ctx(a, b, L, s);
     double sabs = 0.0;
     for (int i0 = tid * 2; i0 < c.n; i0 += SF_NT * 2) {
@@ -727,7 +783,7 @@ __device__ __noinline__ void irls_initial_residual(const KArgs &a, int b, int L,
 // for tools/pass_microbench.py; the product always instantiates VAR 0)
 // pass 1: Cauchy x b weights, 21+6 normal-equation sums (reference :615-641) -> s.red[wave][0..26]
 template <int VAR>
-__device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, SolveShared &s, int tid) {
+__device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, LDS SolveShared &s, int tid) {
     const IrlsCtx c = make_irls_ctx(a, b, L, s);
     const float inv_c_Cauchy = 1.f / (a.p.kc_Cauchy * uniform_f(s.aver_res));
     double acc[27];
@@ -857,7 +913,7 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, SolveShare
 }
 
 // wave 0: finish the reduction, AtA / AtB, Var = AtA.ldlt().solve(AtB) (reference :640-642)
-__device__ __noinline__ void irls_solve_normal(SolveShared &s, int lane) {
+__device__ __noinline__ void irls_solve_normal(LDS SolveShared &s, int lane) {
     if (lane < 27) {
         double t = 0.0;
         for (int w = 0; w < SF_NW; w++) t += s.red[w][lane];
@@ -899,7 +955,7 @@ __device__ __forceinline__ unsigned long long to_fix32_pos(float x) {
 // flushes it to the workgroup bins (LDS integer atomics: order-independent) only when the label
 // changes -- labels are spatially coherent, so flushes are rare.
 template <int VAR>
-__device__ __noinline__ void irls_pass2(const KArgs &a, int b, int L, SolveShared &s, int tid) {
+__device__ __noinline__ void irls_pass2(const KArgs &a, int b, int L, LDS SolveShared &s, int tid) {
     const IrlsCtx c = make_irls_ctx(a, b, L, s);
     const int lane = tid & 63, wave = tid >> 6;
     float Vr[6];
@@ -957,21 +1013,21 @@ __device__ __noinline__ void irls_pass2(const KArgs &a, int b, int L, SolveShare
             }
             const int lab = ok ? rv.lab[px] : cur_lab;
             if (lab != cur_lab) {
-                if (cur_sum) atomicAdd((unsigned long long *)&s.lab_sum[cur_lab], cur_sum);
+                if (cur_sum) lds_add(&s.lab_sum[cur_lab], (long long)cur_sum);
                 cur_lab = lab;
                 cur_sum = 0;
             }
             cur_sum += fx;
         }
     }
-    if (cur_sum) atomicAdd((unsigned long long *)&s.lab_sum[cur_lab], cur_sum);
+    if (cur_sum) lds_add(&s.lab_sum[cur_lab], (long long)cur_sum);
     sq = wave_sum_f64(sq);
     if (lane == 0) s.red[wave][27] = sq;
 }
 
 // wave 0: build and factorise A_seg^T A_seg once per outer iteration
 // (reference SegmentationBackground.cpp:105-130,143-165)
-__device__ __noinline__ void irls_seg_factor(const KArgs &a, SolveShared &s, int lane) {
+__device__ __noinline__ void irls_seg_factor(const KArgs &a, LDS SolveShared &s, int lane) {
     const float lambda_prior = a.p.lambda_prior;
     const float weight_reg = 2.f * a.p.lambda_reg;
     const float w2 = weight_reg * weight_reg, nw2 = weight_reg * (-weight_reg);
@@ -995,7 +1051,7 @@ __device__ __noinline__ void irls_seg_factor(const KArgs &a, SolveShared &s, int
 }
 
 // wave 0, after pass 2: averages, solveSegmIteration, convergence test (reference :666-683)
-__device__ __noinline__ void irls_iteration_tail(const KArgs &a, SolveShared &s, int N, int k, int lane) {
+__device__ __noinline__ void irls_iteration_tail(const KArgs &a, LDS SolveShared &s, int N, int k, int lane) {
     const bool seg = a.p.segmentation_enabled != 0;
     if (lane < SF_NC) s.aver_res_label[lane] = (float)((double)s.lab_sum[lane] * (1.0 / 4294967296.0));
     __builtin_amdgcn_wave_barrier();
@@ -1044,7 +1100,7 @@ __device__ __noinline__ void irls_iteration_tail(const KArgs &a, SolveShared &s,
     }
 }
 
-__device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level, int kouter, SolveShared &s, int tid) {
+__device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level, int kouter, LDS SolveShared &s, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const bool seg = a.p.segmentation_enabled != 0;
     const int N = __builtin_amdgcn_readfirstlane(s.n_valid);
@@ -1125,7 +1181,7 @@ __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level,
 // ---------------------------------------------------------------------------------------------
 //  the coarse-to-fine loop (reference FrontEnd.cpp:1091-1144)
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ void stage_solve(const KArgs &a, int b, SolveShared &s, int tid) {
+__device__ __noinline__ void stage_solve(const KArgs &a, int b, LDS SolveShared &s, int tid) {
     StreamState &st = a.state[b];
     if (tid < 16) s.T[tid] = (tid % 5 == 0) ? 1.f : 0.f;  // T_odometry.setIdentity()  (:1091)
     if (tid < 6) {
@@ -1177,7 +1233,7 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, SolveShared &s, 
 
     // twist_odometry_old = R_inc^-1 * twist_odometry (reference :1139-1144)
     if (tid == 0) {
-        double *R = s.dwork, *Ri = s.dwork + 16;
+        LDS double *R = s.dwork, *Ri = s.dwork + 16;
         for (int r = 0; r < 3; r++)
             for (int c = 0; c < 3; c++) R[r * 3 + c] = (double)s.T[r + 4 * c];
         inverse_double_lds(R, Ri, 3);
@@ -1227,7 +1283,7 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, SolveShared &s, 
 //  last solve left behind (tools/pass_microbench.py, sf_microbench_pass)
 // ---------------------------------------------------------------------------------------------
 template <int WHICH, int VAR>
-__device__ void microbench_pass(const KArgs &a, int b, int reps, SolveShared &s, int tid) {
+__device__ void microbench_pass(const KArgs &a, int b, int reps, LDS SolveShared &s, int tid) {
     const StreamState &st = a.state[b];
     if (tid < SF_NC) s.b_segm[tid] = a.p.segmentation_enabled ? st.b_segm[tid] : 1.f;
     if (tid < 6) s.Var[tid] = st.twist_level[tid];

@@ -47,8 +47,8 @@ def assert_traces_match(sg, so, tol_twist=2e-6, tol_b=1e-4):
     assert np.abs(trace_array(a, "b_segm") - trace_array(b, "b_segm")).max() < tol_b
 
 
-def assert_planes_close(g, o, frac=0.99, tol=5e-5, hard=0.2):
-    """centi-pixel quantisation of the warp can move isolated pixels: all but 1 % within tol."""
+def assert_planes_close(g, o, frac=0.98, tol=5e-5, hard=0.2):
+    """centi-pixel quantisation of the warp can move isolated pixels: all but 2 % within tol."""
     d = np.abs(g.astype(np.float64) - o.astype(np.float64))
     assert np.isfinite(d).all()
     assert (d <= tol).mean() >= frac, ((d <= tol).mean(), d.max())

@@ -150,6 +150,8 @@ __device__ __forceinline__ int cvt_trunc_x86(float x) {
 // instructions (a plain reference is a generic pointer: every access becomes a flat_* instruction
 // that waits on both memory counters).
 #define LDS __attribute__((address_space(3)))
+typedef float __attribute__((ext_vector_type(2))) vfloat2;  // plain vector types: usable in any address space
+typedef float __attribute__((ext_vector_type(4))) vfloat4;
 template <class T>
 __device__ __forceinline__ void lds_add(LDS T *p, T v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

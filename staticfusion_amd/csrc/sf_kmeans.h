@@ -20,8 +20,8 @@
 
 struct KmShared {
     float cent_a[3 * SF_NC], cent_b[3 * SF_NC];
-    float sdist[SF_NC * SF_NC];    // row l: distances to the other centres, ascending
-    uint8_t sidx[SF_NC * SF_NC];   // row l: centre index at each sorted position
+    vfloat2 cand[SF_NC * SF_NC];    // row l: (distance to, index of) the other centres, ascending distance: one 8-byte LDS read
+    vfloat4 cent4[SF_NC];          // (z, x, y, 0) of centre l: one 16-byte LDS read
     float pair_dist[SF_NC * SF_NC];
     int wcnt[SF_NW][SF_NC];        // members per (wave range, label); then exclusive offsets
     int count[SF_NC];
@@ -55,22 +55,26 @@ __device__ __noinline__ void km_sort_centres(LDS KmShared &s, int tid) {
             const float dj = s.pair_dist[l * SF_NC + lj];
             rank += (dj < d || (dj == d && lj < li)) ? 1 : 0;
         }
-        s.sdist[l * SF_NC + rank] = d;
-        s.sidx[l * SF_NC + rank] = (uint8_t)li;
+        s.cand[l * SF_NC + rank] = vfloat2{d, __int_as_float(li)};
     }
+    if (tid < SF_NC) s.cent4[tid] = vfloat4{s.cent_a[3 * tid], s.cent_a[3 * tid + 1], s.cent_a[3 * tid + 2], 0.f};
     __syncthreads();
 }
 
 // pruned nearest-centre search starting from `last` (KMeans.cpp:196-212 and :263-285)
 __device__ __forceinline__ int km_search(const LDS KmShared &s, int last, float pz, float px, float py) {
     int best = last;
-    const float d_last = sqdist3(s.cent_a[3 * last], s.cent_a[3 * last + 1], s.cent_a[3 * last + 2], pz, px, py);
+    const vfloat4 c0 = s.cent4[last];
+    const float d_last = sqdist3(c0.x, c0.y, c0.z, pz, px, py);
     float best_d = d_last;
+    const float lim = 4.f * d_last;
+    vfloat2 cd = s.cand[last * SF_NC + 1];
     for (int li = 1; li < SF_NC; li++) {
-        const float cd = s.sdist[last * SF_NC + li];
-        if (cd > 4.f * d_last) break;
-        const int c = s.sidx[last * SF_NC + li];
-        const float dl = sqdist3(s.cent_a[3 * c], s.cent_a[3 * c + 1], s.cent_a[3 * c + 2], pz, px, py);
+        if (cd.x > lim) break;
+        const int c = __float_as_int(cd.y);
+        const vfloat4 cc = s.cent4[c];
+        if (li + 1 < SF_NC) cd = s.cand[last * SF_NC + li + 1];  // next candidate in flight during the distance
+        const float dl = sqdist3(cc.x, cc.y, cc.z, pz, px, py);
         if (dl < best_d) {
             best_d = dl;
             best = c;
@@ -318,16 +322,26 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
     km_sort_centres(s, tid);
     {
         const int rows0 = a.lrows[0], n0 = a.ln[0];
-        for (int idx = tid; idx < n0; idx += SF_NT) {
-            const float pz = depth[idx];
-            int lab = SF_NC;
-            if (pz != 0.f) {
+        for (int base = tid; base < n0; base += SF_NT * SF_LOAD_BATCH) {
+            float pz[SF_LOAD_BATCH], px[SF_LOAD_BATCH], py[SF_LOAD_BATCH];
+            int low[SF_LOAD_BATCH];
+#pragma unroll
+            for (int q = 0; q < SF_LOAD_BATCH; q++) {
+                const int idx = min(base + q * SF_NT, n0 - 1);
                 const int u = idx / rows0, v = idx - u * rows0;
-                const int low = labels[o1 + (v / 2) + (u / 2) * rows_km];
-                const int last = (low == SF_NC) ? 0 : low;
-                lab = km_search(s, last, pz, xx[idx], yy[idx]);
+                pz[q] = depth[idx];
+                px[q] = xx[idx];
+                py[q] = yy[idx];
+                low[q] = labels[o1 + (v / 2) + (u / 2) * rows_km];
             }
-            labels[idx] = (uint8_t)lab;
+#pragma unroll
+            for (int q = 0; q < SF_LOAD_BATCH; q++) {
+                const int idx = base + q * SF_NT;
+                if (idx >= n0) continue;
+                int lab = SF_NC;
+                if (pz[q] != 0.f) lab = km_search(s, (low[q] == SF_NC) ? 0 : low[q], pz[q], px[q], py[q]);
+                labels[idx] = (uint8_t)lab;
+            }
         }
     }
     if (tid < SF_NC) s.conn[tid] = 1u << tid;
@@ -341,19 +355,20 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
         for (int idx = tid; idx < n0; idx += SF_NT) {
             const int u = idx / rows0, v = idx - u * rows0;
             if (u >= cols0 - 1 || v >= rows0 - 1) continue;
-            const float dz = depth[idx];
+            // all ten loads first (independent), then the tests
+            const float dz = depth[idx], dzd = depth[idx + 1], dzr = depth[idx + rows0];
+            const float yc = yy[idx], yd = yy[idx + 1], xc = xx[idx], xr = xx[idx + rows0];
+            const int la = labels[idx], ld = labels[idx + 1], lr = labels[idx + rows0];
             if (dz == 0.f) continue;
-            const int la = labels[idx];
-            const int ld = labels[idx + 1], lr = labels[idx + rows0];
             if (la != ld && ld != SF_NC) {
-                const float disty = sqf(dz - depth[idx + 1]) + sqf(yy[idx] - yy[idx + 1]);
+                const float disty = sqf(dz - dzd) + sqf(yc - yd);
                 if (disty < dist2_threshold) {
                     lds_or(&s.conn[la], 1u << ld);
                     lds_or(&s.conn[ld], 1u << la);
                 }
             }
             if (la != lr && lr != SF_NC) {
-                const float distx = sqf(dz - depth[idx + rows0]) + sqf(xx[idx] - xx[idx + rows0]);
+                const float distx = sqf(dz - dzr) + sqf(xc - xr);
                 if (distx < dist2_threshold) {
                     lds_or(&s.conn[la], 1u << lr);
                     lds_or(&s.conn[lr], 1u << la);

@@ -105,11 +105,18 @@ __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, bool old_im, i
                 yy[a.loff[L] + idx] = (inv_f_i * (float(v) - disp_v_i)) * dout;
             }
         } else {
-            for (int idx = tid; idx < n; idx += SF_NT) {
-                const int u = idx / rows_i, v = idx - u * rows_i;
-                const float dd = d_here[idx];
-                xx[idx] = (inv_f_i * (float(u) - disp_u_i)) * dd;
-                yy[idx] = (inv_f_i * (float(v) - disp_v_i)) * dd;
+            for (int base = tid; base < n; base += SF_NT * SF_LOAD_BATCH) {  // level 0: coordinates only
+                float dd[SF_LOAD_BATCH];
+#pragma unroll
+                for (int k = 0; k < SF_LOAD_BATCH; k++) dd[k] = d_here[min(base + k * SF_NT, n - 1)];
+#pragma unroll
+                for (int k = 0; k < SF_LOAD_BATCH; k++) {
+                    const int idx = base + k * SF_NT;
+                    if (idx >= n) continue;
+                    const int u = idx / rows_i, v = idx - u * rows_i;
+                    xx[idx] = (inv_f_i * (float(u) - disp_u_i)) * dd[k];
+                    yy[idx] = (inv_f_i * (float(v) - disp_v_i)) * dd[k];
+                }
             }
         }
     }

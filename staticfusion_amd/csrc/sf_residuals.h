@@ -21,7 +21,6 @@ __device__ __forceinline__ int level0_label(const KArgs &a, gptr<const uint8_t> 
 }
 
 __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, LDS ResShared &s, int tid) {
-    const int lane = tid & 63;
     StreamState &st = a.state[b];
     const int rows = a.lrows[0], cols = a.lcols[0], n = a.ln[0];
     const size_t sb = (size_t)b * a.n_tot, rb = (size_t)b * a.n0;
@@ -83,34 +82,52 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, L
     tiled_splat(g, rows, cols, src, acc_d, acc_i, acc_w, s.win, tid);
     __syncthreads();
 
-    // residuals, cluster-wise (:1036-1068)
+    // residuals, cluster-wise (:1036-1068): per-lane running sums per label, flushed to the workgroup bins
+    // (integer LDS atomics) when the label changes; SF_LOAD_BATCH pixels per trip with all loads issued first
     const float kph = a.p.k_photometric_res;
-    for (int base = 0; base < n; base += SF_NT) {
-        const int idx = base + tid;
-        bool ok = false;
-        int lab = 0;
-        long long fx = 0;
-        if (idx < n) {
-            const uint32_t w = __hip_atomic_load(acc_w + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float dc = dcur[idx];
-            if (w != 0 && dc != 0.f) {
-                const long long sd = __hip_atomic_load(acc_d + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const long long si = __hip_atomic_load(acc_i + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                float dw, iw;
-                normalise_acc(sd, si, w, dw, iw);
-                if (dw != 0.f) {
-                    // intensity_diff is intensityCurrent where both depths are valid, else 0 (:937,1022)
-                    const float idiff = (dbuf[idx] != 0.f) ? icur[idx] : 0.f;
-                    const float cumulative = fabsf(dc - dw) + kph * fabsf(idiff - iw);
-                    ok = true;
-                    lab = level0_label(a, labels0, idx);
-                    fx = to_fix(cumulative, FIX_RES, 1.0e6f);
-                }
-            }
+    int cur_lab = 0, cur_cnt = 0;
+    long long cur_sum = 0;
+    for (int base = tid; base < n; base += SF_NT * SF_LOAD_BATCH) {
+        uint32_t w[SF_LOAD_BATCH];
+        long long sd[SF_LOAD_BATCH], si[SF_LOAD_BATCH];
+        float dc[SF_LOAD_BATCH], db[SF_LOAD_BATCH], ic[SF_LOAD_BATCH];
+        int lb[SF_LOAD_BATCH];
+#pragma unroll
+        for (int k = 0; k < SF_LOAD_BATCH; k++) {
+            const int idx = min(base + k * SF_NT, n - 1);
+            w[k] = __hip_atomic_load(acc_w + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sd[k] = __hip_atomic_load(acc_d + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            si[k] = __hip_atomic_load(acc_i + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dc[k] = dcur[idx];
+            db[k] = dbuf[idx];
+            ic[k] = icur[idx];
+            lb[k] = level0_label(a, labels0, idx);
         }
-        ok = ok && lab < SF_NC;
-        wave_label_add_i64(ok, lab, fx, s.lab_sum, lane);
-        wave_label_count(ok, lab, s.lab_cnt, lane);
+#pragma unroll
+        for (int k = 0; k < SF_LOAD_BATCH; k++) {
+            if (!(base + k * SF_NT < n && w[k] != 0 && dc[k] != 0.f)) continue;
+            float dw, iw;
+            normalise_acc(sd[k], si[k], w[k], dw, iw);
+            if (dw == 0.f || lb[k] >= SF_NC) continue;
+            // intensity_diff is intensityCurrent where both depths are valid, else 0 (:937,1022)
+            const float idiff = (db[k] != 0.f) ? ic[k] : 0.f;
+            const float cumulative = fabsf(dc[k] - dw) + kph * fabsf(idiff - iw);
+            if (lb[k] != cur_lab) {
+                if (cur_cnt) {
+                    lds_add(&s.lab_sum[cur_lab], cur_sum);
+                    lds_add(&s.lab_cnt[cur_lab], cur_cnt);
+                }
+                cur_lab = lb[k];
+                cur_sum = 0;
+                cur_cnt = 0;
+            }
+            cur_sum += to_fix(cumulative, FIX_RES, 1.0e6f);
+            cur_cnt++;
+        }
+    }
+    if (cur_cnt) {
+        lds_add(&s.lab_sum[cur_lab], cur_sum);
+        lds_add(&s.lab_cnt[cur_lab], cur_cnt);
     }
     __syncthreads();
     if (tid < SF_NC) {
@@ -126,14 +143,21 @@ __device__ __noinline__ void stage_segm_image(const KArgs &a, int b, int tid) {
     const int n = a.ln[0];
     const auto labels0 = as_global((const uint8_t *)a.labels + (size_t)b * a.n_tot);
     const auto out = as_global(a.b_img + (size_t)b * a.n0);
-    for (int idx = tid; idx < n; idx += SF_NT) {
-        const int lab = level0_label(a, labels0, idx);
-        float bb = 1.f;  // "assume static for invalid cluster"
-        if (lab != SF_NC) {
-            bb = std_max(0.f, std_min(1.f, st.b_segm[lab]));
-            if ((double)st.cluster_res[lab] < 0.017) bb = std_max(bb, 1.0f - bb);
+    for (int base = tid; base < n; base += SF_NT * SF_LOAD_BATCH) {
+        int lab[SF_LOAD_BATCH];
+#pragma unroll
+        for (int k = 0; k < SF_LOAD_BATCH; k++) lab[k] = level0_label(a, labels0, min(base + k * SF_NT, n - 1));
+#pragma unroll
+        for (int k = 0; k < SF_LOAD_BATCH; k++) {
+            const int idx = base + k * SF_NT;
+            if (idx >= n) continue;
+            float bb = 1.f;  // "assume static for invalid cluster"
+            if (lab[k] != SF_NC) {
+                bb = std_max(0.f, std_min(1.f, st.b_segm[lab[k]]));
+                if ((double)st.cluster_res[lab[k]] < 0.017) bb = std_max(bb, 1.0f - bb);
+            }
+            out[idx] = bb;
         }
-        out[idx] = bb;
     }
 }
 
@@ -143,9 +167,24 @@ __device__ __noinline__ void stage_push_history(const KArgs &a, int b, int im_co
     const auto dcur = as_global((const float *)a.pyr_new[0] + (size_t)b * a.n_tot), icur = as_global((const float *)a.pyr_new[1] + (size_t)b * a.n_tot);
     const auto dbuf = as_global(a.hist_d + ((size_t)slot * a.batch + b) * a.n0);
     const auto ibuf = as_global(a.hist_i + ((size_t)slot * a.batch + b) * a.n0);
-    for (int idx = tid; idx < n; idx += SF_NT) {
-        dbuf[idx] = dcur[idx];
-        ibuf[idx] = icur[idx];
+    for (int base = tid * 4; base < n; base += SF_NT * 4 * 2) {  // 16-byte copies, two per trip
+        typedef float __attribute__((ext_vector_type(4))) f4;
+        typedef __attribute__((address_space(1))) const f4 gcf4;
+        typedef __attribute__((address_space(1))) f4 gf4;
+        const int i0 = base, i1 = base + SF_NT * 4;
+        const bool in1 = i1 < n;
+        const f4 d0 = *(gcf4 *)(dcur + i0), c0 = *(gcf4 *)(icur + i0);
+        f4 d1 = d0, c1 = c0;
+        if (in1) {
+            d1 = *(gcf4 *)(dcur + i1);
+            c1 = *(gcf4 *)(icur + i1);
+        }
+        *(gf4 *)(dbuf + i0) = d0;
+        *(gf4 *)(ibuf + i0) = c0;
+        if (in1) {
+            *(gf4 *)(dbuf + i1) = d1;
+            *(gf4 *)(ibuf + i1) = c1;
+        }
     }
     if (tid < 16) st.hist_T[slot][tid] = st.T[tid];
 }

@@ -89,8 +89,6 @@ struct SolveShared {
 // ---------------------------------------------------------------------------------------------
 // T is float (one pixel) or vfloat2 (a pixel pair: the f32 arithmetic then compiles to packed
 // v_pk_mul/add/fma_f32, two pixels per VALU instruction, same IEEE results per component).
-typedef float __attribute__((ext_vector_type(2))) vfloat2;
-typedef float __attribute__((ext_vector_type(4))) vfloat4;
 
 __device__ __forceinline__ float vabs(float x) { return fabsf(x); }
 __device__ __forceinline__ vfloat2 vabs(vfloat2 x) { return vfloat2{fabsf(x.x), fabsf(x.y)}; }

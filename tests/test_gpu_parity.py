@@ -34,13 +34,13 @@ def solve_both(hip, ora, rows, cols, mk_params, pr, seg_image=True):
     return out
 
 
-def assert_traces_match(sg, so, tol_twist=2e-6, tol_b=1e-4):
+def assert_traces_match(sg, so, tol_twist=2e-6, tol_b=1e-4, rtol_aver=2e-4):
     a, b = sg.stats(), so.stats()
     assert (a.n_outer, a.n_irls, a.kmeans_iters, a.status) == (b.n_outer, b.n_irls, b.kmeans_iters, b.status)
     assert a.pixel_iters == b.pixel_iters
     for f in ("level", "k", "n_valid", "irls_iters"):
         assert np.array_equal(trace_array(a, f), trace_array(b, f)), f
-    assert np.allclose(trace_array(a, "aver_res"), trace_array(b, "aver_res"), rtol=2e-4, atol=1e-7)
+    assert np.allclose(trace_array(a, "aver_res"), trace_array(b, "aver_res"), rtol=rtol_aver, atol=1e-7)
     assert np.abs(trace_array(a, "var") - trace_array(b, "var")).max() < tol_twist
     assert np.abs(trace_array(a, "twist_level") - trace_array(b, "twist_level")).max() < tol_twist
     assert np.abs(trace_array(a, "T") - trace_array(b, "T")).max() < tol_twist
@@ -251,3 +251,39 @@ def test_device_resident_inputs_and_counters(hip, pair):
     assert frames == B and irls == int(n_irls2.sum()) and outer == 3 * B and pix > 0
     for ptr in bufs:
         hiprt.hipFree(ptr)
+
+
+def test_vga_resolution_six_levels(hip, ora):
+    """res_factor 1 of the reference constructor: 480x640, ctf_levels = log2(640/40) + 2 = 6 (maximum size)."""
+    from staticfusion_amd.synth import make_pair
+
+    pr = make_pair(seed=5, sphere=True, out_rows=480, out_cols=640)
+    sg, so = solve_both(hip, ora, 480, 640, lambda a: driver_params(a), pr)
+    assert sg.levels == 6 and sg.level_shape(5) == (15, 20)
+    for L in range(6):
+        assert np.array_equal(sg.labels(L), so.labels(L)), L
+        assert np.array_equal(sg.plane(capi.SET_NEW, capi.CH_DEPTH, L), so.plane(capi.SET_NEW, capi.CH_DEPTH, L))
+    assert np.array_equal(sg.kmeans_centres(), so.kmeans_centres())
+    # the oracle sums 600k residuals sequentially in float32 (reference FrontEnd.cpp:655-664): ~1e-3 relative
+    assert_traces_match(sg, so, tol_twist=5e-6, rtol_aver=2e-3, tol_b=3e-3)
+    rot, trans = pose_delta(so.T(), sg.T())
+    assert rot <= POSE_TOL and trans <= POSE_TOL
+    assert np.array_equal(sg.b_image() > 0.5, so.b_image() > 0.5)
+
+
+@pytest.mark.parametrize("seed", range(2000, 2012))
+def test_many_seeds_small(hip, ora, pair, seed):
+    """A dozen random scenes/motions at 160x120: labels identical, iteration counts identical, pose <= 1e-4."""
+    from staticfusion_amd.synth import LCG64
+
+    g = LCG64(seed)
+    xi = tuple(np.array(DEFAULT_XI) * np.array([g.uniform(-2.5, 2.5) for _ in range(6)]))
+    pr = pair(seed=seed, sphere=(seed % 2 == 0), rows=120, cols=160, xi=xi)
+    sg, so = solve_both(hip, ora, 120, 160, lambda a: driver_params(a, kb=1.5 if seed % 3 else 1.05), pr)
+    a, b = sg.stats(), so.stats()
+    assert (a.n_outer, a.n_irls, a.kmeans_iters) == (b.n_outer, b.n_irls, b.kmeans_iters)
+    for L in range(sg.levels):
+        assert np.array_equal(sg.labels(L), so.labels(L))
+    rot, trans = pose_delta(so.T(), sg.T())
+    assert rot <= POSE_TOL and trans <= POSE_TOL
+    assert np.abs(sg.b() - so.b()).max() < 1e-3

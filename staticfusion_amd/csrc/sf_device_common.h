@@ -109,28 +109,56 @@ struct KArgs {
 // ---------------------------------------------------------------------------------------------
 //  wave / workgroup reductions (deterministic: fixed shuffle tree, fixed wave order)
 // ---------------------------------------------------------------------------------------------
+// Wave reductions on the DPP network (row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast15 /
+// row_bcast31 across rows: an inclusive scan whose last lane holds the total) instead of ds_bpermute
+// shuffles: VALU-speed cross-lane moves, no trip through the LDS crossbar.  The association order is
+// fixed, so the sums stay deterministic.  Every lane returns the total (broadcast from lane 63).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_i32<CTRL, ROW_MASK>((int)(b & 0xffffffffll)), hi = dpp_i32<CTRL, ROW_MASK>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_i64(long long b) {
+    const int lo = dpp_i32<CTRL, ROW_MASK>((int)(b & 0xffffffffll)), hi = dpp_i32<CTRL, ROW_MASK>((int)(b >> 32));
+    return ((long long)hi << 32) | (unsigned)lo;
+}
+#define SF_DPP_REDUCE(v, MOVE, OP)         \
+    v = OP(v, (MOVE<0x111, 0xf>(v)));      \
+    v = OP(v, (MOVE<0x112, 0xf>(v)));      \
+    v = OP(v, (MOVE<0x114, 0xf>(v)));      \
+    v = OP(v, (MOVE<0x118, 0xf>(v)));      \
+    v = OP(v, (MOVE<0x142, 0xa>(v)));      \
+    v = OP(v, (MOVE<0x143, 0xc>(v)));
+template <class T>
+__device__ __forceinline__ T sf_op_add(T a, T b) { return a + b; }
+__device__ __forceinline__ int sf_op_maxi(int a, int b) { return a > b ? a : b; }
+
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;  // lane 0
-}
-__device__ __forceinline__ float wave_max_f32(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float w = __shfl_down(v, o, 64);
-        v = (w > v) ? w : v;
-    }
-    return v;
-}
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    SF_DPP_REDUCE(v, dpp_f64, sf_op_add)
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    SF_DPP_REDUCE(v, dpp_i64, sf_op_add)
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
+    return ((long long)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    SF_DPP_REDUCE(v, dpp_i32, sf_op_add)
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// maximum of non-negative floats (identity 0 shifts in at the row edges)
+__device__ __forceinline__ float wave_max_f32(float v) {
+    int b = __float_as_int(v);  // non-negative floats order like their bit patterns
+    SF_DPP_REDUCE(b, dpp_i32, sf_op_maxi)
+    return __int_as_float(__builtin_amdgcn_readlane(b, 63));
 }
 
 // x86 cvttss2si semantics of the reference's int(float) (reference FrontEnd.cpp:819-820): NaN and

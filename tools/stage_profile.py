@@ -18,11 +18,10 @@ pairs = make_batch(8, sphere=(a.workload == "sphere"), distinct=8)
 s = sf.Solver(api, 240, 320, a.batch, p)
 for b in range(a.batch):
     s.set_current(b, *pairs[b % 8]["new"]); s.set_prediction(b, *pairs[b % 8]["old"])
-print("created", flush=True)
 for im in range(5):
     s.process_frame(im)
-s.synchronize(); print("primed", flush=True)
-p0 = s.stage_profile(); print("prof ok", flush=True); c0 = s.counters()
+s.synchronize()
+p0 = s.stage_profile(); c0 = s.counters()
 ms = s.timed_process_frames(5, a.steps)
 p1 = s.stage_profile(); c1 = s.counters()
 frames = c1[0] - c0[0]

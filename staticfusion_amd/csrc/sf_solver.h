@@ -643,6 +643,25 @@ __device__ __forceinline__ vfloat2 vfma(vfloat2 a, float b, vfloat2 c) { return 
 __device__ __forceinline__ vfloat2 vfma(vfloat2 a, vfloat2 b, float c) { return __builtin_elementwise_fma(a, b, vfloat2{c, c}); }
 __device__ __forceinline__ vfloat2 vfma(vfloat2 a, float b, float c) { return __builtin_elementwise_fma(a, vfloat2{b, b}, vfloat2{c, c}); }
 
+// Per-pixel IRLS weights use the hardware reciprocal / reciprocal-square-root (1 ulp) instead of the
+// IEEE division + square root sequences (~10 VALU instructions each; pass 1 is VALU-bound). The
+// linearisation (max weights, records) stays bit-identical to the oracle; the solver result moves by
+// ~1e-7, three orders of magnitude inside the pose tolerance. -DSF_FAST_WEIGHTS=0 restores IEEE.
+#ifndef SF_FAST_WEIGHTS
+#define SF_FAST_WEIGHTS 1
+#endif
+#if SF_FAST_WEIGHTS
+__device__ __forceinline__ float vrsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ vfloat2 vrsq(vfloat2 x) { return vfloat2{__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)}; }
+__device__ __forceinline__ float vrcpw(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ vfloat2 vrcpw(vfloat2 x) { return vfloat2{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+#else
+__device__ __forceinline__ float vrsq(float x) { return sqrtf(1.f / x); }
+__device__ __forceinline__ vfloat2 vrsq(vfloat2 x) { return vsqrt(vrcp1(x)); }
+__device__ __forceinline__ float vrcpw(float x) { return 1.f / x; }
+__device__ __forceinline__ vfloat2 vrcpw(vfloat2 x) { return vrcp1(x); }
+#endif
+
 template <class T>
 struct PixFact {
     T x, y, xd, yd, xyd, xxd, yyd;  // geometry: x, y, x/d, y/d, xy/d, x^2/d + d, y^2/d + d
@@ -668,9 +687,9 @@ __device__ __forceinline__ void fact_from_record(const LevelGeom &g, T fu, T fv,
     const T ddt_ = dn - dw;
     const T error_l_c = 10.f * (vabs(dct_) + vabs(dcu_) + vabs(dcv_));
     const T error_l_d = 200.f * (vabs(ddt_) + vabs(ddu_) + vabs(ddv_));
-    const T twc = (g.inv_max_c * vsqrt(vrcp1(1.f + error_l_c))) * g.kph;
-    o.twd = g.inv_max_d * vsqrt(vrcp1(0.01f + error_l_d));
-    const T inv_d = vrcp1(d);
+    const T twc = (g.inv_max_c * vrsq(1.f + error_l_c)) * g.kph;
+    o.twd = g.inv_max_d * vrsq(0.01f + error_l_d);
+    const T inv_d = vrcpw(d);
     const T fd = g.f_inv * inv_d;
     o.pc = twc * (dcu_ * fd);
     o.qc = twc * (dcv_ * fd);
@@ -777,135 +796,117 @@ __device__ __noinline__ void irls_initial_residual(const KArgs &a, int b, int L,
 }
 
 // pass 1: Cauchy x b weights, 21+6 normal-equation sums (reference :615-641) -> s.red[wave][0..26]
-// VAR: 0 = product code; 1 = loads only; 2 = rows + weights, no fp64 accumulation (ablation builds
-// for tools/pass_microbench.py; the product always instantiates VAR 0)
-// pass 1: Cauchy x b weights, 21+6 normal-equation sums (reference :615-641) -> s.red[wave][0..26]
+// VAR: 0 = product code; 1 = loads only; 2 = rows + weights, no accumulation (ablation builds for
+// tools/pass_microbench.py; the product always instantiates VAR 0)
+//
+// Scalar fp32 per pixel: on gfx950 a v_pk_*_f32 and a v_fma_f64 both cost two v_fma_f32 issue slots
+// (tools/micro/valu_rate.hip), so packing buys nothing and costs registers. The 27 sums are kept
+// per lane in fp32 (each lane sees <= 2 x 300 terms at QVGA level 0; the reference accumulates the
+// whole sum in fp32, FrontEnd.cpp:640-641) and the 256 lanes are combined in fp64. The record of
+// the next pixel pair is in flight while the current one is evaluated.
+__device__ __forceinline__ void accum_row(float (&acc)[27], const float (&aw)[7]) {
+    acc[0] = fmaf(aw[0], aw[0], acc[0]);    acc[1] = fmaf(aw[0], aw[1], acc[1]);
+    acc[2] = fmaf(aw[0], aw[2], acc[2]);    acc[3] = fmaf(aw[0], aw[3], acc[3]);
+    acc[4] = fmaf(aw[0], aw[4], acc[4]);    acc[5] = fmaf(aw[0], aw[5], acc[5]);
+    acc[6] = fmaf(aw[1], aw[1], acc[6]);    acc[7] = fmaf(aw[1], aw[2], acc[7]);
+    acc[8] = fmaf(aw[1], aw[3], acc[8]);    acc[9] = fmaf(aw[1], aw[4], acc[9]);
+    acc[10] = fmaf(aw[1], aw[5], acc[10]);  acc[11] = fmaf(aw[2], aw[2], acc[11]);
+    acc[12] = fmaf(aw[2], aw[3], acc[12]);  acc[13] = fmaf(aw[2], aw[4], acc[13]);
+    acc[14] = fmaf(aw[2], aw[5], acc[14]);  acc[15] = fmaf(aw[3], aw[3], acc[15]);
+    acc[16] = fmaf(aw[3], aw[4], acc[16]);  acc[17] = fmaf(aw[3], aw[5], acc[17]);
+    acc[18] = fmaf(aw[4], aw[4], acc[18]);  acc[19] = fmaf(aw[4], aw[5], acc[19]);
+    acc[20] = fmaf(aw[5], aw[5], acc[20]);
+    acc[21] = fmaf(aw[0], aw[6], acc[21]);  acc[22] = fmaf(aw[1], aw[6], acc[22]);
+    acc[23] = fmaf(aw[2], aw[6], acc[23]);  acc[24] = fmaf(aw[3], aw[6], acc[24]);
+    acc[25] = fmaf(aw[4], aw[6], acc[25]);  acc[26] = fmaf(aw[5], aw[6], acc[26]);
+}
+
 template <int VAR>
 __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, LDS SolveShared &s, int tid) {
     const IrlsCtx c = make_irls_ctx(a, b, L, s);
     const float inv_c_Cauchy = 1.f / (a.p.kc_Cauchy * uniform_f(s.aver_res));
-    double acc[27];
-    float accf[27];
+    float acc[27];
 #pragma unroll
-    for (int q = 0; q < 27; q++) {
-        acc[q] = 0.0;
-        accf[q] = 0.f;
-    }
+    for (int q = 0; q < 27; q++) acc[q] = 0.f;
     float Vr[6];
 #pragma unroll
     for (int q = 0; q < 6; q++) Vr[q] = uniform_f(s.Var[q]);
+    const int last = (c.n - 2) & ~1;  // the prefetch past the end re-reads the last pair instead of branching
+    RecVec<2> rv, nx;
+    if (tid * 2 < c.n) load_rec<2>(c.rp, tid * 2, rv);
     for (int i0 = tid * 2; i0 < c.n; i0 += SF_NT * 2) {
-        RecVec<2> rv;
-        load_rec<2>(c.rp, i0, rv);
+        load_rec<2>(c.rp, min(i0 + SF_NT * 2, last), nx);
         const bool ok0 = sanitize<2>(rv, 0), ok1 = sanitize<2>(rv, 1);
         if constexpr (VAR == 1) {
             float t = rv.dn[0] + rv.dn[1];
 #pragma unroll
             for (int q = 0; q < R_COUNT; q++) t += rv.v[q][0] + rv.v[q][1];
-            acc[0] += (double)t;
+            acc[0] += t;
+            rv = nx;
             continue;
         }
-        // one pixel at a time: the 27 fp64 accumulators leave no room for the rows of a pixel pair
+        float fu0, fv0;
+        split_index(c.g, i0, fu0, fv0);
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const bool ok = j ? ok1 : ok0;
-            float fu, fv;
-            split_index(c.g, i0 + j, fu, fv);
-            const float b_weight = ok ? std_max(0.f, std_min(1.f, s.b_segm[rv.lab[j]])) : 0.f;
-            float awf[2][7];
-#if SF_FACTORED_IRLS
-            {
-                PixFact<float> p;
-                fact_from_record<float>(c.g, fu, fv, rv.dn[j], rv.v[R_DW][j], rv.v[R_DCU][j], rv.v[R_DCV][j], rv.v[R_DCT][j],
-                                        rv.v[R_DDU][j], rv.v[R_DDV][j], p);
-                float res_c, res_d;
-                fact_residuals<float>(p, Vr, res_c, res_d);
-                const float w_c = b_weight * sqrtf(1.f / (1.f + sqf(res_c * inv_c_Cauchy)));
-                const float w_d = b_weight * sqrtf(1.f / (1.f + sqf(res_d * inv_c_Cauchy)));
-                const float P = w_c * p.pc, Q = w_c * p.qc;
-                awf[0][0] = -P;
-                awf[0][1] = -Q;
-                awf[0][2] = fmaf(P, p.xd, Q * p.yd);
-                awf[0][3] = fmaf(P, p.xyd, Q * p.yyd);
-                awf[0][4] = -fmaf(P, p.xxd, Q * p.xyd);
-                awf[0][5] = fmaf(P, p.y, -(Q * p.x));
-                awf[0][6] = -(w_c * p.bct);
-                const float W = w_d * p.twd, Pd = w_d * p.pd, Qd = w_d * p.qd;
-                awf[1][0] = -Pd;
-                awf[1][1] = -Qd;
-                awf[1][2] = fmaf(Pd, p.xd, fmaf(Qd, p.yd, W));
-                awf[1][3] = fmaf(Pd, p.xyd, fmaf(Qd, p.yyd, W * p.y));
-                awf[1][4] = -fmaf(Pd, p.xxd, fmaf(Qd, p.xyd, W * p.x));
-                awf[1][5] = fmaf(Pd, p.y, -(Qd * p.x));
-                awf[1][6] = -(w_d * p.bdt);
+            float fu = fu0, fv = fv0;
+            if (j) {  // the pair may straddle a column at the odd-sized coarse levels
+                const bool wrap = (fv0 + 1.f) >= (float)c.g.rows_i;
+                fu = wrap ? fu0 + 1.f : fu0;
+                fv = wrap ? 0.f : fv0 + 1.f;
             }
+            const float bseg = s.b_segm[rv.lab[j]];  // invalid pixels carry label 0 after sanitize()
+            const float b_weight = ok ? std_max(0.f, std_min(1.f, bseg)) : 0.f;
+            PixFact<float> p;
+            fact_from_record<float>(c.g, fu, fv, rv.dn[j], rv.v[R_DW][j], rv.v[R_DCU][j], rv.v[R_DCV][j], rv.v[R_DCT][j],
+                                    rv.v[R_DDU][j], rv.v[R_DDV][j], p);
+            float res_c, res_d;
+            fact_residuals<float>(p, Vr, res_c, res_d);
+            const float tc = res_c * inv_c_Cauchy, td = res_d * inv_c_Cauchy;
+#if SF_FAST_WEIGHTS
+            const float w_c = b_weight * vrsq(fmaf(tc, tc, 1.f));
+            const float w_d = b_weight * vrsq(fmaf(td, td, 1.f));
 #else
-            {
-                PixRows r;
-                rows_from_record<float>(c.g, fu, fv, rv.dn[j], rv.v[R_DW][j], rv.v[R_DCU][j], rv.v[R_DCV][j], rv.v[R_DCT][j],
-                                        rv.v[R_DDU][j], rv.v[R_DDV][j], r);
-#pragma unroll
-                for (int row = 0; row < 2; row++) {
-                    const float *ar = row ? r.ad : r.ac;
-                    const float br = row ? r.bd : r.bc;
-                    float res = -br;
-#pragma unroll
-                    for (int q = 0; q < 6; q++) res += Vr[q] * ar[q];
-                    const float w = b_weight * sqrtf(1.f / (1.f + sqf(res * inv_c_Cauchy)));
-#pragma unroll
-                    for (int q = 0; q < 6; q++) awf[row][q] = w * ar[q];
-                    awf[row][6] = w * br;
-                }
-            }
+            const float w_c = b_weight * vrsq(1.f + tc * tc);
+            const float w_d = b_weight * vrsq(1.f + td * td);
 #endif
-#pragma unroll
-            for (int row = 0; row < 2; row++) {
-                double aw[7];
-#pragma unroll
-                for (int q = 0; q < 7; q++) aw[q] = (double)awf[row][q];
-                if constexpr (VAR == 2) {
-                    acc[0] += ((aw[0] + aw[1]) + (aw[2] + aw[3])) + ((aw[4] + aw[5]) + aw[6]);
-                    continue;
-                }
-                if constexpr (VAR == 3) {  // ablation: fp32 accumulation (NOT the product's numerics)
-                    const float *f = awf[row];
-                    int q = 0;
-#pragma unroll
-                    for (int i = 0; i < 6; i++)
-#pragma unroll
-                        for (int jj = i; jj < 6; jj++) {
-                            accf[q] = fmaf(f[i], f[jj], accf[q]);
-                            q++;
-                        }
-#pragma unroll
-                    for (int i = 0; i < 6; i++) accf[21 + i] = fmaf(f[i], f[6], accf[21 + i]);
-                    continue;
-                }
-                acc[0] = fma(aw[0], aw[0], acc[0]);   acc[1] = fma(aw[0], aw[1], acc[1]);
-                acc[2] = fma(aw[0], aw[2], acc[2]);   acc[3] = fma(aw[0], aw[3], acc[3]);
-                acc[4] = fma(aw[0], aw[4], acc[4]);   acc[5] = fma(aw[0], aw[5], acc[5]);
-                acc[6] = fma(aw[1], aw[1], acc[6]);   acc[7] = fma(aw[1], aw[2], acc[7]);
-                acc[8] = fma(aw[1], aw[3], acc[8]);   acc[9] = fma(aw[1], aw[4], acc[9]);
-                acc[10] = fma(aw[1], aw[5], acc[10]); acc[11] = fma(aw[2], aw[2], acc[11]);
-                acc[12] = fma(aw[2], aw[3], acc[12]); acc[13] = fma(aw[2], aw[4], acc[13]);
-                acc[14] = fma(aw[2], aw[5], acc[14]); acc[15] = fma(aw[3], aw[3], acc[15]);
-                acc[16] = fma(aw[3], aw[4], acc[16]); acc[17] = fma(aw[3], aw[5], acc[17]);
-                acc[18] = fma(aw[4], aw[4], acc[18]); acc[19] = fma(aw[4], aw[5], acc[19]);
-                acc[20] = fma(aw[5], aw[5], acc[20]);
-                acc[21] = fma(aw[0], aw[6], acc[21]); acc[22] = fma(aw[1], aw[6], acc[22]);
-                acc[23] = fma(aw[2], aw[6], acc[23]); acc[24] = fma(aw[3], aw[6], acc[24]);
-                acc[25] = fma(aw[4], aw[6], acc[25]); acc[26] = fma(aw[5], aw[6], acc[26]);
+            float aw[7];
+            {
+                const float P = w_c * p.pc, Q = w_c * p.qc;
+                aw[0] = -P;
+                aw[1] = -Q;
+                aw[2] = fmaf(P, p.xd, Q * p.yd);
+                aw[3] = fmaf(P, p.xyd, Q * p.yyd);
+                aw[4] = -fmaf(P, p.xxd, Q * p.xyd);
+                aw[5] = fmaf(P, p.y, -(Q * p.x));
+                aw[6] = -(w_c * p.bct);
             }
+            if constexpr (VAR == 2)
+                acc[0] += ((aw[0] + aw[1]) + (aw[2] + aw[3])) + ((aw[4] + aw[5]) + aw[6]);
+            else
+                accum_row(acc, aw);
+            {
+                const float W = w_d * p.twd, Pd = w_d * p.pd, Qd = w_d * p.qd;
+                aw[0] = -Pd;
+                aw[1] = -Qd;
+                aw[2] = fmaf(Pd, p.xd, fmaf(Qd, p.yd, W));
+                aw[3] = fmaf(Pd, p.xyd, fmaf(Qd, p.yyd, W * p.y));
+                aw[4] = -fmaf(Pd, p.xxd, fmaf(Qd, p.xyd, W * p.x));
+                aw[5] = fmaf(Pd, p.y, -(Qd * p.x));
+                aw[6] = -(w_d * p.bdt);
+            }
+            if constexpr (VAR == 2)
+                acc[0] += ((aw[0] + aw[1]) + (aw[2] + aw[3])) + ((aw[4] + aw[5]) + aw[6]);
+            else
+                accum_row(acc, aw);
         }
+        rv = nx;
     }
     const int lane = tid & 63, wave = tid >> 6;
-    if constexpr (VAR == 3) {
-#pragma unroll
-        for (int q = 0; q < 27; q++) acc[q] = (double)accf[q];
-    }
 #pragma unroll
     for (int q = 0; q < 27; q++) {
-        const double t = wave_sum_f64(acc[q]);
+        const double t = wave_sum_f64((double)acc[q]);
         if (lane == 0) s.red[wave][q] = t;
     }
 }
@@ -962,46 +963,38 @@ __device__ __noinline__ void irls_pass2(const KArgs &a, int b, int L, LDS SolveS
     double sq = 0.0;
     int cur_lab = 0;
     unsigned long long cur_sum = 0;
+    const int last = (c.n - 2) & ~1;
+    RecVec<2> rv, nx;
+    if (tid * 2 < c.n) load_rec<2>(c.rp, tid * 2, rv);
     for (int i0 = tid * 2; i0 < c.n; i0 += SF_NT * 2) {
-        RecVec<2> rv;
-        load_rec<2>(c.rp, i0, rv);
+        load_rec<2>(c.rp, min(i0 + SF_NT * 2, last), nx);  // next pair in flight during this one
         const bool ok0 = sanitize<2>(rv, 0), ok1 = sanitize<2>(rv, 1);
         if constexpr (VAR == 1) {
             float t = rv.dn[0] + rv.dn[1];
 #pragma unroll
             for (int q = 0; q < R_COUNT; q++) t += rv.v[q][0] + rv.v[q][1];
             sq += (double)t;
+            rv = nx;
             continue;
         }
-        vfloat2 rc, rd;
-#if SF_FACTORED_IRLS
-        {
-            float fu0, fv0, fu1, fv1;
-            split_index(c.g, i0, fu0, fv0);
-            split_index(c.g, i0 + 1, fu1, fv1);
-            PixFact<vfloat2> p;
-            fact_from_record<vfloat2>(c.g, vfloat2{fu0, fu1}, vfloat2{fv0, fv1}, pair_of(rv.dn), pair_of(rv.v[R_DW]),
-                                      pair_of(rv.v[R_DCU]), pair_of(rv.v[R_DCV]), pair_of(rv.v[R_DCT]), pair_of(rv.v[R_DDU]),
-                                      pair_of(rv.v[R_DDV]), p);
-            fact_residuals<vfloat2>(p, Vr, rc, rd);
-        }
-#else
-        {
-            PixRowsT<vfloat2> r;
-            rows_of_pair(rv, i0, c.g, r);
-            rc = -r.bc;
-            rd = -r.bd;
-#pragma unroll
-            for (int q = 0; q < 6; q++) rc += Vr[q] * r.ac[q];
-#pragma unroll
-            for (int q = 0; q < 6; q++) rd += Vr[q] * r.ad[q];
-        }
-#endif
+        float fu0, fv0;
+        split_index(c.g, i0, fu0, fv0);
 #pragma unroll
         for (int px = 0; px < 2; px++) {
             const bool ok = px ? ok1 : ok0;
-            const float rcs = ok ? (px ? rc.y : rc.x) : 0.f;
-            const float rds = ok ? (px ? rd.y : rd.x) : 0.f;
+            float fu = fu0, fv = fv0;
+            if (px) {
+                const bool wrap = (fv0 + 1.f) >= (float)c.g.rows_i;
+                fu = wrap ? fu0 + 1.f : fu0;
+                fv = wrap ? 0.f : fv0 + 1.f;
+            }
+            PixFact<float> p;
+            fact_from_record<float>(c.g, fu, fv, rv.dn[px], rv.v[R_DW][px], rv.v[R_DCU][px], rv.v[R_DCV][px], rv.v[R_DCT][px],
+                                    rv.v[R_DDU][px], rv.v[R_DDV][px], p);
+            float rc, rd;
+            fact_residuals<float>(p, Vr, rc, rd);
+            const float rcs = ok ? rc : 0.f;
+            const float rds = ok ? rd : 0.f;
             sq = fma((double)rcs, (double)rcs, sq);
             sq = fma((double)rds, (double)rds, sq);
             const unsigned long long fx = to_fix32_pos(fabsf(rcs) + fabsf(rds));
@@ -1017,6 +1010,7 @@ __device__ __noinline__ void irls_pass2(const KArgs &a, int b, int L, LDS SolveS
             }
             cur_sum += fx;
         }
+        rv = nx;
     }
     if (cur_sum) lds_add(&s.lab_sum[cur_lab], (long long)cur_sum);
     sq = wave_sum_f64(sq);

@@ -208,6 +208,15 @@ __device__ __forceinline__ void gatomic_add(gptr<uint32_t> p, uint32_t v) {
 
 // a value every lane holds identically (read from LDS / memory): move it to an SGPR
 __device__ __forceinline__ float uniform_f(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+// a pointer that is the same in every lane, moved to an SGPR pair (arguments of the __noinline__
+// stage functions arrive in VGPRs, which would force per-lane 64-bit address arithmetic)
+template <class P>
+__device__ __forceinline__ P uniform_ptr(P p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (P)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ int uniform_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 __device__ __forceinline__ float sqf(float x) { return x * x; }

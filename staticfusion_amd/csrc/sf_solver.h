@@ -146,16 +146,21 @@ struct RecPtrs {
     gcu8 *lab;
 };
 
+// base (uniform, SGPR pair) + 32-bit unsigned byte offset (one VGPR shared by all planes): the
+// saddr + voffset form of global_load, no 64-bit per-plane address arithmetic in the loop
+typedef __attribute__((address_space(1))) const char gcchar;
 template <int VEC>
 __device__ __forceinline__ void load_plane(gcfloat *p, int idx0, float (&out)[VEC]) {
+    const unsigned boff = (unsigned)idx0 * 4u;
+    gcchar *q = (gcchar *)p + boff;
     if constexpr (VEC == 1) {
-        out[0] = p[idx0];
+        out[0] = *(gcfloat *)q;
     } else if constexpr (VEC == 2) {
-        const vfloat2 v = *(gcfloat2 *)(p + idx0);
+        const vfloat2 v = *(gcfloat2 *)q;
         out[0] = v.x;
         out[1] = v.y;
     } else {
-        const vfloat4 v = *(gcfloat4 *)(p + idx0);
+        const vfloat4 v = *(gcfloat4 *)q;
         out[0] = v.x;
         out[1] = v.y;
         out[2] = v.z;
@@ -164,14 +169,15 @@ __device__ __forceinline__ void load_plane(gcfloat *p, int idx0, float (&out)[VE
 }
 template <int VEC>
 __device__ __forceinline__ void load_labels(gcu8 *p, int idx0, int (&out)[VEC]) {
+    gcchar *q = (gcchar *)p + (unsigned)idx0;
     if constexpr (VEC == 1) {
-        out[0] = p[idx0];
+        out[0] = *(gcu8 *)q;
     } else if constexpr (VEC == 2) {
-        const unsigned v = *(gcu16 *)(p + idx0);
+        const unsigned v = *(gcu16 *)q;
         out[0] = v & 255u;
         out[1] = v >> 8;
     } else {
-        const unsigned v = *(gcu32 *)(p + idx0);
+        const unsigned v = *(gcu32 *)q;
         out[0] = v & 255u;
         out[1] = (v >> 8) & 255u;
         out[2] = (v >> 16) & 255u;
@@ -742,9 +748,9 @@ __device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, c
     IrlsCtx c;
     const size_t rb = (size_t)b * a.n0;
 #pragma unroll
-    for (int q = 0; q < R_COUNT; q++) c.rp.p[q] = (gcfloat *)(a.rec[q] + rb);
-    c.rp.dnew = (gcfloat *)(a.pyr_new[0] + (size_t)b * a.n_tot + a.loff[L]);
-    c.rp.lab = (gcu8 *)(a.rec_lab + rb);
+    for (int q = 0; q < R_COUNT; q++) c.rp.p[q] = uniform_ptr((gcfloat *)(a.rec[q] + rb));
+    c.rp.dnew = uniform_ptr((gcfloat *)(a.pyr_new[0] + (size_t)b * a.n_tot + a.loff[L]));
+    c.rp.lab = uniform_ptr((gcu8 *)(a.rec_lab + rb));
     c.n = a.ln[L];
     c.N = uniform_i(s.n_valid);
     const int rows_i = a.lrows[L], cols_i = a.lcols[L];
@@ -845,6 +851,7 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, LDS SolveS
             rv = nx;
             continue;
         }
+        float bseg0 = s.b_segm[rv.lab[0]], bseg1 = s.b_segm[rv.lab[1]];  // invalid pixels carry label 0 after sanitize()
         float fu0, fv0;
         split_index(c.g, i0, fu0, fv0);
 #pragma unroll
@@ -856,11 +863,11 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, LDS SolveS
                 fu = wrap ? fu0 + 1.f : fu0;
                 fv = wrap ? 0.f : fv0 + 1.f;
             }
-            const float bseg = s.b_segm[rv.lab[j]];  // invalid pixels carry label 0 after sanitize()
-            const float b_weight = ok ? std_max(0.f, std_min(1.f, bseg)) : 0.f;
             PixFact<float> p;
             fact_from_record<float>(c.g, fu, fv, rv.dn[j], rv.v[R_DW][j], rv.v[R_DCU][j], rv.v[R_DCV][j], rv.v[R_DCT][j],
                                     rv.v[R_DDU][j], rv.v[R_DDV][j], p);
+            if (j == 0) asm volatile("" : "+v"(bseg0), "+v"(bseg1));  // LDS reads stay unconditional, landed by now
+            const float b_weight = ok ? std_max(0.f, std_min(1.f, j ? bseg1 : bseg0)) : 0.f;
             float res_c, res_d;
             fact_residuals<float>(p, Vr, res_c, res_d);
             const float tc = res_c * inv_c_Cauchy, td = res_d * inv_c_Cauchy;

@@ -193,11 +193,20 @@ __device__ __forceinline__ void lds_or(LDS T *p, T v) {
     __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// a pointer that is the same in every lane, moved to an SGPR pair (arguments of the __noinline__
+// stage functions arrive in VGPRs, which would force per-lane 64-bit address arithmetic)
+template <class P>
+__device__ __forceinline__ P uniform_ptr(P p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (P)(((unsigned long long)hi << 32) | lo);
+}
 template <class T>
 using gptr = __attribute__((address_space(1))) T *;
 template <class T>
-__device__ __forceinline__ gptr<T> as_global(T *p) {
-    return (gptr<T>)p;
+__device__ __forceinline__ gptr<T> as_global(T *p) {  // every base pointer of a stage is workgroup-uniform
+    return uniform_ptr((gptr<T>)p);
 }
 __device__ __forceinline__ void gatomic_add(gptr<long long> p, long long v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -208,15 +217,6 @@ __device__ __forceinline__ void gatomic_add(gptr<uint32_t> p, uint32_t v) {
 
 // a value every lane holds identically (read from LDS / memory): move it to an SGPR
 __device__ __forceinline__ float uniform_f(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
-// a pointer that is the same in every lane, moved to an SGPR pair (arguments of the __noinline__
-// stage functions arrive in VGPRs, which would force per-lane 64-bit address arithmetic)
-template <class P>
-__device__ __forceinline__ P uniform_ptr(P p) {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (P)(((unsigned long long)hi << 32) | lo);
-}
 __device__ __forceinline__ int uniform_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 __device__ __forceinline__ float sqf(float x) { return x * x; }

@@ -58,6 +58,7 @@ struct SolveShared {
     // IRLS
     float AtA[36], AtB[6], Var[6], prev_sol[6];
     float aver_res, aver_res_old, inv_max_c, inv_max_d, res_sqnorm;
+    double init_abs_c, init_abs_d;  // sum of wc |dct| and wd |ddt| over validPixels (raw pre-weights), from the linearisation
     int n_valid, ctrl, status, n_irls, n_outer, first;
     long long pixel_iters;
     // small solves
@@ -354,6 +355,7 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
         s.valid_cnt[tid] = 0;
     }
     float max_c = 0.f, max_d = 0.f;
+    double abs_c = 0.0, abs_d = 0.0;  // initial |res| = |B| sums (reference :588-590), scaled by 1/max afterwards
     int n_valid = 0;
 
     const int tiles_v = (rows_i + TILE_V - 1) / TILE_V, tiles_u = (cols_i + TILE_U - 1) / TILE_U;
@@ -472,6 +474,8 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                     const float wd = sqrtf(1.f / (0.01f + error_l_d));
                     max_c = (wc > max_c) ? wc : max_c;
                     max_d = (wd > max_d) ? wd : max_d;
+                    abs_c += (double)(wc * fabsf(dct_));
+                    abs_d += (double)(wd * fabsf(ddt_));
                     n_valid++;
                 }
                 rec[R_DW][idx] = dw;
@@ -522,20 +526,29 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
     max_c = wave_max_f32(max_c);
     max_d = wave_max_f32(max_d);
     n_valid = wave_sum_i32(n_valid);
+    abs_c = wave_sum_f64(abs_c);
+    abs_d = wave_sum_f64(abs_d);
     if (lane == 0) {
         s.redf[wave][0] = max_c;
         s.redf[wave][1] = max_d;
         s.redi[wave] = n_valid;
+        s.red[wave][0] = abs_c;
+        s.red[wave][1] = abs_d;
     }
     __syncthreads();
     if (tid == 0) {
         float mc = 0.f, md = 0.f;
         int nv = 0;
+        double ac = 0.0, ad = 0.0;
         for (int w = 0; w < SF_NW; w++) {
             mc = (s.redf[w][0] > mc) ? s.redf[w][0] : mc;
             md = (s.redf[w][1] > md) ? s.redf[w][1] : md;
             nv += s.redi[w];
+            ac += s.red[w][0];
+            ad += s.red[w][1];
         }
+        s.init_abs_c = ac;
+        s.init_abs_d = ad;
         s.n_valid = nv;
         s.inv_max_c = (nv > 0) ? 1.f / mc : 0.f;
         s.inv_max_d = (nv > 0) ? 1.f / md : 0.f;
@@ -767,38 +780,6 @@ __device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, c
     c.g.inv_max_d = uniform_f(s.inv_max_d);
     c.g.first = uniform_i(s.first);
     return c;
-}
-
-// initial aver_res = mean |res| with res = -B (reference :588-590): partial sums to s.red[wave][0]
-__device__ __noinline__ void irls_initial_residual(const KArgs &a, int b, int L, LDS SolveShared &s, int tid) {
-    const IrlsCtx c = make_irls_ctx(a, b, L, s);
-    double sabs = 0.0;
-    for (int i0 = tid * 2; i0 < c.n; i0 += SF_NT * 2) {
-        RecVec<2> rv;
-        load_rec<2>(c.rp, i0, rv);
-        const bool ok0 = sanitize<2>(rv, 0), ok1 = sanitize<2>(rv, 1);
-#if SF_FACTORED_IRLS
-        float fu0, fv0, fu1, fv1;
-        split_index(c.g, i0, fu0, fv0);
-        split_index(c.g, i0 + 1, fu1, fv1);
-        PixFact<vfloat2> p;
-        fact_from_record<vfloat2>(c.g, vfloat2{fu0, fu1}, vfloat2{fv0, fv1}, pair_of(rv.dn), pair_of(rv.v[R_DW]), pair_of(rv.v[R_DCU]),
-                                  pair_of(rv.v[R_DCV]), pair_of(rv.v[R_DCT]), pair_of(rv.v[R_DDU]), pair_of(rv.v[R_DDV]), p);
-        sabs += ok0 ? (double)fabsf(p.bct.x) : 0.0;
-        sabs += ok0 ? (double)fabsf(p.bdt.x) : 0.0;
-        sabs += ok1 ? (double)fabsf(p.bct.y) : 0.0;
-        sabs += ok1 ? (double)fabsf(p.bdt.y) : 0.0;
-#else
-        PixRowsT<vfloat2> r;
-        rows_of_pair(rv, i0, c.g, r);
-        sabs += ok0 ? (double)fabsf(-r.bc.x) : 0.0;
-        sabs += ok0 ? (double)fabsf(-r.bd.x) : 0.0;
-        sabs += ok1 ? (double)fabsf(-r.bc.y) : 0.0;
-        sabs += ok1 ? (double)fabsf(-r.bd.y) : 0.0;
-#endif
-    }
-    sabs = wave_sum_f64(sabs);
-    if ((tid & 63) == 0) s.red[tid >> 6][0] = sabs;
 }
 
 // pass 1: Cauchy x b weights, 21+6 normal-equation sums (reference :615-641) -> s.red[wave][0..26]
@@ -1131,11 +1112,10 @@ __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level,
         return;
     }
 
-    irls_initial_residual(a, b, L, s, tid);
-    __syncthreads();
+    // initial aver_res = mean |res| with res = -B (reference :588-590). B = (pre-weight / max) * derivative:
+    // the sums of raw pre-weight x |dct|, |ddt| come from the linearisation, so no extra pass over the records
     if (tid == 0) {
-        double t = 0.0;
-        for (int w = 0; w < SF_NW; w++) t += s.red[w][0];
+        const double t = (double)(s.inv_max_c * a.p.k_photometric_res) * s.init_abs_c + (double)s.inv_max_d * s.init_abs_d;
         s.aver_res = (float)t / float(2 * N);
     }
     if (seg && wave == 0) irls_seg_factor(a, s, lane);

@@ -161,6 +161,47 @@ int SF_FN(set_segm_state)(sf_handle *h, int stream, const int32_t *labels0, cons
 /* twist_odometry_old (carried motion-filter state, FrontEnd.cpp:1141-1144); rarely needed. */
 int SF_FN(set_twist_old)(sf_handle *h, int stream, const float twist[6]);
 
+/* ---- input stage: what the drivers run before the four methods ---- */
+
+/* StaticFusion::loadImageFromSequenceAssoc minus the file decoding (FrontEnd.cpp:216-254): from a decoded
+ * full-resolution frame -- color_full: full_rows x full_cols x 3 uint8, interleaved, row-major, channels in
+ * the decoder's memory order (the reference applies 0.299 / 0.587 / 0.114 to bytes 0 / 1 / 2 of cv::imread's
+ * output, :231-236); depth_full: full_rows x full_cols uint16, row-major, millimetres -- take every
+ * res_factor-th pixel of the vertically flipped image (row full_rows - res_factor*v - 1, column res_factor*u):
+ *   intensityCurrent(v,u) = 0.299 c0/255 + 0.587 c1/255 + 0.114 c2/255           (:232-236)
+ *   depthCurrent(v,u)     = float(mm) * float(1/1000)                              (:243,249)
+ *   depth_mm(v,u)         = mm                                  rows x cols uint16, row-major (:244,250)
+ *   color_full(v,u)       = (c0, c1, c2)                        rows x cols x 3 uint8, row-major (:237)
+ * full_rows / res_factor and full_cols / res_factor must equal the handle's rows x cols. Host pointers. */
+int SF_FN(load_frame)(sf_handle *h, int stream, const uint8_t *color_full, const uint16_t *depth_full, int full_rows,
+                      int full_cols, int res_factor);
+/* Same for the whole batch from DEVICE-resident buffers [batch][full_rows][full_cols][3] / [batch][full_rows][full_cols]. */
+int SF_FN(load_frame_device)(sf_handle *h, const void *d_color_full, const void *d_depth_full, int full_rows, int full_cols,
+                             int res_factor);
+/* gui->depthCutoff / Reconstruction::depthCutoff, metres (FrontEnd.cpp:168,174: depth_max = 4.5). */
+int SF_FN(set_depth_cutoff)(sf_handle *h, float max_depth_m);
+/* Reconstruction::getFilteredDepth(depth_mm, depthCurrent) (Reconstruction.cpp:722-732), all streams:
+ * bilateral filter of depth_mm (Shaders/depth_bilateral.frag:34-74: 13x13 window clipped to the image,
+ * range gate 300 mm .. cutoff, weight exp(-(space2*0.024691358 + color2*0.000555556)) evaluated with
+ * sf_exp_neg() of sf_detmath.h, result round()ed to integer mm), then metricise (Shaders/depth_metric.frag:32-39:
+ * 0 outside 300 mm .. cutoff, else mm / 1000.0f) into depthCurrent. Also fills the unfiltered DEPTH_METRIC
+ * image the fusion consumes (Reconstruction.cpp:337-346). Needs a previous sf_load_frame*. */
+int SF_FN(filter_depth)(sf_handle *h);
+/* depthCurrent / intensityCurrent as the solver will see them (column-major float, rows*cols each; either may be NULL). */
+int SF_FN(get_current)(sf_handle *h, int stream, float *depth, float *intensity);
+/* Intermediate images of the input stage, row-major rows x cols: which = SF_IN_* ; out type per selector. */
+enum {
+    SF_IN_DEPTH_MM = 0,      /* uint16: depth_mm (FrontEnd.cpp:250) */
+    SF_IN_DEPTH_FILTERED_MM, /* uint16: DEPTH_FILTERED, output of depth_bilateral.frag */
+    SF_IN_DEPTH_METRIC,      /* float : DEPTH_METRIC, unfiltered, metres */
+    SF_IN_COLOR,             /* uint8 x 3: color_full */
+    SF_IN_COUNT
+};
+int SF_FN(get_input_image)(sf_handle *h, int stream, int which, void *out);
+/* Wall time of `calls` back-to-back sf_load_frame_device + sf_filter_depth pairs (HIP events). */
+int SF_FN(timed_input_stage)(sf_handle *h, const void *d_color_full, const void *d_depth_full, int full_rows, int full_cols,
+                             int res_factor, int calls, float *elapsed_ms);
+
 /* ---- the four methods the drivers call (all streams of the batch) ------------------------- */
 
 /* StaticFusion::createImagePyramid(bool old_im)  FrontEnd.cpp:256-391 */

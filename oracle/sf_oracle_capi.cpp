@@ -12,6 +12,8 @@
 #include <vector>
 
 #include "sf_oracle.hpp"
+#include "sf_oracle_input.hpp"
+#include "../include/sf_detmath.h"
 
 struct sf_handle {
     int rows, cols, batch;
@@ -19,6 +21,12 @@ struct sf_handle {
     std::vector<std::unique_ptr<sfo::StaticFusion>> s;
     long long cum_frames = 0, cum_irls = 0, cum_outer = 0, cum_pix = 0;
     float last_ms = 0.f;
+    // input stage (per stream, row-major rows x cols)
+    float depth_cutoff = 4.5f;  // FrontEnd.cpp:168
+    bool have_frame = false;
+    std::vector<std::vector<uint16_t>> depth_mm, filtered_mm;
+    std::vector<std::vector<float>> depth_metric;
+    std::vector<std::vector<uint8_t>> color;
 };
 
 static thread_local std::string g_err;
@@ -377,6 +385,97 @@ int sfo_get_lin_plane(sf_handle *h, int stream, int which, float *out, int *rows
 int sfo_level_rows(const sf_handle *h, int level) { return h ? (h->rows >> level) : 0; }
 int sfo_level_cols(const sf_handle *h, int level) { return h ? (h->cols >> level) : 0; }
 int sfo_batch(const sf_handle *h) { return h ? h->batch : 0; }
+
+// test hook (not part of include/sf.h): the weight function of include/sf_detmath.h, evaluated by this library
+void sfo_test_exp_neg(const float *a, int n, float *out) {
+    for (int i = 0; i < n; i++) out[i] = sf_exp_neg(a[i]);
+}
+
+// ---- input stage (sf_oracle_input.cpp) ----------------------------------------------------
+static int input_alloc(sf_handle *h) {
+    const size_t n = size_t(h->rows) * h->cols;
+    if (h->depth_mm.size() == size_t(h->batch)) return SF_OK;
+    h->depth_mm.assign(h->batch, std::vector<uint16_t>(n, 0));
+    h->filtered_mm.assign(h->batch, std::vector<uint16_t>(n, 0));
+    h->depth_metric.assign(h->batch, std::vector<float>(n, 0.f));
+    h->color.assign(h->batch, std::vector<uint8_t>(n * 3, 0));
+    return SF_OK;
+}
+static int check_full(sf_handle *h, int full_rows, int full_cols, int res) {
+    if (res < 1 || full_rows != h->rows * res || full_cols != h->cols * res) return fail(SF_ERR_ARG, "full resolution / res_factor do not match the handle");
+    return SF_OK;
+}
+int sfo_load_frame(sf_handle *h, int stream, const uint8_t *color_full, const uint16_t *depth_full, int full_rows, int full_cols,
+                   int res_factor) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!color_full || !depth_full) return fail(SF_ERR_ARG, "null image");
+    if (int e = check_full(h, full_rows, full_cols, res_factor)) return e;
+    input_alloc(h);
+    auto &s = *h->s[stream];
+    sfo::load_frame(color_full, depth_full, full_rows, full_cols, res_factor, h->rows, h->cols, s.depthCurrent.d.data(),
+                    s.intensityCurrent.d.data(), h->depth_mm[stream].data(), h->color[stream].data());
+    h->have_frame = true;
+    return SF_OK;
+}
+int sfo_load_frame_device(sf_handle *h, const void *c, const void *d, int full_rows, int full_cols, int res_factor) {
+    if (!h || !c || !d) return fail(SF_ERR_ARG, "null");
+    const size_t n = size_t(full_rows) * full_cols;
+    for (int b = 0; b < h->batch; b++)
+        if (int e = sfo_load_frame(h, b, (const uint8_t *)c + b * n * 3, (const uint16_t *)d + b * n, full_rows, full_cols, res_factor)) return e;
+    return SF_OK;
+}
+int sfo_set_depth_cutoff(sf_handle *h, float m) {
+    if (!h || !(m > 0.f)) return fail(SF_ERR_ARG, "bad cutoff");
+    h->depth_cutoff = m;
+    return SF_OK;
+}
+int sfo_filter_depth(sf_handle *h) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    if (!h->have_frame) return fail(SF_ERR_STATE, "sf_filter_depth needs sf_load_frame first");
+    const int n = h->rows * h->cols;
+    for (int b = 0; b < h->batch; b++) {
+        sfo::bilateral_mm(h->depth_mm[b].data(), h->rows, h->cols, h->depth_cutoff, h->filtered_mm[b].data());  // filterDepth()
+        sfo::metricise(h->depth_mm[b].data(), n, h->depth_cutoff, h->depth_metric[b].data());                    // METRIC
+        std::vector<float> mf(n);
+        sfo::metricise(h->filtered_mm[b].data(), n, h->depth_cutoff, mf.data());                                 // METRIC_FILTERED
+        auto &dc = h->s[b]->depthCurrent;  // cv::cv2eigen (Reconstruction.cpp:730)
+        for (int v = 0; v < h->rows; v++)
+            for (int u = 0; u < h->cols; u++) dc.d[v + size_t(u) * h->rows] = mf[size_t(v) * h->cols + u];
+    }
+    return SF_OK;
+}
+int sfo_get_current(sf_handle *h, int stream, float *depth, float *intensity) {
+    if (int e = check_stream(h, stream)) return e;
+    auto &s = *h->s[stream];
+    const size_t bytes = sizeof(float) * size_t(h->rows) * h->cols;
+    if (depth) std::memcpy(depth, s.depthCurrent.d.data(), bytes);
+    if (intensity) std::memcpy(intensity, s.intensityCurrent.d.data(), bytes);
+    return SF_OK;
+}
+int sfo_get_input_image(sf_handle *h, int stream, int which, void *out) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!out) return fail(SF_ERR_ARG, "null");
+    if (!h->have_frame) return fail(SF_ERR_STATE, "no frame loaded");
+    const size_t n = size_t(h->rows) * h->cols;
+    switch (which) {
+        case SF_IN_DEPTH_MM: std::memcpy(out, h->depth_mm[stream].data(), n * 2); return SF_OK;
+        case SF_IN_DEPTH_FILTERED_MM: std::memcpy(out, h->filtered_mm[stream].data(), n * 2); return SF_OK;
+        case SF_IN_DEPTH_METRIC: std::memcpy(out, h->depth_metric[stream].data(), n * 4); return SF_OK;
+        case SF_IN_COLOR: std::memcpy(out, h->color[stream].data(), n * 3); return SF_OK;
+        default: return fail(SF_ERR_ARG, "bad selector");
+    }
+}
+int sfo_timed_input_stage(sf_handle *h, const void *c, const void *d, int full_rows, int full_cols, int res_factor, int calls,
+                          float *elapsed_ms) {
+    if (!h || calls < 1) return fail(SF_ERR_ARG, "bad argument");
+    auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < calls; k++) {
+        if (int e = sfo_load_frame_device(h, c, d, full_rows, full_cols, res_factor)) return e;
+        if (int e = sfo_filter_depth(h)) return e;
+    }
+    if (elapsed_ms) *elapsed_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return SF_OK;
+}
 
 int sfo_timed_process_frames(sf_handle *h, int im_count, int calls, float *elapsed_ms) {
     if (!h || calls < 1) return fail(SF_ERR_ARG, "bad argument");

@@ -17,6 +17,8 @@ SET_NEW, SET_PRED, SET_WARPED, SET_INTER = 0, 1, 2, 3
 CH_DEPTH, CH_INTENSITY, CH_XX, CH_YY = 0, 1, 2, 3
 (LIN_DCU, LIN_DCV, LIN_DCT, LIN_DDU, LIN_DDV, LIN_DDT, LIN_WC, LIN_WD, LIN_NULL) = range(9)
 
+IN_DEPTH_MM, IN_DEPTH_FILTERED_MM, IN_DEPTH_METRIC, IN_COLOR = range(4)
+
 STATUS_EIG_SKIPPED = 1
 STATUS_EMPTY_LEVEL = 2
 
@@ -91,6 +93,13 @@ SIGNATURES = {
     "current_to_prediction": (C.c_int, [_H]),
     "set_segm_state": (C.c_int, [_H, C.c_int, _ip, _fp, _fp]),
     "set_twist_old": (C.c_int, [_H, C.c_int, _fp]),
+    "load_frame": (C.c_int, [_H, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_int]),
+    "load_frame_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "set_depth_cutoff": (C.c_int, [_H, C.c_float]),
+    "filter_depth": (C.c_int, [_H]),
+    "get_current": (C.c_int, [_H, C.c_int, _fp, _fp]),
+    "get_input_image": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
+    "timed_input_stage": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "build_pyramid": (C.c_int, [_H, C.c_int]),
     "kmeans": (C.c_int, [_H]),
     "run_solver": (C.c_int, [_H, C.c_int]),
@@ -205,6 +214,35 @@ class Solver:
         d, i = _f32(depth), _f32(intensity)
         assert d.shape == (self.cols, self.rows) and i.shape == d.shape
         self.api.check(self.api.set_prediction(self.h, stream, d.ctypes.data_as(_fp), i.ctypes.data_as(_fp)))
+
+    # -- input stage ---------------------------------------------------
+    def load_frame(self, stream, color_full, depth_full, res_factor=2):
+        """color_full: (H, W, 3) uint8 in decoder order; depth_full: (H, W) uint16 millimetres."""
+        cf = np.ascontiguousarray(color_full, dtype=np.uint8)
+        df = np.ascontiguousarray(depth_full, dtype=np.uint16)
+        assert cf.ndim == 3 and cf.shape[2] == 3 and df.shape == cf.shape[:2]
+        self.api.check(self.api.load_frame(self.h, stream, cf.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                           df.ctypes.data_as(C.POINTER(C.c_uint16)), df.shape[0], df.shape[1], res_factor))
+
+    def set_depth_cutoff(self, metres):
+        self.api.check(self.api.set_depth_cutoff(self.h, metres))
+
+    def filter_depth(self):
+        self.api.check(self.api.filter_depth(self.h))
+
+    def current(self, stream=0):
+        """(depthCurrent, intensityCurrent) as (rows, cols) arrays"""
+        d = np.zeros((self.cols, self.rows), dtype=np.float32)
+        i = np.zeros((self.cols, self.rows), dtype=np.float32)
+        self.api.check(self.api.get_current(self.h, stream, d.ctypes.data_as(_fp), i.ctypes.data_as(_fp)))
+        return d.T.copy(), i.T.copy()
+
+    def input_image(self, which, stream=0):
+        shape, dt = {IN_DEPTH_MM: ((self.rows, self.cols), np.uint16), IN_DEPTH_FILTERED_MM: ((self.rows, self.cols), np.uint16),
+                     IN_DEPTH_METRIC: ((self.rows, self.cols), np.float32), IN_COLOR: ((self.rows, self.cols, 3), np.uint8)}[which]
+        out = np.zeros(shape, dtype=dt)
+        self.api.check(self.api.get_input_image(self.h, stream, which, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def current_to_prediction(self):
         self.api.check(self.api.current_to_prediction(self.h))

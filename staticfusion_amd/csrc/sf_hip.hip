@@ -672,7 +672,7 @@ static int check_full(sf_handle *h, int full_rows, int full_cols, int res) {
 }
 static int launch_load(sf_handle *h, const uint8_t *d_color, const uint16_t *d_depth, int full_rows, int full_cols, int res,
                        int stream0, int count) {
-    const dim3 grid((h->k.n0 + 255) / 256, count);
+    const dim3 grid((h->k.cols + LD_T - 1) / LD_T, (h->k.rows + LD_T - 1) / LD_T, count);
     hipLaunchKernelGGL(sf_load_frame_kernel, grid, dim3(256), 0, h->stream, d_color, d_depth, full_cols, (size_t)full_rows * full_cols,
                        res, h->k.rows, h->k.cols, h->k.pyr_new[0], h->k.pyr_new[1], (size_t)h->k.n_tot, h->in_depth_mm, h->in_color,
                        stream0);

@@ -21,6 +21,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 f32 = np.float32
 
 
+def fma32(a, b, c):
+    """Correctly rounded float32 fused multiply-add, array-at-a-time, without an FMA instruction:
+    the product of two float32 is exact in float64; the float64 sum is rounded once; TwoSum gives the
+    exact rounding error, which decides the (rare) case where the float64 sum sits exactly on a
+    float32 rounding boundary (double rounding)."""
+    f64 = np.float64
+    p = a.astype(f64) * b.astype(f64)
+    c64 = c.astype(f64)
+    s = p + c64
+    bb = s - p
+    e = (p - (s - bb)) + (c64 - bb)  # exact error of s
+    r = s.astype(f32)
+    r64 = r.astype(f64)
+    up = np.nextafter(r, f32(np.inf))
+    dn = np.nextafter(r, f32(-np.inf))
+    tie_up = (s > r64) & (s == (r64 + up.astype(f64)) * 0.5)  # s on the boundary, rounded down to r
+    tie_dn = (s < r64) & (s == (r64 + dn.astype(f64)) * 0.5)  # s on the boundary, rounded up to r
+    r = np.where(tie_up & (e > 0), up, r)
+    r = np.where(tie_dn & (e < 0), dn, r)
+    return r.astype(f32)
+
+
 def exp_neg(a):
     """exp(-a), a >= 0 float32 array: include/sf_detmath.h, each line one float32 operation."""
     a = a.astype(f32)
@@ -28,16 +50,37 @@ def exp_neg(a):
     ln2_hi = f32(0.693145751953125)
     ln2_lo = f32(1.42860676533018589e-06)
     live = a <= f32(87.0)
-    aa = np.where(live, a, f32(0.0))
+    aa = np.where(live, a, f32(0.0)).astype(f32)
     n = np.rint(aa * log2e).astype(f32)  # ties to even
-    r = aa - n * ln2_hi
-    r = r - n * ln2_lo
+    r = fma32(-n, np.full_like(n, ln2_hi), aa)
+    r = fma32(-n, np.full_like(n, ln2_lo), r)
     x = -r
     p = np.full_like(x, f32(1.0) / f32(5040.0))
     for c in (f32(1.0) / f32(720.0), f32(1.0) / f32(120.0), f32(1.0) / f32(24.0), f32(1.0) / f32(6.0), f32(0.5), f32(1.0), f32(1.0)):
-        p = p * x + c
+        p = fma32(p, x, np.full_like(x, c))
     scale = ((127 - n.astype(np.int64)).astype(np.uint32) << np.uint32(23)).view(f32)
     return np.where(live, p * scale, f32(0.0)).astype(f32)
+
+
+def check_fma32():
+    """fma32 against libm's fmaf on random and on constructed boundary cases."""
+    import ctypes
+
+    libm = ctypes.CDLL("libm.so.6")
+    libm.fmaf.restype = ctypes.c_float
+    libm.fmaf.argtypes = [ctypes.c_float] * 3
+    rng = np.random.default_rng(7)
+    a = rng.normal(0, 1, 20000).astype(f32)
+    b = rng.normal(0, 1, 20000).astype(f32)
+    cc = (-(a.astype(np.float64) * b.astype(np.float64)) * (1 + rng.normal(0, 1e-7, 20000))).astype(f32)  # cancellation
+    cc[::3] = rng.normal(0, 1, cc[::3].size).astype(f32)
+    # boundary cases: a*b + c exactly half an ulp above a float32, plus a tiny product term
+    a[:64] = f32(1.0) + f32(2.0) ** -12
+    b[:64] = f32(1.0) + f32(2.0) ** -12  # a*b = 1 + 2^-11 + 2^-24: the 2^-24 is exactly half an ulp of 1.0x
+    cc[:64] = rng.choice([f32(0.0), f32(2.0) ** -40, -f32(2.0) ** -40], 64)
+    got = fma32(a, b, cc)
+    ref = np.array([libm.fmaf(float(x), float(y), float(z)) for x, y, z in zip(a, b, cc)], dtype=f32)
+    assert np.array_equal(got, ref), int((got != ref).sum())
 
 
 def load_frame(color_full, depth_full, res):
@@ -111,6 +154,7 @@ def synth_frame(full_rows, full_cols, seed):
 
 
 def main():
+    check_fma32()
     out_dir = os.path.join(ROOT, "tests", "golden")
     color, depth = synth_frame(120, 160, seed=2024)  # -> 60 x 80 at res_factor 2
     inten, d0, mm, col = load_frame(color, depth, 2)

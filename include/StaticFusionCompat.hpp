@@ -138,6 +138,31 @@ class StaticFusionCompat {
         check(sf_build_segm_image(h_), "build_segm_image");
         check(sf_get_b_image(h_, 0, b_segm_perpixel.data()), "get_b_image");
     }
+    // reference: loadImageFromSequenceAssoc(depthFile, rgbFile, res_factor), FrontEnd.cpp:216-254, after its two
+    // cv::imread calls: `color` is the decoded full-resolution 3-channel image (decoder byte order), `depth`
+    // the decoded 16-bit image in millimetres, both (height*res_factor) x (width*res_factor), row-major.
+    // Fills intensityCurrent, depthCurrent, depth_mm and color_full like the reference does.
+    bool loadImageFromDecoded(const uint8_t *color, const uint16_t *depth, unsigned int res_factor) {
+        if (!color || !depth) return true;  // "End of sequence (or color image not found...)" (:222-226)
+        check(sf_load_frame(h_, 0, color, depth, int(height * res_factor), int(width * res_factor), int(res_factor)), "load_frame");
+        depth_mm.resize(size_t(rows) * cols);
+        color_full.resize(size_t(rows) * cols * 3);
+        check(sf_get_current(h_, 0, depthCurrent.data(), intensityCurrent.data()), "get_current");
+        check(sf_get_input_image(h_, 0, SF_IN_DEPTH_MM, depth_mm.data()), "get_input_image");
+        check(sf_get_input_image(h_, 0, SF_IN_COLOR, color_full.data()), "get_input_image");
+        return false;
+    }
+    // reference: reconstruction->getFilteredDepth(depth_mm, depthCurrent), Reconstruction.cpp:722-732
+    // (bilateral filter + metricise of the frame loaded last); depthCurrent := the filtered depth in metres
+    void getFilteredDepth() {
+        check(sf_set_depth_cutoff(h_, depth_max), "set_depth_cutoff");
+        check(sf_filter_depth(h_), "filter_depth");
+        check(sf_get_current(h_, 0, depthCurrent.data(), nullptr), "get_current");
+    }
+    std::vector<uint16_t> depth_mm;   // cv::Mat depth_mm  (StaticFusion.h:71), rows x cols, row-major
+    std::vector<uint8_t> color_full;  // cv::Mat color_full (StaticFusion.h:71), rows x cols x 3
+    float depth_max = 4.5f;           // StaticFusion.h:77, FrontEnd.cpp:168
+
     // the drivers' ring buffer writes: depthBuffer[i%5] = depthCurrent; intensityBuffer[i%5] = ...;
     // odomBuffer[i%5] = T_odometry   (StaticFusion-datasets.cpp:182-184)
     void pushBuffers(int im_count) { check(sf_push_history(h_, im_count), "push_history"); }

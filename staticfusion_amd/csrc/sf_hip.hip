@@ -103,7 +103,6 @@ __global__ __launch_bounds__(SF_NT, 4) void sf_irls_pass_kernel(const KArgs *__r
             if (variant == 0) microbench_pass<1, 0>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
             if (variant == 1) microbench_pass<1, 1>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
             if (variant == 2) microbench_pass<1, 2>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
-            if (variant == 3) microbench_pass<1, 3>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
         } else {
             if (variant == 0) microbench_pass<2, 0>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
             if (variant == 1) microbench_pass<2, 1>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
@@ -806,7 +805,7 @@ int sf_get_stage_profile(sf_handle *h, int64_t ticks[24]) {
     return SF_OK;
 }
 int sf_microbench_pass(sf_handle *h, int which, int variant, int reps, float *elapsed_ms) {
-    if (!h || (which != 1 && which != 2) || variant < 0 || variant > 3 || reps < 1) return fail(SF_ERR_ARG, "bad argument");
+    if (!h || (which != 1 && which != 2) || variant < 0 || variant > 2 || reps < 1) return fail(SF_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemsetAsync(h->k.queue, 0, sizeof(int), h->stream));
     const int grid = std::min(h->k.batch, h->max_blocks);

@@ -44,5 +44,25 @@ int main(int argc, char **argv) {
     double dyn = 0;
     for (size_t q = 0; q < n; q++) dyn += staticFusion.b_segm_perpixel.data()[q] < 0.5f;
     std::printf("dynamic_fraction %.6f\n", dyn / double(n));
+
+    if (argc >= 3) {  // the drivers' input stage (StaticFusion-imagesequenceassoc.cpp:149,165) on a decoded VGA frame
+        FILE *g = std::fopen(argv[2], "rb");
+        if (!g) return 5;
+        const size_t full = size_t(480) * 640;
+        std::vector<uint8_t> color(full * 3);
+        std::vector<uint16_t> depth(full);
+        if (std::fread(color.data(), 1, full * 3, g) != full * 3 || std::fread(depth.data(), 2, full, g) != full) return 6;
+        std::fclose(g);
+        if (staticFusion.loadImageFromDecoded(color.data(), depth.data(), 2)) return 7;
+        staticFusion.getFilteredDepth();
+        double sum_d = 0, sum_i = 0;
+        unsigned long long sum_mm = 0;
+        for (size_t q = 0; q < n; q++) {
+            sum_d += staticFusion.depthCurrent.data()[q];
+            sum_i += staticFusion.intensityCurrent.data()[q];
+            sum_mm += staticFusion.depth_mm[q];
+        }
+        std::printf("input_stage %.9f %.9f %llu\n", sum_d, sum_i, sum_mm);
+    }
     return 0;
 }

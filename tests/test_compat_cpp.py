@@ -36,7 +36,16 @@ def test_compat_driver_matches_oracle(tmp_path, ora, pair):
     with open(blob, "wb") as f:
         for img in (pr["old"][0], pr["old"][1], pr["new"][0], pr["new"][1]):
             f.write(np.ascontiguousarray(img.T, dtype=np.float32).tobytes())  # column-major
-    out = subprocess.check_output([exe, str(blob)]).decode().split("\n")
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools", "golden"))
+    from make_golden_input import synth_frame
+
+    color, depth = synth_frame(480, 640, 77)
+    frame = tmp_path / "frame.bin"
+    with open(frame, "wb") as f:
+        f.write(color.tobytes())
+        f.write(depth.tobytes())
+    out = subprocess.check_output([exe, str(blob), str(frame)]).decode().split("\n")
     T = np.array([[float(x) for x in out[r].split()] for r in range(4)])
     dyn = float(out[4].split()[1])
     s = make_solver(ora, 240, 320, driver_params(ora), pr)
@@ -46,3 +55,13 @@ def test_compat_driver_matches_oracle(tmp_path, ora, pair):
     rot, trans = pose_delta(s.T(), T)
     assert rot <= 1e-4 and trans <= 1e-4
     assert dyn == pytest.approx(float((s.b_image() < 0.5).mean()), abs=1e-6)
+    # loadImageFromDecoded + getFilteredDepth through the class surface: the same images as the oracle's
+    so = make_solver(ora, 240, 320, driver_params(ora))
+    so.load_frame(0, color, depth, 2)
+    so.filter_depth()
+    d, i = so.current()
+    got = out[5].split()
+    assert got[0] == "input_stage"
+    assert float(got[1]) == pytest.approx(float(d.astype(np.float64).sum()), abs=1e-6)
+    assert float(got[2]) == pytest.approx(float(i.astype(np.float64).sum()), abs=1e-6)
+    assert int(got[3]) == int(so.input_image(0).astype(np.uint64).sum())

@@ -20,9 +20,7 @@ for b in range(a.batch):
 s.process_frame(0); s.synchronize()
 npx = 240 * 320
 for which in (1, 2):
-    for variant, name in ((0, "product"), (1, "loads only"), (2, "no accumulation"), (3, "fp32 accumulation")):
-        if which == 2 and variant == 3:
-            continue
+    for variant, name in ((0, "product"), (1, "loads only"), (2, "no accumulation")):
         s.microbench_pass(which, variant, 2)
         ms = s.microbench_pass(which, variant, a.reps)
         px = a.batch * a.reps * npx

@@ -21,7 +21,7 @@ for ev, val in cur.execute("select event_id, value from %s" % tab("rocpd_pmc_eve
     pmc[ev] += val
 mine = [d for d in disp if "sf_irls_pass_kernel" in names[d[1]]]
 # order of launches in pass_microbench.py: for pass in (1,2): variants (product, loads, noacc, [fp32]) x (2 reps warm, 10 reps timed)
-labels = ["p1 product", "p1 loads", "p1 noacc", "p1 fp32", "p2 product", "p2 loads", "p2 noacc"]
+labels = ["p1 product", "p1 loads", "p1 noacc", "p2 product", "p2 loads", "p2 noacc"]
 px = lambda reps: 512 * reps * 76800
 for k, d in enumerate(mine):
     reps = 2 if k % 2 == 0 else 10

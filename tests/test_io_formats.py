@@ -1,0 +1,205 @@
+"""On-disk formats either side of the path (include/sf_io.h, libsf_io.so):
+association file (reference FrontEnd.cpp:183-214), PNG frames as cv::imread delivers them to
+FrontEnd.cpp:220,240, trajectory lines (Utils/Datasets.cpp:252-265, Reconstruction.cpp:53-81).
+The C++ library against (i) the source arrays the test's own PNG encoder started from and
+(ii) the independent Python restatement oracle/io_oracle.py. Host-only: no GPU needed."""
+import os
+
+import numpy as np
+import pytest
+
+from png_util import encode_png
+from oracle import io_oracle
+from staticfusion_amd import io as sfio
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return sfio.Io()  # no fallback: a missing libsf_io.so is an error
+
+
+CASES = [  # (colour type, bit depth)
+    (0, 8), (0, 16), (0, 1), (0, 2), (0, 4), (2, 8), (2, 16), (3, 8), (3, 4), (4, 8), (6, 8), (6, 16),
+]
+
+
+def expected_bgr(samples, ct, bd, palette):
+    s = samples.astype(np.int64)
+    if ct == 3:
+        rgb = np.asarray(palette, np.uint8)[s[..., 0]]
+    else:
+        v = (s >> 8) if bd == 16 else ((s * 255 // ((1 << bd) - 1)) if (bd < 8 and ct == 0) else s)
+        rgb = np.repeat(v[..., :1], 3, axis=2) if ct in (0, 4) else v[..., :3]
+    return np.ascontiguousarray(rgb[..., ::-1]).astype(np.uint8)
+
+
+@pytest.mark.parametrize("ct,bd", CASES)
+def test_png_colour_decode_all_types_and_filters(lib, ct, bd):
+    rng = np.random.default_rng(100 * ct + bd)
+    h, w = 23, 37  # odd sizes: partial bytes for the sub-byte depths
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ct]
+    palette = rng.integers(0, 256, (min(256, 1 << bd), 3)) if ct == 3 else None
+    hi = len(palette) if ct == 3 else (1 << bd)
+    # smooth + noise so that every filter type produces non-trivial residuals
+    base = (np.add.outer(np.arange(h), np.arange(w))[..., None] * (hi // 64 + 1) + rng.integers(0, max(2, hi // 8), (h, w, ch))) % hi
+    png = encode_png(base, ct, bd, palette=palette, extra_chunks=[(b"gAMA", b"\x00\x00\xb1\x8f"), (b"tEXt", b"Comment\x00synthetic")])
+    exp = expected_bgr(base, ct, bd, palette)
+    assert np.array_equal(lib.decode_color(png), exp)
+    assert np.array_equal(io_oracle.decode_color(png), exp)
+
+
+def test_png_depth16_decode_and_files(lib, tmp_path):
+    rng = np.random.default_rng(5)
+    depth = (1500 + 40 * np.add.outer(np.arange(48), np.arange(64)) % 3000 + rng.integers(0, 9, (48, 64))).astype(np.uint16)
+    depth[5:9, 7:30] = 0
+    depth[0, 0], depth[0, 1] = 65535, 256  # both bytes matter: big-endian on disk, host order in memory
+    for filters in ((0,), (1,), (2,), (3,), (4,), (4, 1, 3, 2, 0)):
+        png = encode_png(depth, 0, 16, filters=filters, idat_split=5)
+        assert np.array_equal(lib.decode_depth16(png), depth)
+        assert np.array_equal(io_oracle.decode_depth16(png), depth)
+    p = tmp_path / "d.png"
+    p.write_bytes(encode_png(depth, 0, 16))
+    assert np.array_equal(lib.imread_depth16(str(p)), depth)
+    g8 = (depth >> 8).astype(np.uint8)
+    assert np.array_equal(lib.decode_depth16(encode_png(g8, 0, 8)), g8.astype(np.uint16))  # 8-bit grey is widened
+    rgb = rng.integers(0, 256, (48, 64, 3))
+    c = tmp_path / "c.png"
+    c.write_bytes(encode_png(rgb, 2, 8))
+    assert np.array_equal(lib.imread_color(str(c)), rgb[..., ::-1].astype(np.uint8))  # B G R like cv::imread
+    with pytest.raises(sfio.SfIoError):
+        lib.decode_depth16(encode_png(rgb, 2, 8))  # a colour image is not a depth image
+
+
+def test_png_errors(lib, tmp_path):
+    good = encode_png(np.arange(64, dtype=np.uint8).reshape(8, 8), 0, 8)
+    with pytest.raises(sfio.SfIoError):
+        lib.decode_color(b"JFIF" + good[4:])  # signature
+    bad = bytearray(good)
+    bad[40] ^= 0x55
+    with pytest.raises(sfio.SfIoError):
+        lib.decode_color(bytes(bad))  # CRC
+    with pytest.raises(sfio.SfIoError):
+        lib.decode_color(good[:-20])  # truncated
+    with pytest.raises(sfio.SfIoError):
+        lib.decode_color(encode_png(np.zeros((8, 8), np.uint8), 0, 8, interlace=1))  # Adam7: unsupported, reported
+    with pytest.raises(sfio.SfIoError):
+        lib.imread_color(str(tmp_path / "missing.png"))
+
+
+def test_assoc_file(lib, tmp_path):
+    d = str(tmp_path) + "/"
+    text = ("# color and depth association\n"
+            "\n"
+            "1305031102.175304 rgb/1305031102.175304.png 1305031102.160407 depth/1305031102.160407.png\n"
+            "1305031102.211214 rgb/1305031102.211214.png 1305031102.194330 depth/1305031102.194330.png\n"
+            "#1305031102.243211 rgb/skipped.png 1 depth/skipped.png\n"
+            "1305031102.275326   rgb/c.png\t1305031102.262886 depth/d.png   trailing tokens are ignored\n"
+            "not-a-number rgb/x.png 3 depth/x.png\n"
+            "1305031103.0 rgb/after_the_break.png 1305031103.0 depth/after_the_break.png\n")
+    (tmp_path / "rgbd_assoc.txt").write_text(text)
+    ts, fd, fc = lib.load_assoc(d, "rgbd_assoc.txt")
+    assert ts == [1305031102.160407, 1305031102.194330, 1305031102.262886]  # the DEPTH timestamps
+    assert fd == [d + "depth/1305031102.160407.png", d + "depth/1305031102.194330.png", d + "depth/d.png"]
+    assert fc == [d + "rgb/1305031102.175304.png", d + "rgb/1305031102.211214.png", d + "rgb/c.png"]
+    assert (ts, fd, fc) == io_oracle.load_assoc(d, "rgbd_assoc.txt")
+    with pytest.raises(sfio.SfIoError):
+        lib.load_assoc(d, "missing.txt")
+
+
+def random_pose(rng, angle_scale=3.0):
+    w = rng.normal(0, 1, 3)
+    w = w / np.linalg.norm(w) * rng.uniform(0, angle_scale)
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    R = np.eye(3) + (np.sin(th) / th) * K + ((1 - np.cos(th)) / th ** 2) * K @ K if th > 1e-9 else np.eye(3)
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = rng.normal(0, 2, 3)
+    return T.astype(np.float32)
+
+
+def test_trajectory_lines_and_pose_composition(lib):
+    rng = np.random.default_rng(11)
+    branches = set()
+    pose = np.eye(4, dtype=np.float32)
+    for k in range(300):
+        T = random_pose(rng, 3.1 if k % 3 else 0.05)
+        a, b = lib.pose_compose(pose, T), io_oracle.pose_compose(pose, T)
+        assert np.array_equal(a, b)
+        pose = a if k % 50 else np.eye(4, dtype=np.float32)
+        tr = np.trace(pose[:3, :3])
+        branches.add(bool(tr > 0))
+        ts = 1305031102.0 + 0.033 * k
+        for rot in (0, 1):
+            assert lib.trajectory_line(ts, pose, rot) == io_oracle.trajectory_line(ts, pose, rot), (k, rot)
+    assert branches == {True, False}  # both quaternion branches of Eigen's conversion were exercised
+    line = lib.trajectory_line(12.5, np.eye(4, dtype=np.float32), 0)
+    assert line == "12.500000 0 0 0 0 0 0 1\n"
+    z = lib.trajectory_line(12.5, np.eye(4, dtype=np.float32), 1).split()
+    assert z[0] == "12.5000" and abs(float(z[6])) == 1.0 and abs(float(z[7])) < 1e-7  # identity * Rz(pi): q = (0, 0, +-1, ~0)
+
+
+# ------------------------------------------------------------------------------------------------
+#  end to end: a synthetic dataset on disk -> loader -> input stage -> solver -> trajectory file
+# ------------------------------------------------------------------------------------------------
+def write_dataset(root, n_frames, sphere=True):
+    """TUM-style directory of a synthetic walk (the reference README.md:67-89 layout); returns the ground-truth poses."""
+    from staticfusion_amd.synth import DEFAULT_XI, Scene, se3_exp
+
+    os.makedirs(os.path.join(root, "rgb"))
+    os.makedirs(os.path.join(root, "depth"))
+    scene = Scene(seed=77, sphere=sphere)
+    xi = np.array(DEFAULT_XI) * 0.6
+    T, gts, lines = np.eye(4), [], ["# color depth association, synthetic"]
+    for k in range(n_frames):
+        depth, inten = scene.render(T, 640, 480, sphere_offset=(0.02 * k, 0, 0))
+        d_mm = np.clip(np.rint(depth * 1000.0), 0, 65535).astype(np.uint16)
+        g8 = np.clip(np.rint(inten * 255.0), 0, 255).astype(np.uint8)
+        t = 1305031102.0 + k / 30.0
+        # the loader flips vertically (FrontEnd.cpp:231): store the frames upside down so that it sees them upright
+        open(os.path.join(root, "rgb", "%.6f.png" % t), "wb").write(encode_png(np.repeat(g8[::-1, :, None], 3, axis=2), 2, 8))
+        open(os.path.join(root, "depth", "%.6f.png" % t), "wb").write(encode_png(d_mm[::-1], 0, 16))
+        lines.append("%.6f rgb/%.6f.png %.6f depth/%.6f.png" % (t, t, t, t))
+        gts.append(T.copy())
+        T = T @ se3_exp(xi)
+    open(os.path.join(root, "rgbd_assoc.txt"), "w").write("\n".join(lines) + "\n")
+    return gts
+
+
+def test_sequence_runner_on_the_oracle_tiny(ora, lib, tmp_path):
+    """CPU-sized: 3 frames through loadAssoc -> PNG -> loader -> bilateral filter -> solver -> trajectory lines."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from run_sequence import run
+    from staticfusion_amd.synth import pose_delta
+
+    root = str(tmp_path / "ds")
+    gts = write_dataset(root, 3)
+    poses, lines, _ = run(ora, lib, root, out_path=str(tmp_path / "traj.txt"))
+    assert len(poses) == 3 and open(str(tmp_path / "traj.txt")).read() == "".join(lines)
+    for k in range(1, 3):  # tracks the synthetic camera (frame-to-frame, quantised, filtered input): centimetre / 0.1 deg level
+        rot, trans = pose_delta(poses[k], gts[k])
+        assert rot < 5e-3 and trans < 1.5e-2, (k, rot, trans)
+    assert lines[0].split()[1:] == ["0", "0", "0", "0", "0", "0", "1"]
+
+
+@pytest.mark.gpu
+def test_sequence_runner_hip_vs_oracle(hip, ora, lib, tmp_path):
+    """8 frames from disk on MI355X: the per-frame pose is the CPU path's (<= 1e-4), the trajectory files agree."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from run_sequence import run
+    from staticfusion_amd.synth import pose_delta
+
+    root = str(tmp_path / "ds")
+    gts = write_dataset(root, 8)
+    pg, lg, sg = run(hip, lib, root)
+    po, lo, so = run(ora, lib, root)
+    for k in range(8):
+        rot, trans = pose_delta(po[k], pg[k])
+        assert rot <= 1e-4 and trans <= 1e-4, (k, rot, trans)
+    assert np.array_equal(sg.labels(0), so.labels(0))  # cluster labels of the last frame: bit exact
+    for a, b in zip(lg, lo):  # 6 significant digits printed
+        assert np.allclose([float(x) for x in a.split()], [float(x) for x in b.split()], rtol=0, atol=2e-5)
+    rot, trans = pose_delta(pg[7], gts[7])
+    assert rot < 2e-2 and trans < 5e-2

@@ -1,0 +1,78 @@
+"""The reference's image-sequence driver (StaticFusion-imagesequenceassoc.cpp:57-191) over the C ABIs of this
+repository, in FRAME-TO-FRAME mode: the prediction is the previous (filtered) frame instead of a rendering of
+the OpenGL surfel map, which is out of scope (mode (a)).
+
+  dataset/rgb/*.png  dataset/depth/*.png  dataset/rgbd_assoc.txt      (reference README.md:67-89)
+
+usage: python tools/run_sequence.py <dataset dir> [--out trajectory.txt] [--max-frames N] [--res-factor 2]
+Writes one `timestamp tx ty tz qx qy qz qw` line per frame (the .freiburg format of Reconstruction.cpp:53-81).
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+
+def run(api, io, directory, assoc_file="rgbd_assoc.txt", res_factor=2, max_frames=None, out_path=None, filter_first=False):
+    """api: an include/sf.h implementation (staticfusion_amd.load() or the test oracle); io: staticfusion_amd.io.Io()."""
+    import staticfusion_amd as sf
+
+    if not directory.endswith("/"):
+        directory += "/"
+    ts, files_depth, files_color = io.load_assoc(directory, assoc_file)  # loadAssoc, :96
+    if max_frames is not None:
+        ts, files_depth, files_color = ts[:max_frames], files_depth[:max_frames], files_color[:max_frames]
+    if not ts:
+        raise RuntimeError("empty association file")
+    color, depth = io.imread_color(files_color[0]), io.imread_depth16(files_depth[0])
+    rows, cols = depth.shape[0] // res_factor, depth.shape[1] // res_factor
+    p = api.default_params_struct()  # the drivers' parameter block, StaticFusion-imagesequenceassoc.cpp:62-79
+    s = sf.Solver(api, rows, cols, 1, p)
+    pose = np.eye(4, dtype=np.float32)
+    poses, lines = [pose.copy()], [io.trajectory_line(ts[0], pose, 0)]
+    # bootstrap (:102-137): the first frame becomes the prediction; kb = 1.05 until the model is dense (:152-163) --
+    # without a map, every frame is "not dense": kb stays 1.05
+    s.load_frame(0, color, depth, res_factor)
+    if filter_first:
+        s.filter_depth()
+    s.current_to_prediction()
+    s.push_history(0)
+    s.set_kb(1.05)
+    for k in range(1, len(ts)):
+        color, depth = io.imread_color(files_color[k]), io.imread_depth16(files_depth[k])  # loadImageFromSequenceAssoc, :149
+        s.load_frame(0, color, depth, res_factor)
+        s.filter_depth()      # reconstruction->getFilteredDepth(depth_mm, depthCurrent), :165
+        s.process_frame(k)    # createImagePyramid(true); runSolver(true); residuals (k >= 5); buildSegmImage; ring push, :167-179
+        pose = io.pose_compose(pose, s.T())  # currPose = currPose * T_odometry, Reconstruction.cpp:265
+        poses.append(pose.copy())
+        lines.append(io.trajectory_line(ts[k], pose, 0))
+        s.current_to_prediction()  # frame-to-frame mode
+    if out_path:
+        with open(out_path, "w") as f:
+            f.writelines(lines)
+    return poses, lines, s
+
+
+def main():
+    import staticfusion_amd as sf
+    from staticfusion_amd import io as sfio
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dataset")
+    ap.add_argument("--assoc", default="rgbd_assoc.txt")
+    ap.add_argument("--out", default="trajectory.freiburg")
+    ap.add_argument("--max-frames", type=int, default=None)
+    ap.add_argument("--res-factor", type=int, default=2)
+    a = ap.parse_args()
+    if not os.path.isdir(a.dataset):
+        print("dataset absent: %s (no datasets ship with this repository; see SURVEY.md §8(d) config 1)" % a.dataset)
+        return 2
+    poses, lines, _ = run(sf.load(), sfio.Io(), a.dataset, a.assoc, a.res_factor, a.max_frames, a.out)
+    print("%d frames -> %s" % (len(poses), a.out))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -203,3 +203,17 @@ def test_sequence_runner_hip_vs_oracle(hip, ora, lib, tmp_path):
         assert np.allclose([float(x) for x in a.split()], [float(x) for x in b.split()], rtol=0, atol=2e-5)
     rot, trans = pose_delta(pg[7], gts[7])
     assert rot < 2e-2 and trans < 5e-2
+
+
+def test_io_header_matches_library_exports():
+    """every function include/sf_io.h declares is exported by libsf_io.so and bound by staticfusion_amd/io.py -- and nothing else"""
+    import re
+    import subprocess
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    hdr = open(os.path.join(root, "include", "sf_io.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(sf_io_\w+)\s*\(", hdr)))
+    assert declared == sorted(sfio.SIGNATURES.keys())
+    out = subprocess.check_output(["nm", "-D", "--defined-only", sfio.LIB]).decode()
+    assert set(re.findall(r" T (sf_io_\w+)", out)) == set(declared)

@@ -267,7 +267,10 @@ int SF_FN(get_stage_profile)(sf_handle *h, int64_t ticks[24]);
 /* The IRLS streaming passes in isolation: `reps` executions of pass `which` (1 = weights + normal
  * equations, 2 = residuals + label sums) over the level-0 records of every stream left by the last
  * solve, one launch of sf_irls_pass_kernel. variant 0 = product code; 1 = loads only; 2 = no
- * accumulation (ablations). Elapsed HIP-event milliseconds of the launch. Not part of a solve. */
+ * accumulation (ablations); variant | (S << 8) splits every level into S pixel ranges walked by S different
+ * workgroups (how fast the passes run when fewer streams are in flight and their records stay in the
+ * Infinity Cache; an experiment, partial sums are not combined). Elapsed HIP-event milliseconds of the
+ * launch. Not part of a solve. */
 int SF_FN(microbench_pass)(sf_handle *h, int which, int variant, int reps, float *elapsed_ms);
 /* Elapsed ms of the most recent solver kernel launch (HIP events around that launch). */
 int SF_FN(last_solver_kernel_ms)(sf_handle *h, float *ms);

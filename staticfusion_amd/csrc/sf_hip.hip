@@ -81,7 +81,7 @@ __global__ __launch_bounds__(SF_NT, 4) void sf_frame_kernel(const KArgs *__restr
 }
 
 // the IRLS passes alone (measurement support; never part of a solve)
-__global__ __launch_bounds__(SF_NT, 4) void sf_irls_pass_kernel(const KArgs *__restrict__ ka, int which, int variant, int reps) {
+__global__ __launch_bounds__(SF_NT, 4) void sf_irls_pass_kernel(const KArgs *__restrict__ ka, int which, int variant, int reps, int slices) {
     __shared__ FrameShared sh;
     __shared__ int s_next;
     const KArgs &a = *ka;
@@ -90,8 +90,9 @@ __global__ __launch_bounds__(SF_NT, 4) void sf_irls_pass_kernel(const KArgs *__r
     for (;;) {
         if (tid == 0) s_next = atomicAdd(a.queue, 1);
         __syncthreads();
-        const int b = __builtin_amdgcn_readfirstlane(s_next);
+        const int item = __builtin_amdgcn_readfirstlane(s_next);
         __syncthreads();
+        const int b = item / slices, slice = item - b * slices;
         if (b >= a.batch) {
             if (tid == 0 && blockIdx.x == 0) {  // shader clock estimate: s_memtime ticks per 100 MHz tick
                 a.state[0].prof[22] = clock64() - c0;
@@ -100,13 +101,13 @@ __global__ __launch_bounds__(SF_NT, 4) void sf_irls_pass_kernel(const KArgs *__r
             break;
         }
         if (which == 1) {
-            if (variant == 0) microbench_pass<1, 0>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
-            if (variant == 1) microbench_pass<1, 1>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
-            if (variant == 2) microbench_pass<1, 2>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
+            if (variant == 0) microbench_pass<1, 0>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
+            if (variant == 1) microbench_pass<1, 1>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
+            if (variant == 2) microbench_pass<1, 2>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
         } else {
-            if (variant == 0) microbench_pass<2, 0>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
-            if (variant == 1) microbench_pass<2, 1>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
-            if (variant == 2) microbench_pass<2, 2>(a, b, reps, *(LDS SolveShared *)&sh.sv, tid);
+            if (variant == 0) microbench_pass<2, 0>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
+            if (variant == 1) microbench_pass<2, 1>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
+            if (variant == 2) microbench_pass<2, 2>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
         }
         __syncthreads();
     }
@@ -805,12 +806,14 @@ int sf_get_stage_profile(sf_handle *h, int64_t ticks[24]) {
     return SF_OK;
 }
 int sf_microbench_pass(sf_handle *h, int which, int variant, int reps, float *elapsed_ms) {
-    if (!h || (which != 1 && which != 2) || variant < 0 || variant > 2 || reps < 1) return fail(SF_ERR_ARG, "bad argument");
+    const int slices = (variant >> 8) ? (variant >> 8) : 1;  // bits 8.. of `variant`: workgroups per stream (experiment)
+    variant &= 255;
+    if (!h || (which != 1 && which != 2) || variant < 0 || variant > 2 || reps < 1 || slices > 64) return fail(SF_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemsetAsync(h->k.queue, 0, sizeof(int), h->stream));
-    const int grid = std::min(h->k.batch, h->max_blocks);
+    const int grid = std::min(h->k.batch * slices, h->max_blocks);
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(sf_irls_pass_kernel, dim3(grid), dim3(SF_NT), 0, h->stream, (const KArgs *)h->d_args, which, variant, reps);
+    hipLaunchKernelGGL(sf_irls_pass_kernel, dim3(grid), dim3(SF_NT), 0, h->stream, (const KArgs *)h->d_args, which, variant, reps, slices);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev1));

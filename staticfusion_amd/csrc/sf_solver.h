@@ -58,6 +58,7 @@ struct SolveShared {
     // IRLS
     float AtA[36], AtB[6], Var[6], prev_sol[6];
     float aver_res, aver_res_old, inv_max_c, inv_max_d, res_sqnorm;
+    int px_begin, px_end;  // pixel range of the level the streaming passes walk (the whole level in the product)
     double init_abs_c, init_abs_d;  // sum of wc |dct| and wd |ddt| over validPixels (raw pre-weights), from the linearisation
     int n_valid, ctrl, status, n_irls, n_outer, first;
     long long pixel_iters;
@@ -753,8 +754,9 @@ __device__ __forceinline__ bool sanitize(RecVec<VEC> &r, int j) {
 struct IrlsCtx {
     RecPtrs rp;
     LevelGeom g;
-    int n;  // pixels of the level
-    int N;  // valid pixels
+    int n;       // end of the pixel range of this workgroup (the level size in the product)
+    int begin;   // start of the range (0 in the product; tools/pass_microbench.py --slices splits a level)
+    int N;       // valid pixels
 };
 
 __device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, const LDS SolveShared &s) {
@@ -764,7 +766,8 @@ __device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, c
     for (int q = 0; q < R_COUNT; q++) c.rp.p[q] = uniform_ptr((gcfloat *)(a.rec[q] + rb));
     c.rp.dnew = uniform_ptr((gcfloat *)(a.pyr_new[0] + (size_t)b * a.n_tot + a.loff[L]));
     c.rp.lab = uniform_ptr((gcu8 *)(a.rec_lab + rb));
-    c.n = a.ln[L];
+    c.n = uniform_i(s.px_end);
+    c.begin = uniform_i(s.px_begin);
     c.N = uniform_i(s.n_valid);
     const int rows_i = a.lrows[L], cols_i = a.lcols[L];
     const float f = float(cols_i) / (2.f * a.tan_half_fovh);
@@ -820,8 +823,8 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, LDS SolveS
     for (int q = 0; q < 6; q++) Vr[q] = uniform_f(s.Var[q]);
     const int last = (c.n - 2) & ~1;  // the prefetch past the end re-reads the last pair instead of branching
     RecVec<2> rv, nx;
-    if (tid * 2 < c.n) load_rec<2>(c.rp, tid * 2, rv);
-    for (int i0 = tid * 2; i0 < c.n; i0 += SF_NT * 2) {
+    if (c.begin + tid * 2 < c.n) load_rec<2>(c.rp, c.begin + tid * 2, rv);
+    for (int i0 = c.begin + tid * 2; i0 < c.n; i0 += SF_NT * 2) {
         load_rec<2>(c.rp, min(i0 + SF_NT * 2, last), nx);
         const bool ok0 = sanitize<2>(rv, 0), ok1 = sanitize<2>(rv, 1);
         if constexpr (VAR == 1) {
@@ -953,8 +956,8 @@ __device__ __noinline__ void irls_pass2(const KArgs &a, int b, int L, LDS SolveS
     unsigned long long cur_sum = 0;
     const int last = (c.n - 2) & ~1;
     RecVec<2> rv, nx;
-    if (tid * 2 < c.n) load_rec<2>(c.rp, tid * 2, rv);
-    for (int i0 = tid * 2; i0 < c.n; i0 += SF_NT * 2) {
+    if (c.begin + tid * 2 < c.n) load_rec<2>(c.rp, c.begin + tid * 2, rv);
+    for (int i0 = c.begin + tid * 2; i0 < c.n; i0 += SF_NT * 2) {
         load_rec<2>(c.rp, min(i0 + SF_NT * 2, last), nx);  // next pair in flight during this one
         const bool ok0 = sanitize<2>(rv, 0), ok1 = sanitize<2>(rv, 1);
         if constexpr (VAR == 1) {
@@ -1097,6 +1100,10 @@ __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level,
     if (tid < 6) {
         s.Var[tid] = 0.f;
         s.prev_sol[tid] = 0.f;
+    }
+    if (tid == 0) {
+        s.px_begin = 0;
+        s.px_end = a.ln[L];
     }
     __syncthreads();
 
@@ -1262,7 +1269,7 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, LDS SolveShared 
 //  last solve left behind (tools/pass_microbench.py, sf_microbench_pass)
 // ---------------------------------------------------------------------------------------------
 template <int WHICH, int VAR>
-__device__ void microbench_pass(const KArgs &a, int b, int reps, LDS SolveShared &s, int tid) {
+__device__ void microbench_pass(const KArgs &a, int b, int slice, int slices, int reps, LDS SolveShared &s, int tid) {
     const StreamState &st = a.state[b];
     if (tid < SF_NC) s.b_segm[tid] = a.p.segmentation_enabled ? st.b_segm[tid] : 1.f;
     if (tid < 6) s.Var[tid] = st.twist_level[tid];
@@ -1272,6 +1279,9 @@ __device__ void microbench_pass(const KArgs &a, int b, int reps, LDS SolveShared
         s.aver_res = 0.002f;
         s.first = 0;
         s.n_valid = a.ln[0];
+        const int per = ((a.ln[0] / slices) + 1) & ~1;  // even: the passes walk pixel pairs
+        s.px_begin = slice * per;
+        s.px_end = (slice == slices - 1) ? a.ln[0] : min(a.ln[0], (slice + 1) * per);
     }
     if (tid < SF_NC) s.lab_sum[tid] = 0;
     __syncthreads();

@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--workload", default="static")
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--slices", type=int, default=1, help="workgroups per stream (experiment: records resident in the Infinity Cache)")
 a = ap.parse_args()
 api = sf.load()
 p = bench.make_params(api, a.workload)
@@ -21,8 +22,8 @@ s.process_frame(0); s.synchronize()
 npx = 240 * 320
 for which in (1, 2):
     for variant, name in ((0, "product"), (1, "loads only"), (2, "no accumulation")):
-        s.microbench_pass(which, variant, 2)
-        ms = s.microbench_pass(which, variant, a.reps)
+        s.microbench_pass(which, variant | (a.slices << 8), 2)
+        ms = s.microbench_pass(which, variant | (a.slices << 8), a.reps)
         px = a.batch * a.reps * npx
         print("pass %d %-16s %8.3f ms  %6.2f Gpx/s  streamed(29 B/px) %7.1f GB/s  algorithmic(30 B/px/pass) %7.1f GB/s" % (
             which, name, ms, px / ms / 1e6, 29.0 * px / ms / 1e6, 30.0 * px / ms / 1e6))

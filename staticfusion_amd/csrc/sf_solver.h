@@ -89,49 +89,6 @@ struct SolveShared {
 //  Jacobian rows of one pixel (reference FrontEnd.cpp:544-585). Expressions keep the reference's
 //  association; the build uses -ffp-contract=off.
 // ---------------------------------------------------------------------------------------------
-// T is float (one pixel) or vfloat2 (a pixel pair: the f32 arithmetic then compiles to packed
-// v_pk_mul/add/fma_f32, two pixels per VALU instruction, same IEEE results per component).
-
-__device__ __forceinline__ float vabs(float x) { return fabsf(x); }
-__device__ __forceinline__ vfloat2 vabs(vfloat2 x) { return vfloat2{fabsf(x.x), fabsf(x.y)}; }
-__device__ __forceinline__ float vsqrt(float x) { return sqrtf(x); }
-__device__ __forceinline__ vfloat2 vsqrt(vfloat2 x) { return vfloat2{sqrtf(x.x), sqrtf(x.y)}; }
-__device__ __forceinline__ float vrcp1(float x) { return 1.f / x; }
-__device__ __forceinline__ vfloat2 vrcp1(vfloat2 x) { return vfloat2{1.f / x.x, 1.f / x.y}; }  // IEEE division per component
-
-template <class T>
-struct PixRowsT {
-    T ac[6], bc, ad[6], bd;
-};
-typedef PixRowsT<float> PixRows;
-
-template <class T>
-__device__ __forceinline__ void build_rows(T d, T x, T y, T dcu_, T dcv_, T dct_, T ddu_, T ddv_, T ddt_, T wc_norm,
-                                           T wd_norm, float f_inv, float k_photometric_res, PixRowsT<T> &r) {
-    const T inv_d = vrcp1(d);
-    const T dycomp_c = dcu_ * f_inv * inv_d;
-    const T dzcomp_c = dcv_ * f_inv * inv_d;
-    const T twc = wc_norm * k_photometric_res;
-    r.ac[0] = twc * (-dycomp_c);
-    r.ac[1] = twc * (-dzcomp_c);
-    r.ac[2] = twc * (dycomp_c * x * inv_d + dzcomp_c * y * inv_d);
-    r.ac[3] = twc * (dycomp_c * inv_d * y * x + dzcomp_c * (y * y * inv_d + d));
-    r.ac[4] = twc * (-dycomp_c * (x * x * inv_d + d) - dzcomp_c * inv_d * y * x);
-    r.ac[5] = twc * (dycomp_c * y - dzcomp_c * x);
-    r.bc = twc * (-dct_);
-
-    const T dycomp_d = ddu_ * f_inv * inv_d;
-    const T dzcomp_d = ddv_ * f_inv * inv_d;
-    const T twd = wd_norm;
-    r.ad[0] = twd * (-dycomp_d);
-    r.ad[1] = twd * (-dzcomp_d);
-    r.ad[2] = twd * (1.f + dycomp_d * x * inv_d + dzcomp_d * y * inv_d);
-    r.ad[3] = twd * (y + dycomp_d * inv_d * y * x + dzcomp_d * (y * y * inv_d + d));
-    r.ad[4] = twd * (-x - dycomp_d * (x * x * inv_d + d) - dzcomp_d * inv_d * y * x);
-    r.ad[5] = twd * (dycomp_d * y - dzcomp_d * x);
-    r.bd = twd * (-ddt_);
-}
-
 // Records are read through GLOBAL address-space pointers (global_load_*, not flat_load_*) and
 // SF_VEC consecutive pixels per lane (8- or 16-byte loads: more bytes in flight per wave).
 #define SF_VEC 2  // pixels per lane and iteration in the streaming passes (pixel pairs -> packed f32 math)
@@ -220,51 +177,6 @@ __device__ __forceinline__ void split_index(const LevelGeom &g, int idx, float &
     if ((u + 1) * g.rows_i <= idx) u++;
     fu = float(u);
     fv = float(idx - u * g.rows_i);
-}
-
-// The two Jacobian rows of a pixel (or pixel pair) from its record. Every expression below repeats,
-// with the same association, what the linearisation / the reference computes for this pixel
-// (calculateCoord :403-407, warp :883-884, pyramid :385-386, derivatives :478, weights :494-501).
-template <class T>
-__device__ __forceinline__ void rows_from_record(const LevelGeom &g, T fu, T fv, T dn, T dw, T dcu_, T dcv_, T dct_,
-                                                 T ddu_, T ddv_, PixRowsT<T> &out) {
-    const T xn = (g.inv_f_pyr * (fu - g.disp_u_i)) * dn;
-    const T yn = (g.inv_f_pyr * (fv - g.disp_v_i)) * dn;
-    T xw, yw;
-    if (g.first) {
-        xw = (g.inv_f_pyr * (fu - g.disp_u_i)) * dw;
-        yw = (g.inv_f_pyr * (fv - g.disp_v_i)) * dw;
-    } else {
-        xw = (fu - g.disp_u_i) * dw * g.inv_f_w;
-        yw = (fv - g.disp_v_i) * dw * g.inv_f_w;
-    }
-    const T d_i = 0.5f * (dn + dw);
-    const T x_i = 0.5f * (xn + xw);
-    const T y_i = 0.5f * (yn + yw);
-    const T ddt_ = dn - dw;
-    const T error_l_c = 10.f * (vabs(dct_) + vabs(dcu_) + vabs(dcv_));
-    const T error_l_d = 200.f * (vabs(ddt_) + vabs(ddu_) + vabs(ddv_));
-    const T wc = vsqrt(vrcp1(1.f + error_l_c));
-    const T wd = vsqrt(vrcp1(0.01f + error_l_d));
-    build_rows<T>(d_i, x_i, y_i, dcu_, dcv_, dct_, ddu_, ddv_, ddt_, g.inv_max_c * wc, g.inv_max_d * wd, g.f_inv, g.kph, out);
-}
-__device__ __forceinline__ vfloat2 pair_of(const float (&v)[2]) { return vfloat2{v[0], v[1]}; }
-
-// rows of the pixel pair (idx0, idx0 + 1) held in a RecVec<2>
-__device__ __forceinline__ void rows_of_pair(const RecVec<2> &r, int idx0, const LevelGeom &g, PixRowsT<vfloat2> &out) {
-    float fu0, fv0, fu1, fv1;
-    split_index(g, idx0, fu0, fv0);
-    split_index(g, idx0 + 1, fu1, fv1);
-    rows_from_record<vfloat2>(g, vfloat2{fu0, fu1}, vfloat2{fv0, fv1}, pair_of(r.dn), pair_of(r.v[R_DW]), pair_of(r.v[R_DCU]),
-                              pair_of(r.v[R_DCV]), pair_of(r.v[R_DCT]), pair_of(r.v[R_DDU]), pair_of(r.v[R_DDV]), out);
-}
-
-// res = -B; res += Var(k)*A(k), k = 0..5   (reference FrontEnd.cpp:644-646)
-__device__ __forceinline__ float residual(const float a[6], float bb, const volatile float *Var) {
-    float res = -bb;
-#pragma unroll
-    for (int k = 0; k < 6; k++) res += Var[k] * a[k];
-    return res;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -642,26 +554,17 @@ __device__ __noinline__ void solve_filter_and_update(const KArgs &a, LDS SolveSh
 }
 
 // ---------------------------------------------------------------------------------------------
-//  Factored form of the two Jacobian rows (SF_FACTORED_IRLS, default).  With
+//  Factored form of the two Jacobian rows.  With
 //     g1 = [-1, 0, x/d, xy/d, -(x^2/d + d),  y],  g2 = [0, -1, y/d, y^2/d + d, -xy/d, -x],  g3 = [0, 0, 1, y, -x, 0]
 //  the reference's rows (FrontEnd.cpp:552-585) are  a_c = pc g1 + qc g2,  a_d = twd g3 + pd g1 + qd g2,
 //  b_c = -bct, b_d = -bdt  with pc = twc dcu f/d, qc = twc dcv f/d, pd = twd ddu f/d, qd = twd ddv f/d,
 //  bct = twc dct, bdt = twd ddt.  Residuals then need three 6-term dot products with the solution instead
 //  of twelve row entries, and the weighted rows of pass 1 are built from (w pc, w qc, ...) directly.
 //  Same mathematics, different rounding association than the reference's expression order (~1e-7
-//  relative on a row entry); the pre-weights, 1/d and the Cauchy weights stay IEEE-exact.
-//  -DSF_FACTORED_IRLS=0 builds the passes with the reference's expression order instead.
+//  relative on a row entry).
 // ---------------------------------------------------------------------------------------------
-#ifndef SF_FACTORED_IRLS
-#define SF_FACTORED_IRLS 1
-#endif
-
+__device__ __forceinline__ float vabs(float x) { return fabsf(x); }
 __device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a, b, c); }
-__device__ __forceinline__ vfloat2 vfma(vfloat2 a, vfloat2 b, vfloat2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ vfloat2 vfma(float a, vfloat2 b, vfloat2 c) { return __builtin_elementwise_fma(vfloat2{a, a}, b, c); }
-__device__ __forceinline__ vfloat2 vfma(vfloat2 a, float b, vfloat2 c) { return __builtin_elementwise_fma(a, vfloat2{b, b}, c); }
-__device__ __forceinline__ vfloat2 vfma(vfloat2 a, vfloat2 b, float c) { return __builtin_elementwise_fma(a, b, vfloat2{c, c}); }
-__device__ __forceinline__ vfloat2 vfma(vfloat2 a, float b, float c) { return __builtin_elementwise_fma(a, vfloat2{b, b}, vfloat2{c, c}); }
 
 // Per-pixel IRLS weights use the hardware reciprocal / reciprocal-square-root (1 ulp) instead of the
 // IEEE division + square root sequences (~10 VALU instructions each; pass 1 is VALU-bound). The
@@ -672,16 +575,13 @@ __device__ __forceinline__ vfloat2 vfma(vfloat2 a, float b, float c) { return __
 #endif
 #if SF_FAST_WEIGHTS
 __device__ __forceinline__ float vrsq(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ vfloat2 vrsq(vfloat2 x) { return vfloat2{__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)}; }
 __device__ __forceinline__ float vrcpw(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ vfloat2 vrcpw(vfloat2 x) { return vfloat2{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
 #else
 __device__ __forceinline__ float vrsq(float x) { return sqrtf(1.f / x); }
-__device__ __forceinline__ vfloat2 vrsq(vfloat2 x) { return vsqrt(vrcp1(x)); }
 __device__ __forceinline__ float vrcpw(float x) { return 1.f / x; }
-__device__ __forceinline__ vfloat2 vrcpw(vfloat2 x) { return vrcp1(x); }
 #endif
 
+// T = float: one pixel per lane and step (packed pixel pairs buy nothing on gfx950, §5.1 of DESIGN.md)
 template <class T>
 struct PixFact {
     T x, y, xd, yd, xyd, xxd, yyd;  // geometry: x, y, x/d, y/d, xy/d, x^2/d + d, y^2/d + d

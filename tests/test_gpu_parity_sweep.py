@@ -1,0 +1,88 @@
+"""More GPU parity: a randomised parameter sweep, a 30-frame sequence through the input stage with
+carried solver state, and the bench-size batch (every duplicate stream bit-identical)."""
+import numpy as np
+import pytest
+
+from conftest import config2_params, driver_params, make_solver
+from staticfusion_amd import capi
+from staticfusion_amd.synth import DEFAULT_XI, LCG64, Scene, pose_delta, se3_exp
+from test_gpu_parity import POSE_TOL, assert_traces_match, solve_both
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_random_parameter_sweep(hip, ora, pair, case):
+    """parameters drawn from the ranges the drivers / constructor use (StaticFusion-datasets.cpp:79-94, FrontEnd.cpp:57-76)"""
+    g = LCG64(9000 + case)
+    u = lambda lo, hi: lo + (hi - lo) * g.uniform()
+    sphere = case % 2 == 0
+    over = dict(ctf_levels=2 + int(u(0, 2.999)), max_iter_per_level=1 + int(u(0, 2.999)), max_iter_irls=2 + int(u(0, 8.999)),
+                use_motion_filter=int(u(0, 1.999)), segmentation_enabled=1 if sphere else int(u(0, 1.999)),
+                irls_delta_threshold=float(10 ** u(-6, -2.5)), kc_Cauchy=float(u(0.3, 1.0)), kz=float(u(1.0, 2.0)),
+                lambda_reg=float(u(0.1, 0.6)), lambda_prior=float(u(0.2, 0.8)), k_photometric_res=float(u(0.08, 0.3)),
+                previous_speed_const_weight=float(u(0.02, 0.2)), previous_speed_eig_weight=float(u(0.3, 2.5)))
+    kb = float(u(1.0, 1.6))
+    xi = tuple(float(u(0.4, 1.6)) * np.array(DEFAULT_XI))
+    pr = pair(seed=300 + case, sphere=sphere, rows=120, cols=160, xi=xi)
+    sg, so = solve_both(hip, ora, 120, 160, lambda a: driver_params(a, kb=kb, **over), pr)
+    assert_traces_match(sg, so, tol_twist=5e-6, tol_b=5e-4, rtol_aver=1e-3)
+    rot, trans = pose_delta(so.T(), sg.T())
+    assert rot <= POSE_TOL and trans <= POSE_TOL
+    for L in range(sg.levels):
+        assert np.array_equal(sg.labels(L), so.labels(L))
+    assert np.array_equal(sg.b_image() > 0.5, so.b_image() > 0.5)
+
+
+def test_sequence_through_the_input_stage(hip, ora):
+    """30 decoded VGA frames: loader + bilateral filter + the solver with carried state (twist_old, b, 5-frame
+    ring, residual check from frame 5 on), frame-to-frame mode. Per-frame pose parity and the drift of the
+    accumulated trajectory between the two implementations."""
+    scene = Scene(seed=4242, sphere=True)
+    g = LCG64(77)
+    T, frames = np.eye(4), []
+    xi = np.array(DEFAULT_XI) * 0.5
+    for k in range(30):  # smooth random walk of the twist
+        xi = 0.85 * xi + 0.15 * np.array(DEFAULT_XI) * np.array([g.uniform(-1.5, 1.5) for _ in range(6)])
+        depth, inten = scene.render(T, 640, 480, sphere_offset=(0.015 * k, 0.0, 0.004 * k))
+        d_mm = np.clip(np.rint(depth * 1000.0), 0, 65535).astype(np.uint16)
+        g8 = np.clip(np.rint(inten * 255.0), 0, 255).astype(np.uint8)
+        frames.append((np.ascontiguousarray(np.repeat(g8[::-1, :, None], 3, axis=2)), np.ascontiguousarray(d_mm[::-1])))
+        T = T @ se3_exp(xi)
+    solvers = [make_solver(api, 240, 320, driver_params(api, kb=1.05)) for api in (hip, ora)]
+    acc = [np.eye(4), np.eye(4)]
+    for s in solvers:
+        s.load_frame(0, *frames[0], 2)
+        s.filter_depth()
+        s.current_to_prediction()
+        s.push_history(0)
+    for k in range(1, 30):
+        for i, s in enumerate(solvers):
+            s.load_frame(0, *frames[k], 2)
+            s.filter_depth()
+            s.process_frame(k)
+            acc[i] = acc[i] @ s.T().astype(np.float64)
+            s.current_to_prediction()
+        sg, so = solvers
+        rot, trans = pose_delta(so.T(), sg.T())
+        assert rot <= POSE_TOL and trans <= POSE_TOL, (k, rot, trans)
+        assert np.array_equal(sg.labels(0), so.labels(0)), k
+        assert np.array_equal(sg.b_image() > 0.5, so.b_image() > 0.5), k
+        assert (sg.stats().n_outer, sg.stats().n_irls) == (so.stats().n_outer, so.stats().n_irls), k
+    rot, trans = pose_delta(acc[0], acc[1])
+    assert rot <= 1e-4 and trans <= 1e-4, (rot, trans)  # 29 frames of accumulated difference
+
+
+def test_bench_size_batch_duplicates_identical(hip, pair):
+    """2048 QVGA streams (8 distinct pairs tiled), one launch: every copy of a pair gives bit-identical T, b and counters."""
+    prs = [pair(seed=1234 + i, rows=240, cols=320) for i in range(8)]
+    B = 2048
+    s = make_solver(hip, 240, 320, config2_params(hip, levels=3), batch=B)
+    for b in range(B):
+        s.set_current(b, *prs[b % 8]["new"])
+        s.set_prediction(b, *prs[b % 8]["old"])
+    s.process_frame(0)
+    T, n_irls, n_outer, pix = s.batch_results()
+    for b in range(8, B):
+        assert np.array_equal(T[b], T[b % 8]) and n_irls[b] == n_irls[b % 8] and pix[b] == pix[b % 8], b
+    assert len({tuple(T[i].ravel()) for i in range(8)}) == 8  # and the distinct pairs give distinct poses

@@ -18,7 +18,7 @@
 #ifndef SF_NT
 #define SF_NT 256          // threads per workgroup (4 waves; 4 workgroups resident per CU)
 #endif
-#define SF_BLOCKS_PER_CU (1024 / SF_NT)  // 16 waves per CU at <= 128 VGPRs
+#define SF_BLOCKS_PER_CU (1024 / SF_NT)  // 16 waves per CU at <= 128 VGPRs (5 per CU measured 3 % slower: DESIGN.md §9)
 #define SF_NW (SF_NT / 64) // waves per workgroup
 #define SF_NC SF_NUM_CLUSTERS
 #define SF_INVALID_LABEL 255

@@ -20,16 +20,20 @@
 
 struct KmShared {
     float cent_a[3 * SF_NC], cent_b[3 * SF_NC];
-    vfloat2 cand[SF_NC * SF_NC];    // row l: (distance to, index of) the other centres, ascending distance: one 8-byte LDS read
+    union {  // the radix-select histogram (initialisation only) and the centre-distance tables (Lloyd iterations onwards)
+        unsigned hist[SF_NC * 256];
+        struct {
+            vfloat2 cand[SF_NC * SF_NC];    // row l: (distance to, index of) the other centres, ascending distance: one 8-byte LDS read
+            float pair_dist[SF_NC * SF_NC];
+        };
+    };
     vfloat4 cent4[SF_NC];          // (z, x, y, 0) of centre l: one 16-byte LDS read
-    float pair_dist[SF_NC * SF_NC];
     int wcnt[SF_NW][SF_NC];        // members per (wave range, label); then exclusive offsets
     int count[SF_NC];
     int off[SF_NC];
     unsigned conn[SF_NC];
     unsigned useed[SF_NC], vseed[SF_NC];
     unsigned prefix[SF_NC], krank[SF_NC];
-    unsigned hist[SF_NC * 256];
     float red[SF_NW];
     int stop;
 };

@@ -87,6 +87,47 @@ __device__ __forceinline__ int km_search(const LDS KmShared &s, int last, float 
     return best;
 }
 
+// The same search for N independent pixels of a lane in lock step: the dependent LDS reads of one pixel
+// (candidate -> centre) overlap those of the others. Per pixel the candidate sequence, the comparisons and the
+// exit rule (first candidate farther than 4 d_last ends the search) are those of km_search(); pixels whose
+// search has ended ride along without effect. act[k] = false: pixel k is not searched (best[k] = last[k]).
+template <int N>
+__device__ __forceinline__ void km_search_n(const LDS KmShared &s, const int (&last)[N], const float (&pz)[N], const float (&px)[N],
+                                            const float (&py)[N], const bool (&act)[N], int (&best)[N]) {
+    float best_d[N], lim[N];
+    vfloat2 cd[N];
+    bool run[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const vfloat4 c0 = s.cent4[last[k]];
+        best[k] = last[k];
+        best_d[k] = sqdist3(c0.x, c0.y, c0.z, pz[k], px[k], py[k]);
+        lim[k] = 4.f * best_d[k];
+        cd[k] = s.cand[last[k] * SF_NC + 1];
+        run[k] = act[k];
+    }
+    for (int li = 1; li < SF_NC; li++) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            run[k] = run[k] && !(cd[k].x > lim[k]);
+            any = any || run[k];
+        }
+        if (!__any(any)) break;
+        const int nxt = min(li + 1, SF_NC - 1);
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const int c = __float_as_int(cd[k].y);
+            const vfloat4 cc = s.cent4[c];
+            cd[k] = s.cand[last[k] * SF_NC + nxt];
+            const float dl = sqdist3(cc.x, cc.y, cc.z, pz[k], px[k], py[k]);
+            const bool upd = run[k] && (dl < best_d[k]);
+            best_d[k] = upd ? dl : best_d[k];
+            best[k] = upd ? c : best[k];
+        }
+    }
+}
+
 __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const size_t sb = (size_t)b * a.n_tot;
@@ -207,21 +248,23 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
                 py[k] = yy[o1 + idx];
                 old[k] = labels[o1 + idx];
             }
+            bool valid[SF_LOAD_BATCH];
+            int best[SF_LOAD_BATCH];
+#pragma unroll
+            for (int k = 0; k < SF_LOAD_BATCH; k++) {
+                valid[k] = (base + k * 64 + lane < w_end) && pz[k] != 0.f;
+                old[k] = valid[k] ? old[k] : 0;  // a safe table row for pixels that are not searched
+            }
+            km_search_n<SF_LOAD_BATCH>(s, old, pz, px, py, valid, best);
 #pragma unroll
             for (int k = 0; k < SF_LOAD_BATCH; k++) {
                 const int idx = base + k * 64 + lane;
-                bool valid = false;
-                int best = 0;
-                if (idx < w_end && pz[k] != 0.f) {
-                    valid = true;
-                    best = km_search(s, old[k], pz[k], px[k], py[k]);
-                    labels[o1 + idx] = (uint8_t)best;
-                }
-                unsigned long long rem = __ballot(valid);
+                if (valid[k]) labels[o1 + idx] = (uint8_t)best[k];
+                unsigned long long rem = __ballot(valid[k]);
                 while (rem) {
                     const int src = __ffsll((long long)rem) - 1;
-                    const int l = __builtin_amdgcn_readlane(best, src);
-                    const unsigned long long m = __ballot(valid && best == l);
+                    const int l = __builtin_amdgcn_readlane(best[k], src);
+                    const unsigned long long m = __ballot(valid[k] && best[k] == l);
                     if (lane == l) cnt += __popcll(m);
                     rem &= ~m;
                 }
@@ -294,7 +337,14 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
             const int n = s.count[c];
             float acc = 0.f;
             int j = 0;
-            for (; j + 16 <= n; j += 16) {  // 16 loads in flight, then 16 strictly ordered adds
+            for (; j + 64 <= n; j += 64) {  // 64 loads in flight (only 72 lanes run here), then strictly ordered adds
+                float v[64];
+#pragma unroll
+                for (int q = 0; q < 64; q++) v[q] = src[j + q];
+#pragma unroll
+                for (int q = 0; q < 64; q++) acc += v[q];
+            }
+            for (; j + 16 <= n; j += 16) {
                 float v[16];
 #pragma unroll
                 for (int q = 0; q < 16; q++) v[q] = src[j + q];
@@ -338,13 +388,18 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
                 py[q] = yy[idx];
                 low[q] = labels[o1 + (v / 2) + (u / 2) * rows_km];
             }
+            bool act[SF_LOAD_BATCH];
+            int start[SF_LOAD_BATCH], lab[SF_LOAD_BATCH];
+#pragma unroll
+            for (int q = 0; q < SF_LOAD_BATCH; q++) {
+                act[q] = (base + q * SF_NT < n0) && pz[q] != 0.f;
+                start[q] = (low[q] == SF_NC) ? 0 : low[q];
+            }
+            km_search_n<SF_LOAD_BATCH>(s, start, pz, px, py, act, lab);
 #pragma unroll
             for (int q = 0; q < SF_LOAD_BATCH; q++) {
                 const int idx = base + q * SF_NT;
-                if (idx >= n0) continue;
-                int lab = SF_NC;
-                if (pz[q] != 0.f) lab = km_search(s, (low[q] == SF_NC) ? 0 : low[q], pz[q], px[q], py[q]);
-                labels[idx] = (uint8_t)lab;
+                if (idx < n0) labels[idx] = (uint8_t)(act[q] ? lab[q] : SF_NC);
             }
         }
     }

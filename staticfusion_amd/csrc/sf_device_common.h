@@ -50,7 +50,12 @@ enum {
 
 // fixed-point scales of the order-independent accumulations
 #define FIX_DEPTH 67108864.f        /* 2^26 : warp depth accumulators */
-#define FIX_INTENS 1073741824.f     /* 2^30 : warp intensity accumulators */
+#define FIX_INTENS 268435456.f      /* 2^28 : warp intensity accumulators (44-bit field, see ACC_W_SHIFT) */
+// An accumulator cell is two 64-bit words: sum(w * depth) in Q26, and sum(w) << 44 + sum(w * intensity) in Q28 --
+// the integer weight sum (each weight <= 200) shares the intensity word, so a splat is two atomics and a cell is
+// 16 bytes. The intensity field holds +-2^43: > 160 full-weight contributions of intensity 1 on ONE cell (a rigid
+// warp between neighbouring frames produces < 10); sum(w) holds 2^20.
+#define ACC_W_SHIFT 44
 #define FIX_RES 4294967296.f        /* 2^32 : per-label residual / prior sums */
 
 // Per-stream persistent state (global memory, one per stream).
@@ -92,8 +97,7 @@ struct KArgs {
     float *dbg_inter[4];
     uint8_t *labels;     // [batch][n_tot]
     long long *acc_d;    // [batch][n0] warp accumulators
-    long long *acc_i;
-    uint32_t *acc_w;
+    long long *acc_i;    // packed: (sum w << ACC_W_SHIFT) + sum(w * intensity)
     float *rec[R_COUNT];  // [plane][batch][n0]
     uint8_t *rec_lab;     // [batch][n0]  label of a valid pixel, SF_INVALID_LABEL otherwise
     uint8_t *rec_null;    // [batch][n0]  Null mask of the last linearisation
@@ -270,10 +274,15 @@ struct SplatGeom {
 // depth / intensity of a target pixel from its fixed-point accumulators: sum(w * value) / sum(w).
 // The integer sums are exact; one int64 -> float conversion and one IEEE float division round twice
 // (<= 1 ulp from the exact quotient, the same order as the reference's own float accumulation).
-__device__ __forceinline__ void normalise_acc(long long sd, long long si, unsigned w, float &dw, float &iw) {
-    const float wf = (float)w;
+__device__ __forceinline__ unsigned acc_weight(long long packed) {
+    const long long ipart = (long long)((unsigned long long)packed << (64 - ACC_W_SHIFT)) >> (64 - ACC_W_SHIFT);
+    return (unsigned)((packed - ipart) >> ACC_W_SHIFT);
+}
+__device__ __forceinline__ void normalise_acc(long long sd, long long packed, float &dw, float &iw) {
+    const long long si = (long long)((unsigned long long)packed << (64 - ACC_W_SHIFT)) >> (64 - ACC_W_SHIFT);
+    const float wf = (float)(unsigned)((packed - si) >> ACC_W_SHIFT);
     dw = ((float)sd * (1.f / 67108864.f)) / wf;
-    iw = ((float)si * (1.f / 1073741824.f)) / wf;
+    iw = ((float)si * (1.f / FIX_INTENS)) / wf;
 }
 
 #define SF_LOAD_BATCH 4  // independent pixels whose loads are issued before any of them is consumed
@@ -295,15 +304,14 @@ __device__ __forceinline__ void normalise_acc(long long sd, long long si, unsign
 
 struct SplatWin {
     long long d[WIN_CELLS];
-    long long i[WIN_CELLS];
-    unsigned w[WIN_CELLS];
+    long long i[WIN_CELLS];  // packed like the global cell
     int vmin, umin;
 };
 
 // Src::load(v, u, idx, z, xr, yr, iw) -> bool valid
 template <class Src>
 __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int cols_i, const Src &src, gptr<long long> acc_d,
-                                            gptr<long long> acc_i, gptr<uint32_t> acc_w, LDS SplatWin &win, int tid) {
+                                            gptr<long long> acc_i, LDS SplatWin &win, int tid) {
     const int lane = tid & 63;
     const int tiles_v = (rows_i + SPLAT_TV - 1) / SPLAT_TV, tiles_u = (cols_i + SPLAT_TU - 1) / SPLAT_TU;
     for (int tile = 0; tile < tiles_v * tiles_u; tile++) {
@@ -312,7 +320,6 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
         for (int q = tid; q < WIN_CELLS; q += SF_NT) {
             win.d[q] = 0;
             win.i[q] = 0;
-            win.w[q] = 0;
         }
         if (tid == 0) {
             win.vmin = 0x7fffffff;
@@ -363,13 +370,11 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
             if (dv >= 0 && dv < WIN_V && du >= 0 && du < WIN_U) {
                 const int c = dv + du * WIN_V;
                 lds_add(&win.d[c], (long long)w * df);
-                lds_add(&win.i[c], (long long)w * jf);
-                lds_add(&win.w[c], (unsigned)w);
+                lds_add(&win.i[c], ((long long)w << ACC_W_SHIFT) + (long long)w * jf);
             } else {
                 const int t = v + u * g.rows_i;
                 gatomic_add(acc_d + t, (long long)w * df);
-                gatomic_add(acc_i + t, (long long)w * jf);
-                gatomic_add(acc_w + t, (uint32_t)w);
+                gatomic_add(acc_i + t, ((long long)w << ACC_W_SHIFT) + (long long)w * jf);
             }
         };
 #pragma unroll
@@ -394,13 +399,12 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
         __syncthreads();
         // ---- phase 3: add the touched cells to the global accumulators (consecutive lanes -> consecutive v)
         for (int q = tid; q < WIN_CELLS; q += SF_NT) {
-            const unsigned w = win.w[q];
-            if (w == 0) continue;
+            const long long packed = win.i[q];
+            if (packed == 0) continue;  // sum(w) >= 1 makes a touched cell non-zero
             const int du = q / WIN_V, dv = q - du * WIN_V;
             const int t = (wv0 + dv) + (wu0 + du) * g.rows_i;
             gatomic_add(acc_d + t, win.d[q]);
-            gatomic_add(acc_i + t, win.i[q]);
-            gatomic_add(acc_w + t, (uint32_t)w);
+            gatomic_add(acc_i + t, packed);
         }
         __syncthreads();  // before the next tile clears the window
     }

@@ -327,7 +327,6 @@ int sf_create(const sf_params *p, int rows, int cols, int batch, int device, sf_
     TRY_OR_FREE(dev_alloc(h, &k.labels, B * NT));
     TRY_OR_FREE(dev_alloc(h, &k.acc_d, B * N0));
     TRY_OR_FREE(dev_alloc(h, &k.acc_i, B * N0));
-    TRY_OR_FREE(dev_alloc(h, &k.acc_w, B * N0));
     for (int q = 0; q < R_COUNT; q++) TRY_OR_FREE(dev_alloc(h, &k.rec[q], B * N0));
     TRY_OR_FREE(dev_alloc(h, &k.rec_lab, B * N0));
     TRY_OR_FREE(dev_alloc(h, &k.rec_null, B * N0));

@@ -30,7 +30,6 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, L
     const auto dbuf = as_global((const float *)a.hist_d + ((size_t)idx_to_warp * a.batch + b) * a.n0);
     const auto ibuf = as_global((const float *)a.hist_i + ((size_t)idx_to_warp * a.batch + b) * a.n0);
     const auto acc_d = as_global(a.acc_d + rb), acc_i = as_global(a.acc_i + rb);
-    const auto acc_w = as_global(a.acc_w + rb);
 
     if (tid == 0) {
         // T = prod odomBuffer[(index-4 .. index-1) % 5] * T_odometry, then inverse (:901-909)
@@ -50,7 +49,6 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, L
     for (int idx = tid; idx < n; idx += SF_NT) {
         acc_d[idx] = 0;
         acc_i[idx] = 0;
-        acc_w[idx] = 0;
     }
     __syncthreads();
 
@@ -79,7 +77,7 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, L
             return z != 0.f && dc != 0.f;
         }
     } src{dbuf, ibuf, dcur, inv_f_i, g.disp_u_i, g.disp_v_i};
-    tiled_splat(g, rows, cols, src, acc_d, acc_i, acc_w, s.win, tid);
+    tiled_splat(g, rows, cols, src, acc_d, acc_i, s.win, tid);
     __syncthreads();
 
     // residuals, cluster-wise (:1036-1068): per-lane running sums per label, flushed to the workgroup bins
@@ -88,14 +86,12 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, L
     int cur_lab = 0, cur_cnt = 0;
     long long cur_sum = 0;
     for (int base = tid; base < n; base += SF_NT * SF_LOAD_BATCH) {
-        uint32_t w[SF_LOAD_BATCH];
         long long sd[SF_LOAD_BATCH], si[SF_LOAD_BATCH];
         float dc[SF_LOAD_BATCH], db[SF_LOAD_BATCH], ic[SF_LOAD_BATCH];
         int lb[SF_LOAD_BATCH];
 #pragma unroll
         for (int k = 0; k < SF_LOAD_BATCH; k++) {
             const int idx = min(base + k * SF_NT, n - 1);
-            w[k] = __hip_atomic_load(acc_w + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sd[k] = __hip_atomic_load(acc_d + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             si[k] = __hip_atomic_load(acc_i + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             dc[k] = dcur[idx];
@@ -105,9 +101,9 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, L
         }
 #pragma unroll
         for (int k = 0; k < SF_LOAD_BATCH; k++) {
-            if (!(base + k * SF_NT < n && w[k] != 0 && dc[k] != 0.f)) continue;
+            if (!(base + k * SF_NT < n && si[k] != 0 && dc[k] != 0.f)) continue;
             float dw, iw;
-            normalise_acc(sd[k], si[k], w[k], dw, iw);
+            normalise_acc(sd[k], si[k], dw, iw);
             if (dw == 0.f || lb[k] >= SF_NC) continue;
             // intensity_diff is intensityCurrent where both depths are valid, else 0 (:937,1022)
             const float idiff = (db[k] != 0.f) ? ic[k] : 0.f;

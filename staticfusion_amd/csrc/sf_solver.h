@@ -190,13 +190,11 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
     const auto xpred = as_global((const float *)a.pyr_pred[2] + sb + o), ypred = as_global((const float *)a.pyr_pred[3] + sb + o);
     const auto acc_d = as_global(a.acc_d + (size_t)b * a.n0);
     const auto acc_i = as_global(a.acc_i + (size_t)b * a.n0);
-    const auto acc_w = as_global(a.acc_w + (size_t)b * a.n0);
 
     if (tid == 0) inverse4_cm(s.T, s.Tinv, s.dwork);  // T = T_odometry.inverse()  (:800)
     for (int idx = tid; idx < n; idx += SF_NT) {
         acc_d[idx] = 0;
         acc_i[idx] = 0;
-        acc_w[idx] = 0;
     }
     __syncthreads();
 
@@ -222,7 +220,7 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
             return z != 0.f;
         }
     } src{dpred, ipred, xpred, ypred};
-    tiled_splat(g, rows_i, cols_i, src, acc_d, acc_i, acc_w, s.win, tid);
+    tiled_splat(g, rows_i, cols_i, src, acc_d, acc_i, s.win, tid);
     __syncthreads();  // all atomics of this workgroup performed at L2
 }
 
@@ -244,7 +242,6 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
     const auto dpred = as_global((const float *)a.pyr_pred[0] + sb + o), ipred = as_global((const float *)a.pyr_pred[1] + sb + o);
     const auto xpred = as_global((const float *)a.pyr_pred[2] + sb + o), ypred = as_global((const float *)a.pyr_pred[3] + sb + o);
     const auto acc_d = as_global((const long long *)a.acc_d + rb), acc_i = as_global((const long long *)a.acc_i + rb);
-    const auto acc_w = as_global((const uint32_t *)a.acc_w + rb);
     const auto labels = as_global((const uint8_t *)a.labels + sb + o);
     gptr<float> rec[R_COUNT];
 #pragma unroll
@@ -276,7 +273,6 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
 
     // prefetch registers (plain local arrays + a macro: a lambda capturing a struct kept it in scratch memory)
     float pf_dn[TILE_EPT], pf_in[TILE_EPT];
-    unsigned pf_aw[TILE_EPT];
     long long pf_ad[TILE_EPT], pf_ai[TILE_EPT];
     int pf_lab[TILE_CPX];
 #define LIN_PREFETCH(TILE_IDX)                                                                                        \
@@ -294,7 +290,6 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                 const unsigned lo = __float_as_uint(dpred[idx]), hi = __float_as_uint(ipred[idx]);                    \
                 pf_ad[q] = (long long)(((unsigned long long)hi << 32) | lo);                                          \
             } else {                                                                                                  \
-                pf_aw[q] = __hip_atomic_load(acc_w + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                \
                 pf_ad[q] = __hip_atomic_load(acc_d + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                \
                 pf_ai[q] = __hip_atomic_load(acc_i + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                \
             }                                                                                                         \
@@ -325,8 +320,8 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                 if (first) {
                     dw = __uint_as_float((unsigned)((unsigned long long)pf_ad[q] & 0xffffffffu));
                     iw = __uint_as_float((unsigned)((unsigned long long)pf_ad[q] >> 32));
-                } else if (pf_aw[q] != 0) {  // normalise the warp accumulators (reference :876-881)
-                    normalise_acc(pf_ad[q], pf_ai[q], pf_aw[q], dw, iw);
+                } else if (pf_ai[q] != 0) {  // normalise the warp accumulators (reference :876-881); touched <=> sum(w) > 0
+                    normalise_acc(pf_ad[q], pf_ai[q], dw, iw);
                 }
             }
             const bool nul = !(inside && (dn != 0.f) && (dw != 0.f));

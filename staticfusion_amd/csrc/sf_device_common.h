@@ -91,7 +91,7 @@ struct KArgs {
     sf_params p;
     float tan_half_fovh;  // tanf(0.5f*fovh), evaluated on the host like the reference does
     // buffers
-    float *pyr_new[4];   // [ch][batch][n_tot]  depth, intensity, xx, yy
+    float *pyr_new[4];   // [ch][batch][n_tot]  depth, intensity (xx, yy are recomputed: level_coord(); entries 2, 3 are null)
     float *pyr_pred[4];
     float *dbg_warped[4];  // debug_planes only, else null
     float *dbg_inter[4];
@@ -259,6 +259,36 @@ __device__ __forceinline__ void wave_label_count(bool active, int lab, LDS int *
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+//  xx / yy of the pyramids (reference FrontEnd.cpp:385-386: xx = (inv_f_i (u - disp_u_i)) depth) are not
+//  stored: every consumer has the depth and the pixel position and repeats this expression (same
+//  operations, same bits), which saves 8 B per pixel on the pyramid write and on every read.
+// ---------------------------------------------------------------------------------------------
+struct LevelCoord {
+    float inv_f_i, disp_u_i, disp_v_i, inv_rows;
+    int rows_i;
+};
+__device__ __forceinline__ LevelCoord level_coord(const KArgs &a, int L) {
+    LevelCoord c;
+    const int rows_i = a.lrows[L], cols_i = a.lcols[L];
+    c.inv_f_i = 2.f * a.tan_half_fovh / float(cols_i);
+    c.disp_u_i = 0.5f * (cols_i - 1);
+    c.disp_v_i = 0.5f * (rows_i - 1);
+    c.inv_rows = 1.f / float(rows_i);
+    c.rows_i = rows_i;
+    return c;
+}
+__device__ __forceinline__ float coord_x(const LevelCoord &c, int u, float d) { return (c.inv_f_i * (float(u) - c.disp_u_i)) * d; }
+__device__ __forceinline__ float coord_y(const LevelCoord &c, int v, float d) { return (c.inv_f_i * (float(v) - c.disp_v_i)) * d; }
+// flat column-major index -> (u, v), exact (float reciprocal estimate + integer correction)
+__device__ __forceinline__ void split_uv(const LevelCoord &c, int idx, int &u, int &v) {
+    int q = (int)((float)idx * c.inv_rows);
+    if (q * c.rows_i > idx) q--;
+    if ((q + 1) * c.rows_i <= idx) q++;
+    u = q;
+    v = idx - q * c.rows_i;
+}
 
 // ---------------------------------------------------------------------------------------------
 //  forward splat of one source pixel (reference FrontEnd.cpp:808-868 / :960-1019): transform with T

@@ -316,14 +316,15 @@ int sf_create(const sf_params *p, int rows, int cols, int batch, int device, sf_
     HIP_OR_FREE(hipEventCreate(&h->evk1));
 
     const size_t B = batch, NT = k.n_tot, N0 = k.n0, N1 = k.ln[1];
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < 2; c++) {  // depth, intensity; xx / yy are recomputed (level_coord), their table entries stay null
         TRY_OR_FREE(dev_alloc(h, &k.pyr_new[c], B * NT));
         TRY_OR_FREE(dev_alloc(h, &k.pyr_pred[c], B * NT));
-        if (p->debug_planes) {
+    }
+    if (p->debug_planes)
+        for (int c = 0; c < 4; c++) {
             TRY_OR_FREE(dev_alloc(h, &k.dbg_warped[c], B * NT));
             TRY_OR_FREE(dev_alloc(h, &k.dbg_inter[c], B * NT));
         }
-    }
     TRY_OR_FREE(dev_alloc(h, &k.labels, B * NT));
     TRY_OR_FREE(dev_alloc(h, &k.acc_d, B * N0));
     TRY_OR_FREE(dev_alloc(h, &k.acc_i, B * N0));
@@ -591,9 +592,24 @@ int sf_get_plane(sf_handle *h, int stream, int set, int channel, int level, floa
     if (!out || level < 0 || level >= h->k.levels || set < 0 || set > 3 || channel < 0 || channel > 3)
         return fail(SF_ERR_ARG, "bad selector");
     float *const *tab[4] = {h->k.pyr_new, h->k.pyr_pred, h->k.dbg_warped, h->k.dbg_inter};
+    const size_t off = (size_t)stream * h->k.n_tot + h->k.loff[level], n = h->k.ln[level];
+    if (set <= SF_SET_PRED && channel >= SF_CH_XX) {
+        // xx / yy of the pyramids are not stored on the device (every kernel recomputes them from the depth):
+        // the same float expression (reference FrontEnd.cpp:385-386) evaluated here
+        if (int e = d2h(h, out, tab[set][SF_CH_DEPTH] + off, sizeof(float) * n)) return e;
+        const int rows_i = h->k.lrows[level], cols_i = h->k.lcols[level];
+        const float inv_f_i = 2.f * h->k.tan_half_fovh / float(cols_i);
+        const float disp = (channel == SF_CH_XX) ? 0.5f * (cols_i - 1) : 0.5f * (rows_i - 1);
+        for (int u = 0; u < cols_i; u++)
+            for (int v = 0; v < rows_i; v++) {
+                float &d = out[v + (size_t)u * rows_i];
+                d = (inv_f_i * (float(channel == SF_CH_XX ? u : v) - disp)) * d;
+            }
+        return SF_OK;
+    }
     const float *base = tab[set][channel];
     if (!base) return fail(SF_ERR_STATE, "WARPED / INTER planes need params.debug_planes = 1 at sf_create");
-    return d2h(h, out, base + (size_t)stream * h->k.n_tot + h->k.loff[level], sizeof(float) * h->k.ln[level]);
+    return d2h(h, out, base + off, sizeof(float) * n);
 }
 
 int sf_get_lin_plane(sf_handle *h, int stream, int which, float *out, int *rows, int *cols) {

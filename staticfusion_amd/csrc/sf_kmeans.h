@@ -131,8 +131,8 @@ __device__ __forceinline__ void km_search_n(const LDS KmShared &s, const int (&l
 __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const size_t sb = (size_t)b * a.n_tot;
-    const auto depth = as_global((const float *)a.pyr_new[0] + sb), xx = as_global((const float *)a.pyr_new[2] + sb),
-               yy = as_global((const float *)a.pyr_new[3] + sb);
+    const auto depth = as_global((const float *)a.pyr_new[0] + sb);
+    const LevelCoord lc0 = level_coord(a, 0), lc1 = level_coord(a, 1);
     const auto labels = as_global(a.labels + sb);
     StreamState &st = a.state[b];
     long long kt = wall_clock64();
@@ -243,9 +243,11 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
 #pragma unroll
             for (int k = 0; k < SF_LOAD_BATCH; k++) {  // all loads of the batch in flight before the first search
                 const int idx = min(base + k * 64 + lane, n1 - 1);
+                int u, v;
+                split_uv(lc1, idx, u, v);
                 pz[k] = depth[o1 + idx];
-                px[k] = xx[o1 + idx];
-                py[k] = yy[o1 + idx];
+                px[k] = coord_x(lc1, u, pz[k]);
+                py[k] = coord_y(lc1, v, pz[k]);
                 old[k] = labels[o1 + idx];
             }
             bool valid[SF_LOAD_BATCH];
@@ -300,9 +302,11 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
 #pragma unroll
             for (int k = 0; k < SF_LOAD_BATCH; k++) {
                 const int idx = min(base + k * 64 + lane, n1 - 1);
+                int u, v;
+                split_uv(lc1, idx, u, v);
                 pz[k] = depth[o1 + idx];
-                px[k] = xx[o1 + idx];
-                py[k] = yy[o1 + idx];
+                px[k] = coord_x(lc1, u, pz[k]);
+                py[k] = coord_y(lc1, v, pz[k]);
                 labk[k] = labels[o1 + idx];
             }
 #pragma unroll
@@ -384,8 +388,8 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
                 const int idx = min(base + q * SF_NT, n0 - 1);
                 const int u = idx / rows0, v = idx - u * rows0;
                 pz[q] = depth[idx];
-                px[q] = xx[idx];
-                py[q] = yy[idx];
+                px[q] = coord_x(lc0, u, pz[q]);
+                py[q] = coord_y(lc0, v, pz[q]);
                 low[q] = labels[o1 + (v / 2) + (u / 2) * rows_km];
             }
             bool act[SF_LOAD_BATCH];
@@ -416,7 +420,7 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
             if (u >= cols0 - 1 || v >= rows0 - 1) continue;
             // all ten loads first (independent), then the tests
             const float dz = depth[idx], dzd = depth[idx + 1], dzr = depth[idx + rows0];
-            const float yc = yy[idx], yd = yy[idx + 1], xc = xx[idx], xr = xx[idx + rows0];
+            const float yc = coord_y(lc0, v, dz), yd = coord_y(lc0, v + 1, dzd), xc = coord_x(lc0, u, dz), xr = coord_x(lc0, u + 1, dzr);
             const int la = labels[idx], ld = labels[idx + 1], lr = labels[idx + rows0];
             if (dz == 0.f) continue;
             if (la != ld && ld != SF_NC) {
@@ -442,11 +446,14 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
     // pair_dist holds |kmeans_la - kmeans_lb|^2 from the last km_sort_centres (cent_a == kmeans)
     for (int L = 2; L < a.levels; L++) {
         const int n = a.ln[L], o = a.loff[L];
+        const LevelCoord lc = level_coord(a, L);
         for (int idx = tid; idx < n; idx += SF_NT) {
             const float pz = depth[o + idx];
             int lab = SF_NC;
             if (pz != 0.f) {
-                const float px = xx[o + idx], py = yy[o + idx];
+                int u, v;
+                split_uv(lc, idx, u, v);
+                const float px = coord_x(lc, u, pz), py = coord_y(lc, v, pz);
                 int label = 0;
                 float min_dist = sqdist3(s.cent_a[0], s.cent_a[1], s.cent_a[2], pz, px, py);
                 for (int l = 1; l < SF_NC; l++) {

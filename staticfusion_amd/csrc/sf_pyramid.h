@@ -18,17 +18,11 @@ __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, bool old_im, i
     float *const *set = old_im ? a.pyr_pred : a.pyr_new;
     const auto depth = as_global(set[0] + (size_t)b * a.n_tot);
     const auto inten = as_global(set[1] + (size_t)b * a.n_tot);
-    const auto xx = as_global(set[2] + (size_t)b * a.n_tot);
-    const auto yy = as_global(set[3] + (size_t)b * a.n_tot);
     const float max_depth_dif = 0.1f;
 
     for (int L = 0; L < a.levels; L++) {
         const int rows_i = a.lrows[L], cols_i = a.lcols[L], n = a.ln[L];
         const auto d_here = depth + a.loff[L], i_here = inten + a.loff[L];
-        const float inv_f_i = 2.f * a.tan_half_fovh / float(cols_i);
-        const float disp_u_i = 0.5f * (cols_i - 1);
-        const float disp_v_i = 0.5f * (rows_i - 1);
-
         if (L > 0) {
             __syncthreads();  // level L-1 complete (written by this workgroup)
             const auto d_prev = depth + a.loff[L - 1], i_prev = inten + a.loff[L - 1];
@@ -100,25 +94,9 @@ __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, bool old_im, i
                     dout = (cont != 0) ? new_d / float(cont) : 0.f;
                 }
                 d_here[idx] = dout;
-                i_here[idx] = iout;
-                xx[a.loff[L] + idx] = (inv_f_i * (float(u) - disp_u_i)) * dout;
-                yy[a.loff[L] + idx] = (inv_f_i * (float(v) - disp_v_i)) * dout;
+                i_here[idx] = iout;  // xx / yy (:385-386) are recomputed by their consumers: level_coord()
             }
-        } else {
-            for (int base = tid; base < n; base += SF_NT * SF_LOAD_BATCH) {  // level 0: coordinates only
-                float dd[SF_LOAD_BATCH];
-#pragma unroll
-                for (int k = 0; k < SF_LOAD_BATCH; k++) dd[k] = d_here[min(base + k * SF_NT, n - 1)];
-#pragma unroll
-                for (int k = 0; k < SF_LOAD_BATCH; k++) {
-                    const int idx = base + k * SF_NT;
-                    if (idx >= n) continue;
-                    const int u = idx / rows_i, v = idx - u * rows_i;
-                    xx[idx] = (inv_f_i * (float(u) - disp_u_i)) * dd[k];
-                    yy[idx] = (inv_f_i * (float(v) - disp_v_i)) * dd[k];
-                }
-            }
-        }
+        }  // level 0 is the input itself
     }
     __syncthreads();
 }

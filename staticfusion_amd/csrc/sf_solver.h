@@ -187,7 +187,6 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
     const int rows_i = a.lrows[L], cols_i = a.lcols[L], n = a.ln[L], o = a.loff[L];
     const size_t sb = (size_t)b * a.n_tot;
     const auto dpred = as_global((const float *)a.pyr_pred[0] + sb + o), ipred = as_global((const float *)a.pyr_pred[1] + sb + o);
-    const auto xpred = as_global((const float *)a.pyr_pred[2] + sb + o), ypred = as_global((const float *)a.pyr_pred[3] + sb + o);
     const auto acc_d = as_global(a.acc_d + (size_t)b * a.n0);
     const auto acc_i = as_global(a.acc_i + (size_t)b * a.n0);
 
@@ -211,15 +210,16 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
         for (int c = 0; c < 4; c++) g.T[r * 4 + c] = uniform_f(s.Tinv[r + 4 * c]);
 
     struct Src {
-        gptr<const float> d, i, x, y;
-        __device__ __forceinline__ bool load(int, int, int idx, float &z, float &xr, float &yr, float &iw) const {
+        gptr<const float> d, i;
+        LevelCoord lc;
+        __device__ __forceinline__ bool load(int v, int u, int idx, float &z, float &xr, float &yr, float &iw) const {
             z = d[idx];
             iw = i[idx];
-            xr = x[idx];
-            yr = y[idx];
+            xr = coord_x(lc, u, z);  // xxPrediction / yyPrediction of the pyramid (:385-386)
+            yr = coord_y(lc, v, z);
             return z != 0.f;
         }
-    } src{dpred, ipred, xpred, ypred};
+    } src{dpred, ipred, level_coord(a, L)};
     tiled_splat(g, rows_i, cols_i, src, acc_d, acc_i, s.win, tid);
     __syncthreads();  // all atomics of this workgroup performed at L2
 }
@@ -238,9 +238,7 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
     const int rows_i = a.lrows[L], cols_i = a.lcols[L], o = a.loff[L];
     const size_t sb = (size_t)b * a.n_tot, rb = (size_t)b * a.n0;
     const auto dnew = as_global((const float *)a.pyr_new[0] + sb + o), inew = as_global((const float *)a.pyr_new[1] + sb + o);
-    const auto xnew = as_global((const float *)a.pyr_new[2] + sb + o), ynew = as_global((const float *)a.pyr_new[3] + sb + o);
     const auto dpred = as_global((const float *)a.pyr_pred[0] + sb + o), ipred = as_global((const float *)a.pyr_pred[1] + sb + o);
-    const auto xpred = as_global((const float *)a.pyr_pred[2] + sb + o), ypred = as_global((const float *)a.pyr_pred[3] + sb + o);
     const auto acc_d = as_global((const long long *)a.acc_d + rb), acc_i = as_global((const long long *)a.acc_i + rb);
     const auto labels = as_global((const uint8_t *)a.labels + sb + o);
     gptr<float> rec[R_COUNT];
@@ -395,17 +393,18 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                 rec_lab[idx] = valid ? (uint8_t)(seg ? lab : 0) : (uint8_t)SF_INVALID_LABEL;
                 if (dbg) {
                     float d_i = 0.f, x_i = 0.f, y_i = 0.f, xw = 0.f, yw = 0.f;
-                    if (first) {
-                        xw = xpred[idx];
-                        yw = ypred[idx];
+                    const LevelCoord lcd = level_coord(a, L);
+                    if (first) {  // xxWarped := xxPrediction (:1107-1108)
+                        xw = coord_x(lcd, u, dw);
+                        yw = coord_y(lcd, v, dw);
                     } else if (dw != 0.f) {
                         xw = (float(u) - disp_u_i) * dw * inv_f_w;
                         yw = (float(v) - disp_v_i) * dw * inv_f_w;
                     }
                     if (!nul) {
                         d_i = s.lt.t_D[e];
-                        x_i = 0.5f * (xnew[idx] + xw);
-                        y_i = 0.5f * (ynew[idx] + yw);
+                        x_i = 0.5f * (coord_x(lcd, u, dn) + xw);
+                        y_i = 0.5f * (coord_y(lcd, v, dn) + yw);
                     }
                     a.rec_null[rb + idx] = nul ? 1 : 0;
                     const size_t q = sb + o + idx;

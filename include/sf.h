@@ -202,6 +202,40 @@ int SF_FN(get_input_image)(sf_handle *h, int stream, int which, void *out);
 int SF_FN(timed_input_stage)(sf_handle *h, const void *d_color_full, const void *d_depth_full, int full_rows, int full_cols,
                              int res_factor, int calls, float *elapsed_ms);
 
+/* ---- frame-to-model prediction without OpenGL ---------------------- */
+
+/* Uniforms of Reconstruction::getPredictedImages (Reconstruction.cpp:628-720). */
+typedef struct sf_model_params {
+    float cx, cy, fx, fy;       /* Intrinsics: fx = 0.5 cols / tan(fovh/2), fy = 0.5 rows / tan(fovv/2), cx = cols/2, cy = rows/2 (FrontEnd.cpp:57-63,165) */
+    float max_depth;            /* maxDepthProcessed = 20 (Reconstruction.cpp:36): surfel cull + depth-buffer scale */
+    float conf_low, conf_high;  /* 0.13 and confidenceThreshold = 0.25 (Reconstruction.cpp:630-632, FrontEnd.cpp:167) */
+    int32_t time, max_time;     /* tick, tick (Reconstruction.cpp:642-643) */
+    int32_t time_delta;         /* INT_MAX in the drivers (FrontEnd.cpp:176) */
+    float extract_max_depth;    /* 4.5 (FillIn.cpp:277) */
+} sf_model_params;
+/* The values the reference uses for a handle of this resolution (fovh from the handle's parameters, fovv = 48.5 deg). */
+int SF_FN(default_model_params)(const sf_handle *h, sf_model_params *p);
+
+/* Reconstruction::getPredictedImages(depthPrediction, intensityPrediction) for one stream, from a surfel
+ * buffer in the layout of the reference's global model (Shaders/Vertex.cpp:40: 3 x vec4 per surfel =
+ * position.xyz + confidence | encoded colour, -, init time, last time | normal.xyz + radius; host pointer,
+ * count x 12 floats) and the camera pose `pose` (currPose, 4x4 column-major):
+ *   two point-sprite renderings of the model at confidence >= conf_low / conf_high
+ *       (IndexMap::combinedPredict IndexMap.cpp:221-300, Shaders/splat.vert, combo_splat.frag: per-fragment
+ *        ray / surfel-disc intersection, nearest surface wins, surfels in buffer order on ties),
+ *   the density test of the low-confidence image (Resize 1/40 + Reconstruction::denseEnough :218-233),
+ *   fill-in from the stream's DEPTH_FILTERED / WEIGHT (= b_segm_perpixel) / RGB images where b > 0.6
+ *       (Shaders/fill_vertex.frag, fill_vertex_from_texture.frag, fill_rgb.frag; FillIn.cpp),
+ *   depth = vertex.z where 0 < z <= extract_max_depth (Shaders/extract_depth.frag), intensity =
+ *       0.299 r + 0.587 g + 0.114 b of the 8-bit prediction (Reconstruction.cpp:684-692).
+ * The fill-in reads what the stream holds at the time of the call: as in the reference's frame loop
+ * (StaticFusion-imagesequenceassoc.cpp:164-165,183) that is the PREVIOUS frame's filtered depth, colour
+ * and b image -- call this before sf_load_frame of the new frame. Writes depthPrediction / intensityPrediction. */
+int SF_FN(predict_from_model)(sf_handle *h, int stream, const float *surfels, int count, const float pose[16],
+                              const sf_model_params *p);
+/* depthPrediction / intensityPrediction (column-major float, rows*cols each; either may be NULL). */
+int SF_FN(get_prediction)(sf_handle *h, int stream, float *depth, float *intensity);
+
 /* ---- the four methods the drivers call (all streams of the batch) ------------------------- */
 
 /* StaticFusion::createImagePyramid(bool old_im)  FrontEnd.cpp:256-391 */

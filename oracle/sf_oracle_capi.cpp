@@ -13,6 +13,7 @@
 
 #include "sf_oracle.hpp"
 #include "sf_oracle_input.hpp"
+#include "sf_oracle_predict.hpp"
 #include "../include/sf_detmath.h"
 
 struct sf_handle {
@@ -474,6 +475,48 @@ int sfo_timed_input_stage(sf_handle *h, const void *c, const void *d, int full_r
         if (int e = sfo_filter_depth(h)) return e;
     }
     if (elapsed_ms) *elapsed_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return SF_OK;
+}
+
+// ---- frame-to-model prediction (sf_oracle_predict.cpp) --------------------------------------
+int sfo_default_model_params(const sf_handle *h, sf_model_params *p) {
+    if (!h || !p) return fail(SF_ERR_ARG, "null");
+    const float fovv = float(M_PI * 48.5 / 180.0);  // FrontEnd.cpp:58
+    p->fx = float(0.5 * h->cols / std::tan(h->params.fovh * 0.5));  // :62 (double arithmetic, then float)
+    p->fy = float(0.5 * h->rows / std::tan(fovv * 0.5));             // :63
+    p->cx = float(h->cols / 2);                                       // :165 (integer division)
+    p->cy = float(h->rows / 2);
+    p->max_depth = 20.0f;
+    p->conf_low = 0.13f;
+    p->conf_high = 0.25f;
+    p->time = p->max_time = 0;
+    p->time_delta = 2147483647;
+    p->extract_max_depth = 4.5f;
+    return SF_OK;
+}
+int sfo_predict_from_model(sf_handle *h, int stream, const float *surfels, int count, const float pose[16], const sf_model_params *p) {
+    if (int e = check_stream(h, stream)) return e;
+    if ((!surfels && count > 0) || count < 0 || !pose || !p) return fail(SF_ERR_ARG, "bad argument");
+    input_alloc(h);
+    double A[16], Ai[16];  // t_inv = pose.inverse() (IndexMap.cpp:251), [C5]: double Gauss-Jordan, rounded to float
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) A[r * 4 + c] = double(pose[r + 4 * c]);
+    sfo::inverse_double(A, Ai, 4);
+    float t_inv[16];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) t_inv[r + 4 * c] = float(Ai[r * 4 + c]);
+    sfo::ModelParams mp{p->cx, p->cy, p->fx, p->fy, p->max_depth, p->conf_low, p->conf_high, p->time, p->max_time, p->time_delta, p->extract_max_depth};
+    auto &s = *h->s[stream];
+    sfo::predict_from_model(surfels, count, t_inv, mp, h->rows, h->cols, h->filtered_mm[stream].data(), h->color[stream].data(),
+                            s.b_segm_perpixel.d.data(), s.depthPrediction.d.data(), s.intensityPrediction.d.data());
+    return SF_OK;
+}
+int sfo_get_prediction(sf_handle *h, int stream, float *depth, float *intensity) {
+    if (int e = check_stream(h, stream)) return e;
+    auto &s = *h->s[stream];
+    const size_t bytes = sizeof(float) * size_t(h->rows) * h->cols;
+    if (depth) std::memcpy(depth, s.depthPrediction.d.data(), bytes);
+    if (intensity) std::memcpy(intensity, s.intensityPrediction.d.data(), bytes);
     return SF_OK;
 }
 

@@ -44,6 +44,15 @@ class SfParams(C.Structure):
     ]
 
 
+class SfModelParams(C.Structure):
+    _fields_ = [
+        ("cx", C.c_float), ("cy", C.c_float), ("fx", C.c_float), ("fy", C.c_float),
+        ("max_depth", C.c_float), ("conf_low", C.c_float), ("conf_high", C.c_float),
+        ("time", C.c_int32), ("max_time", C.c_int32), ("time_delta", C.c_int32),
+        ("extract_max_depth", C.c_float),
+    ]
+
+
 class SfOuterTrace(C.Structure):
     _fields_ = [
         ("level", C.c_int32),
@@ -100,6 +109,9 @@ SIGNATURES = {
     "get_current": (C.c_int, [_H, C.c_int, _fp, _fp]),
     "get_input_image": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
     "timed_input_stage": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "default_model_params": (C.c_int, [_H, C.POINTER(SfModelParams)]),
+    "predict_from_model": (C.c_int, [_H, C.c_int, _fp, C.c_int, _fp, C.POINTER(SfModelParams)]),
+    "get_prediction": (C.c_int, [_H, C.c_int, _fp, _fp]),
     "build_pyramid": (C.c_int, [_H, C.c_int]),
     "kmeans": (C.c_int, [_H]),
     "run_solver": (C.c_int, [_H, C.c_int]),
@@ -243,6 +255,26 @@ class Solver:
         out = np.zeros(shape, dtype=dt)
         self.api.check(self.api.get_input_image(self.h, stream, which, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    # -- frame-to-model prediction ----------------------------------------
+    def default_model_params(self):
+        p = SfModelParams()
+        self.api.check(self.api.default_model_params(self.h, C.byref(p)))
+        return p
+
+    def predict_from_model(self, stream, surfels, pose, params=None):
+        """surfels: (count, 12) float32 in the reference's vertex layout; pose: 4x4 (row, col) camera pose"""
+        s = np.ascontiguousarray(surfels, dtype=np.float32).reshape(-1, 12)
+        T = np.ascontiguousarray(np.asarray(pose, np.float32).T)  # column-major storage
+        p = params if params is not None else self.default_model_params()
+        self.api.check(self.api.predict_from_model(self.h, stream, s.ctypes.data_as(_fp), s.shape[0], T.ctypes.data_as(_fp), C.byref(p)))
+
+    def prediction(self, stream=0):
+        """(depthPrediction, intensityPrediction) as (rows, cols) arrays"""
+        d = np.zeros((self.cols, self.rows), dtype=np.float32)
+        i = np.zeros((self.cols, self.rows), dtype=np.float32)
+        self.api.check(self.api.get_prediction(self.h, stream, d.ctypes.data_as(_fp), i.ctypes.data_as(_fp)))
+        return d.T.copy(), i.T.copy()
 
     def current_to_prediction(self):
         self.api.check(self.api.current_to_prediction(self.h))

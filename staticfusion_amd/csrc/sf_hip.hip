@@ -20,6 +20,7 @@
 #include "sf_pyramid.h"
 #include "sf_residuals.h"
 #include "sf_input.h"
+#include "sf_predict.h"
 #include "sf_smallmath.h"
 #include "sf_solver.h"
 
@@ -136,6 +137,11 @@ struct sf_handle {
     uint8_t *stage_color = nullptr;  // one full-resolution frame, for the host-pointer variant
     uint16_t *stage_depth = nullptr;
     size_t stage_px = 0;
+    // model prediction (sf_predict.h), allocated by the first sf_predict_from_model
+    unsigned long long *pr_key_low = nullptr, *pr_key_high = nullptr;
+    int *pr_dense = nullptr;
+    float *pr_surfels = nullptr;
+    size_t pr_capacity = 0;
 };
 
 static thread_local std::string g_err;
@@ -774,6 +780,111 @@ int sf_timed_input_stage(sf_handle *h, const void *d_color_full, const void *d_d
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     if (elapsed_ms) *elapsed_ms = ms;
+    return SF_OK;
+}
+
+// ---- frame-to-model prediction -------------------------------------------------------------------
+int sf_default_model_params(const sf_handle *h, sf_model_params *p) {
+    if (!h || !p) return fail(SF_ERR_ARG, "null");
+    const float fovv = float(M_PI * 48.5 / 180.0);                      // FrontEnd.cpp:58
+    p->fx = float(0.5 * h->k.cols / std::tan(h->k.p.fovh * 0.5));       // :62 (double arithmetic, then float)
+    p->fy = float(0.5 * h->k.rows / std::tan(fovv * 0.5));              // :63
+    p->cx = float(h->k.cols / 2);                                        // :165 (integer division)
+    p->cy = float(h->k.rows / 2);
+    p->max_depth = 20.0f;
+    p->conf_low = 0.13f;
+    p->conf_high = 0.25f;
+    p->time = p->max_time = 0;
+    p->time_delta = 2147483647;
+    p->extract_max_depth = 4.5f;
+    return SF_OK;
+}
+// 4x4 inverse, double Gauss-Jordan with partial pivoting, rounded to float (the [C5] convention of the solver)
+static void invert_pose(const float pose[16], float out[16]) {
+    double A[16], Ai[16];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+            A[r * 4 + c] = double(pose[r + 4 * c]);
+            Ai[r * 4 + c] = (r == c) ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 4; c++) {
+        int piv = c;
+        double pv = std::fabs(A[c * 4 + c]);
+        for (int r = c + 1; r < 4; r++)
+            if (std::fabs(A[r * 4 + c]) > pv) {
+                pv = std::fabs(A[r * 4 + c]);
+                piv = r;
+            }
+        if (piv != c)
+            for (int j = 0; j < 4; j++) {
+                std::swap(A[c * 4 + j], A[piv * 4 + j]);
+                std::swap(Ai[c * 4 + j], Ai[piv * 4 + j]);
+            }
+        const double inv = 1.0 / A[c * 4 + c];
+        for (int j = 0; j < 4; j++) {
+            A[c * 4 + j] *= inv;
+            Ai[c * 4 + j] *= inv;
+        }
+        for (int r = 0; r < 4; r++) {
+            if (r == c) continue;
+            const double f = A[r * 4 + c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < 4; j++) {
+                A[r * 4 + j] -= f * A[c * 4 + j];
+                Ai[r * 4 + j] -= f * Ai[c * 4 + j];
+            }
+        }
+    }
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) out[r + 4 * c] = float(Ai[r * 4 + c]);
+}
+int sf_predict_from_model(sf_handle *h, int stream, const float *surfels, int count, const float pose[16], const sf_model_params *p) {
+    if (int e = check_stream(h, stream)) return e;
+    if ((!surfels && count > 0) || count < 0 || !pose || !p) return fail(SF_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (int e = input_alloc(h)) return e;
+    const size_t n = h->k.n0;
+    if (!h->pr_key_low) {
+        if (int e = dev_alloc(h, &h->pr_key_low, n)) return e;
+        if (int e = dev_alloc(h, &h->pr_key_high, n)) return e;
+        if (int e = dev_alloc(h, &h->pr_dense, 1)) return e;
+    }
+    if (h->pr_capacity < (size_t)count) {
+        if (int e = dev_alloc(h, &h->pr_surfels, (size_t)count * 12)) return e;  // grows; the old block is freed with the handle
+        h->pr_capacity = count;
+    }
+    if (count) HIP_TRY(hipMemcpyAsync(h->pr_surfels, surfels, (size_t)count * 12 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    PredictArgs a;
+    a.surfels = h->pr_surfels;
+    a.count = count;
+    invert_pose(pose, a.t_inv);  // t_inv = pose.inverse() (IndexMap.cpp:251)
+    a.cx = p->cx; a.cy = p->cy; a.fx = p->fx; a.fy = p->fy;
+    a.max_depth = p->max_depth; a.conf_low = p->conf_low; a.conf_high = p->conf_high; a.extract_max_depth = p->extract_max_depth;
+    a.time = p->time; a.max_time = p->max_time; a.time_delta = p->time_delta;
+    a.rows = h->k.rows; a.cols = h->k.cols;
+    a.key_low = h->pr_key_low; a.key_high = h->pr_key_high; a.dense_count = h->pr_dense;
+    a.filtered_mm = h->in_filtered_mm + (size_t)stream * n;
+    a.color = h->in_color + (size_t)stream * n * 3;
+    a.b_img = h->k.b_img + (size_t)stream * n;
+    a.depth_pred = h->k.pyr_pred[0] + (size_t)stream * h->k.n_tot;
+    a.inten_pred = h->k.pyr_pred[1] + (size_t)stream * h->k.n_tot;
+    if (!(a.conf_low <= a.conf_high)) return fail(SF_ERR_ARG, "conf_low must not exceed conf_high");
+    const int pix_blocks = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(sf_predict_clear_kernel, dim3(pix_blocks), dim3(256), 0, h->stream, a);
+    if (count) hipLaunchKernelGGL(sf_predict_splat_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(sf_predict_dense_kernel, dim3(1), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL(sf_predict_resolve_kernel, dim3(pix_blocks), dim3(256), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));  // the host surfel buffer is free again; the staging block may be reused
+    return SF_OK;
+}
+int sf_get_prediction(sf_handle *h, int stream, float *depth, float *intensity) {
+    if (int e = check_stream(h, stream)) return e;
+    const size_t bytes = sizeof(float) * h->k.n0;
+    if (depth)
+        if (int e = d2h(h, depth, h->k.pyr_pred[0] + (size_t)stream * h->k.n_tot, bytes)) return e;
+    if (intensity)
+        if (int e = d2h(h, intensity, h->k.pyr_pred[1] + (size_t)stream * h->k.n_tot, bytes)) return e;
     return SF_OK;
 }
 

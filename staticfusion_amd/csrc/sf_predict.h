@@ -1,0 +1,195 @@
+// sf_predict.h — frame-to-model prediction on gfx950 without OpenGL:
+// Reconstruction::getPredictedImages (reference Reconstruction.cpp:628-720) = two point-sprite renderings of
+// the surfel model (IndexMap::combinedPredict IndexMap.cpp:221-300; Shaders/splat.vert, combo_splat.frag),
+// the density test (Resize + denseEnough :218-233), the fill-in passes (Shaders/FillIn.cpp, fill_*.frag) and
+// the depth extraction (extract_depth.frag).
+//
+// A GL rasteriser resolves visibility with an ordered depth test; here every surfel is one lane that walks
+// the pixels of its sprite and does ONE 64-bit atomicMin per surviving fragment on
+//     key = (bits of gl_FragDepth) << 32 | surfel index
+// (gl_FragDepth is a positive float: its bit pattern is monotonic; the index makes the earlier surfel win a
+// tie, as in-order GL_LESS does). A second kernel re-evaluates the winning fragment per pixel and runs the
+// per-pixel fill-in / extraction. Both confidence levels are rendered by the same pass (two key buffers).
+// Every float expression repeats the shader's association; no contraction: bit-identical to the CPU oracle.
+#pragma once
+#include "sf_device_common.h"
+
+struct PredictArgs {
+    const float *surfels;  // count x 12
+    int count;
+    float t_inv[16];       // column-major
+    float cx, cy, fx, fy, max_depth, conf_low, conf_high, extract_max_depth;
+    int time, max_time, time_delta;
+    int rows, cols;
+    unsigned long long *key_low, *key_high;  // rows x cols, row-major
+    int *dense_count;                        // [1]
+    const uint16_t *filtered_mm;             // rows x cols row-major
+    const uint8_t *color;                    // rows x cols x 3
+    const float *b_img;                      // column-major
+    float *depth_pred, *inten_pred;          // column-major
+};
+
+#define SF_PRED_EMPTY 0xffffffffffffffffull
+
+struct PV3 { float x, y, z; };
+__device__ __forceinline__ float pdot(PV3 a, PV3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ PV3 padd(PV3 a, PV3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ PV3 psub(PV3 a, PV3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ PV3 pmul(PV3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ PV3 pnormalize(PV3 a) {
+    const float n = sqrtf(pdot(a, a));
+    return {a.x / n, a.y / n, a.z / n};
+}
+__device__ __forceinline__ PV3 pcross(PV3 a, PV3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+
+// camera-frame position, normal and radius of surfel s (splat.vert:55,68); false if culled by :57
+__device__ __forceinline__ bool surfel_to_camera(const PredictArgs &a, int s, float conf_threshold, PV3 &h, PV3 &n, float &rad) {
+    const float *q = a.surfels + (size_t)s * 12;
+    const float *T = a.t_inv;
+    const PV3 vp{q[0], q[1], q[2]};
+    const float conf = q[3], tlast = q[7];
+    h = PV3{T[0] * vp.x + T[4] * vp.y + T[8] * vp.z + T[12], T[1] * vp.x + T[5] * vp.y + T[9] * vp.z + T[13],
+            T[2] * vp.x + T[6] * vp.y + T[10] * vp.z + T[14]};
+    if (h.z > a.max_depth || h.z < 0.4f || conf < conf_threshold || float(a.time) - tlast > float(a.time_delta) || tlast > float(a.max_time))
+        return false;
+    const PV3 nin{q[8], q[9], q[10]};
+    n = pnormalize(PV3{T[0] * nin.x + T[4] * nin.y + T[8] * nin.z, T[1] * nin.x + T[5] * nin.y + T[9] * nin.z,
+                       T[2] * nin.x + T[6] * nin.y + T[10] * nin.z});
+    rad = q[11];
+    return true;
+}
+
+// combo_splat.frag:37-49,63 for the fragment at pixel (i, j); false = discard
+__device__ __forceinline__ bool surfel_fragment(const PredictArgs &a, PV3 h, PV3 n, float rad, int i, int j, float &z, float &depth) {
+    const float fx_ = float(i) + 0.5f, fy_ = float(j) + 0.5f;
+    const PV3 l = pnormalize(PV3{(fx_ - a.cx) / a.fx, (fy_ - a.cy) / a.fy, 1.0f});
+    const PV3 corrected = pmul(l, pdot(h, n) / pdot(l, n));
+    const PV3 diff = psub(corrected, h);
+    if (pdot(diff, diff) > rad * rad) return false;
+    z = corrected.z;
+    depth = (corrected.z / (2.f * a.max_depth)) + 0.5f;
+    return depth >= 0.f && depth <= 1.f;
+}
+
+__global__ __launch_bounds__(256) void sf_predict_clear_kernel(PredictArgs a) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o < a.rows * a.cols) {
+        a.key_low[o] = SF_PRED_EMPTY;
+        a.key_high[o] = SF_PRED_EMPTY;
+    }
+    if (o == 0) *a.dense_count = 0;
+}
+
+// one lane per surfel: sprite extent (splat.vert:64-85), then one atomicMin per surviving fragment
+__global__ __launch_bounds__(256) void sf_predict_splat_kernel(PredictArgs a) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.count) return;
+    PV3 h, n;
+    float rad;
+    if (!surfel_to_camera(a, s, a.conf_low, h, n, rad)) return;  // conf_low <= conf_high: the low pass is the superset
+    const bool high = !(a.surfels[(size_t)s * 12 + 3] < a.conf_high);
+    const float fcols = float(a.cols), frows = float(a.rows);
+    const float ndc_x = ((((a.fx * h.x) / h.z) + a.cx) - (fcols * 0.5f)) / (fcols * 0.5f);
+    const float ndc_y = ((((a.fy * h.y) / h.z) + a.cy) - (frows * 0.5f)) / (frows * 0.5f);
+    if (!(ndc_x >= -1.f && ndc_x <= 1.f && ndc_y >= -1.f && ndc_y <= 1.f)) return;
+    const float xw = (ndc_x + 1.f) * (fcols * 0.5f), yw = (ndc_y + 1.f) * (frows * 0.5f);
+    const PV3 x1 = pmul(pmul(pnormalize(PV3{n.y - n.z, -n.x, n.x}), rad), 1.41421356f);
+    const PV3 y1 = pcross(n, x1);
+    const PV3 c1 = padd(h, x1), c2 = padd(h, y1), c3 = psub(h, y1), c4 = psub(h, x1);
+    const float p1x = ((a.fx * c1.x) / c1.z) + a.cx, p1y = ((a.fy * c1.y) / c1.z) + a.cy;
+    const float p2x = ((a.fx * c2.x) / c2.z) + a.cx, p2y = ((a.fy * c2.y) / c2.z) + a.cy;
+    const float p3x = ((a.fx * c3.x) / c3.z) + a.cx, p3y = ((a.fy * c3.y) / c3.z) + a.cy;
+    const float p4x = ((a.fx * c4.x) / c4.z) + a.cx, p4y = ((a.fy * c4.y) / c4.z) + a.cy;
+    const float xDiff = fabsf(fmaxf(p1x, fmaxf(p2x, fmaxf(p3x, p4x))) - fminf(p1x, fminf(p2x, fminf(p3x, p4x))));
+    const float yDiff = fabsf(fmaxf(p1y, fmaxf(p2y, fmaxf(p3y, p4y))) - fminf(p1y, fminf(p2y, fminf(p3y, p4y))));
+    const float size = fmaxf(0.f, fmaxf(xDiff, yDiff));
+    if (!(size > 0.f)) return;
+    const float half = size * 0.5f;
+    const int i0 = max(0, (int)ceilf(xw - half - 0.5f)), i1 = min(a.cols - 1, (int)floorf(xw + half - 0.5f));
+    const int j0 = max(0, (int)ceilf(yw - half - 0.5f)), j1 = min(a.rows - 1, (int)floorf(yw + half - 0.5f));
+    for (int j = j0; j <= j1; j++)
+        for (int i = i0; i <= i1; i++) {
+            float z, depth;
+            if (!surfel_fragment(a, h, n, rad, i, j, z, depth)) continue;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned)s;
+            const int o = j * a.cols + i;
+            atomicMin(a.key_low + o, key);
+            if (high) atomicMin(a.key_high + o, key);
+        }
+}
+
+// z and colour bytes of the fragment that won pixel (i, j) in one target (0 / black where nothing was drawn)
+__device__ __forceinline__ void resolve_pixel(const PredictArgs &a, unsigned long long key, int i, int j, float &z, int &r, int &g, int &b) {
+    z = 0.f;
+    r = g = b = 0;
+    if (key == SF_PRED_EMPTY) return;
+    const int s = (int)(unsigned)(key & 0xffffffffull);
+    PV3 h, n;
+    float rad, depth;
+    surfel_to_camera(a, s, -1.0e30f, h, n, rad);
+    surfel_fragment(a, h, n, rad, i, j, z, depth);
+    const int c = (int)a.surfels[(size_t)s * 12 + 4];  // color.glsl decodeColor; the RGBA8 target holds the bytes
+    r = (c >> 16) & 0xFF;
+    g = (c >> 8) & 0xFF;
+    b = c & 0xFF;
+}
+
+// Resize to (cols/40) x (rows/40) + denseEnough: counts the sampled low-confidence pixels with all channels > 0
+__global__ __launch_bounds__(64) void sf_predict_dense_kernel(PredictArgs a) {
+    const int rw = a.cols / 40, rh = a.rows / 40;
+    int sum = 0;
+    for (int q = threadIdx.x; q < rw * rh; q += 64) {
+        const int j = q / rw, i = q - j * rw;
+        const int sx = min(a.cols - 1, (int)(((float(i) + 0.5f) / float(rw)) * float(a.cols)));
+        const int sy = min(a.rows - 1, (int)(((float(j) + 0.5f) / float(rh)) * float(a.rows)));
+        float z;
+        int r, g, b;
+        resolve_pixel(a, a.key_low[sy * a.cols + sx], sx, sy, z, r, g, b);
+        sum += (r > 0 && g > 0 && b > 0) ? 1 : 0;
+    }
+    sum = wave_sum_i32(sum);
+    if (threadIdx.x == 0) *a.dense_count = sum;
+}
+
+// per pixel: resolve both targets, fill-in, extract depth, intensity (lanes along y: the outputs are column-major)
+__global__ __launch_bounds__(256) void sf_predict_resolve_kernel(PredictArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // y + x * rows
+    if (idx >= a.rows * a.cols) return;
+    const int x = idx / a.rows, y = idx - x * a.rows;
+    const int o = y * a.cols + x;
+    const int rw = a.cols / 40, rh = a.rows / 40;
+    const bool dense = (rw * rh > 0) && (float(*a.dense_count) / float(rh * rw) > 0.25f);
+    float zl, zh;
+    int rl, gl, bl, rh_, gh, bh;
+    resolve_pixel(a, a.key_low[o], x, y, zl, rl, gl, bl);
+    resolve_pixel(a, a.key_high[o], x, y, zh, rh_, gh, bh);
+    const bool high_empty = (rh_ + gh + bh) == 0, low_empty = (rl + gl + bl) == 0;
+    float z;
+    int r, g, b;
+    if (!dense) {
+        float z1 = zl;
+        if (z1 == 0.f) {
+            const float zr = float(a.filtered_mm[o]) / 1000.0f;
+            z1 = (a.b_img[idx] > 0.6f) ? zr : 0.0f;
+        }
+        z = (zh == 0.f) ? z1 : zh;
+        int r1 = rl, g1 = gl, b1 = bl;
+        if (low_empty) {
+            r1 = a.color[(size_t)o * 3];
+            g1 = a.color[(size_t)o * 3 + 1];
+            b1 = a.color[(size_t)o * 3 + 2];
+        }
+        r = high_empty ? r1 : rh_;
+        g = high_empty ? g1 : gh;
+        b = high_empty ? b1 : bh;
+    } else {
+        z = (zh == 0.f) ? zl : zh;
+        r = high_empty ? rl : rh_;
+        g = high_empty ? gl : gh;
+        b = high_empty ? bl : bh;
+    }
+    a.depth_pred[idx] = (z > a.extract_max_depth || z <= 0.f) ? 0.f : z;
+    const float norm_factor = 1.f / 255.f;
+    const float fr = float(r) * norm_factor, fg = float(g) * norm_factor, fb = float(b) * norm_factor;
+    a.inten_pred[idx] = 0.299f * fr + 0.587f * fg + 0.114f * fb;
+}

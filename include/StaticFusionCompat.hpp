@@ -159,6 +159,16 @@ class StaticFusionCompat {
         check(sf_filter_depth(h_), "filter_depth");
         check(sf_get_current(h_, 0, depthCurrent.data(), nullptr), "get_current");
     }
+    // reference: reconstruction->getPredictedImages(depthPrediction, intensityPrediction), Reconstruction.cpp:628-720,
+    // without OpenGL: `surfels` is the global model in the reference's vertex layout (count x 12 floats),
+    // `currPose` the camera pose. Call it where the reference does: before the new frame is loaded.
+    void getPredictedImages(const float *surfels, int count, const sf::Matrix4f &currPose, int tick = 0) {
+        sf_model_params mp;
+        check(sf_default_model_params(h_, &mp), "default_model_params");
+        mp.time = mp.max_time = tick;
+        check(sf_predict_from_model(h_, 0, surfels, count, currPose.m, &mp), "predict_from_model");
+        check(sf_get_prediction(h_, 0, depthPrediction.data(), intensityPrediction.data()), "get_prediction");
+    }
     std::vector<uint16_t> depth_mm;   // cv::Mat depth_mm  (StaticFusion.h:71), rows x cols, row-major
     std::vector<uint8_t> color_full;  // cv::Mat color_full (StaticFusion.h:71), rows x cols x 3
     float depth_max = 4.5f;           // StaticFusion.h:77, FrontEnd.cpp:168

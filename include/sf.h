@@ -233,6 +233,9 @@ int SF_FN(default_model_params)(const sf_handle *h, sf_model_params *p);
  * and b image -- call this before sf_load_frame of the new frame. Writes depthPrediction / intensityPrediction. */
 int SF_FN(predict_from_model)(sf_handle *h, int stream, const float *surfels, int count, const float pose[16],
                               const sf_model_params *p);
+/* The same with the surfel buffer already in HBM (where a HIP-resident map keeps it); asynchronous on the handle's stream. */
+int SF_FN(predict_from_model_device)(sf_handle *h, int stream, const void *d_surfels, int count, const float pose[16],
+                                     const sf_model_params *p);
 /* depthPrediction / intensityPrediction (column-major float, rows*cols each; either may be NULL). */
 int SF_FN(get_prediction)(sf_handle *h, int stream, float *depth, float *intensity);
 

@@ -511,6 +511,9 @@ int sfo_predict_from_model(sf_handle *h, int stream, const float *surfels, int c
                             s.b_segm_perpixel.d.data(), s.depthPrediction.d.data(), s.intensityPrediction.d.data());
     return SF_OK;
 }
+int sfo_predict_from_model_device(sf_handle *h, int stream, const void *s, int count, const float pose[16], const sf_model_params *p) {
+    return sfo_predict_from_model(h, stream, (const float *)s, count, pose, p);
+}
 int sfo_get_prediction(sf_handle *h, int stream, float *depth, float *intensity) {
     if (int e = check_stream(h, stream)) return e;
     auto &s = *h->s[stream];

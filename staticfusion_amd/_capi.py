@@ -111,6 +111,7 @@ SIGNATURES = {
     "timed_input_stage": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "default_model_params": (C.c_int, [_H, C.POINTER(SfModelParams)]),
     "predict_from_model": (C.c_int, [_H, C.c_int, _fp, C.c_int, _fp, C.POINTER(SfModelParams)]),
+    "predict_from_model_device": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int, _fp, C.POINTER(SfModelParams)]),
     "get_prediction": (C.c_int, [_H, C.c_int, _fp, _fp]),
     "build_pyramid": (C.c_int, [_H, C.c_int]),
     "kmeans": (C.c_int, [_H]),

@@ -838,24 +838,15 @@ static void invert_pose(const float pose[16], float out[16]) {
     for (int r = 0; r < 4; r++)
         for (int c = 0; c < 4; c++) out[r + 4 * c] = float(Ai[r * 4 + c]);
 }
-int sf_predict_from_model(sf_handle *h, int stream, const float *surfels, int count, const float pose[16], const sf_model_params *p) {
-    if (int e = check_stream(h, stream)) return e;
-    if ((!surfels && count > 0) || count < 0 || !pose || !p) return fail(SF_ERR_ARG, "bad argument");
-    HIP_TRY(hipSetDevice(h->device));
-    if (int e = input_alloc(h)) return e;
+static int predict_launch(sf_handle *h, int stream, const float *d_surfels, int count, const float pose[16], const sf_model_params *p) {
     const size_t n = h->k.n0;
     if (!h->pr_key_low) {
         if (int e = dev_alloc(h, &h->pr_key_low, n)) return e;
         if (int e = dev_alloc(h, &h->pr_key_high, n)) return e;
         if (int e = dev_alloc(h, &h->pr_dense, 1)) return e;
     }
-    if (h->pr_capacity < (size_t)count) {
-        if (int e = dev_alloc(h, &h->pr_surfels, (size_t)count * 12)) return e;  // grows; the old block is freed with the handle
-        h->pr_capacity = count;
-    }
-    if (count) HIP_TRY(hipMemcpyAsync(h->pr_surfels, surfels, (size_t)count * 12 * sizeof(float), hipMemcpyHostToDevice, h->stream));
     PredictArgs a;
-    a.surfels = h->pr_surfels;
+    a.surfels = d_surfels;
     a.count = count;
     invert_pose(pose, a.t_inv);  // t_inv = pose.inverse() (IndexMap.cpp:251)
     a.cx = p->cx; a.cy = p->cy; a.fx = p->fx; a.fy = p->fy;
@@ -875,8 +866,29 @@ int sf_predict_from_model(sf_handle *h, int stream, const float *surfels, int co
     hipLaunchKernelGGL(sf_predict_dense_kernel, dim3(1), dim3(64), 0, h->stream, a);
     hipLaunchKernelGGL(sf_predict_resolve_kernel, dim3(pix_blocks), dim3(256), 0, h->stream, a);
     HIP_TRY(hipGetLastError());
+    return SF_OK;
+}
+int sf_predict_from_model(sf_handle *h, int stream, const float *surfels, int count, const float pose[16], const sf_model_params *p) {
+    if (int e = check_stream(h, stream)) return e;
+    if ((!surfels && count > 0) || count < 0 || !pose || !p) return fail(SF_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (int e = input_alloc(h)) return e;
+    if (h->pr_capacity < (size_t)count) {
+        if (int e = dev_alloc(h, &h->pr_surfels, (size_t)count * 12)) return e;  // grows; the old block is freed with the handle
+        h->pr_capacity = count;
+    }
+    if (count) HIP_TRY(hipMemcpyAsync(h->pr_surfels, surfels, (size_t)count * 12 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (int e = predict_launch(h, stream, h->pr_surfels, count, pose, p)) return e;
     HIP_TRY(hipStreamSynchronize(h->stream));  // the host surfel buffer is free again; the staging block may be reused
     return SF_OK;
+}
+int sf_predict_from_model_device(sf_handle *h, int stream, const void *d_surfels, int count, const float pose[16],
+                                 const sf_model_params *p) {
+    if (int e = check_stream(h, stream)) return e;
+    if ((!d_surfels && count > 0) || count < 0 || !pose || !p) return fail(SF_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (int e = input_alloc(h)) return e;
+    return predict_launch(h, stream, (const float *)d_surfels, count, pose, p);
 }
 int sf_get_prediction(sf_handle *h, int stream, float *depth, float *intensity) {
     if (int e = check_stream(h, stream)) return e;

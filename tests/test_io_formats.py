@@ -217,3 +217,36 @@ def test_io_header_matches_library_exports():
     assert declared == sorted(sfio.SIGNATURES.keys())
     out = subprocess.check_output(["nm", "-D", "--defined-only", sfio.LIB]).decode()
     assert set(re.findall(r" T (sf_io_\w+)", out)) == set(declared)
+
+
+def build_example(tmp_path):
+    import subprocess
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    libdir = os.path.join(root, "staticfusion_amd", "csrc")
+    exe = str(tmp_path / "imagesequence_driver")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "imagesequence_driver.cpp"),
+                           "-o", exe, "-L" + libdir, "-lsf_hip", "-lsf_io", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cpp_example_driver_builds(tmp_path):
+    assert os.path.exists(build_example(tmp_path))
+
+
+@pytest.mark.gpu
+def test_cpp_example_driver_matches_the_python_runner(hip, lib, tmp_path):
+    """examples/imagesequence_driver.cpp (the reference's image-sequence main loop over StaticFusionCompat + sf_io)
+    writes the same trajectory file as tools/run_sequence.py: both are the same calls on the same device code."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from run_sequence import run
+
+    root = str(tmp_path / "ds")
+    write_dataset(root, 7)
+    exe = build_example(tmp_path)
+    out = str(tmp_path / "cpp.freiburg")
+    subprocess.check_call([exe, root, out])
+    _, lines, _ = run(hip, lib, root)
+    assert open(out).read() == "".join(lines)

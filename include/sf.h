@@ -30,6 +30,7 @@
 #ifndef SF_H_
 #define SF_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -152,6 +153,16 @@ int SF_FN(set_prediction)(sf_handle *h, int stream, const float *depth, const fl
  * (what an MI355X-resident producer such as a HIP renderer / loader hands over). */
 int SF_FN(set_current_device)(sf_handle *h, const void *d_depth, const void *d_intensity);
 int SF_FN(set_prediction_device)(sf_handle *h, const void *d_depth, const void *d_intensity);
+/* Overlapped upload for PCIe-fed deployments: sf_upload_current_async starts copying depthCurrent / intensityCurrent
+ * of the WHOLE batch (host buffers laid out [batch][cols][rows]; page-locked memory from sf_alloc_pinned makes the
+ * copy truly asynchronous) into a staging block on a second HIP stream and returns at once -- the solver launches
+ * already queued on the handle's stream keep running meanwhile. sf_commit_upload makes the handle's stream wait (on
+ * the device) for the copy and moves the frames into place; the host buffers may be refilled after it returns AND
+ * the copy has finished (sf_synchronize, or the next sf_upload_current_async, which orders itself after it). */
+int SF_FN(upload_current_async)(sf_handle *h, const float *depth_batch, const float *intensity_batch);
+int SF_FN(commit_upload)(sf_handle *h);
+int SF_FN(alloc_pinned)(size_t bytes, void **out);
+int SF_FN(free_pinned)(void *p);
 /* The bootstrap `depthCurrent.swap(depthPrediction)` (StaticFusion-imagesequenceassoc.cpp:105-108):
  * prediction := current, for every stream. */
 int SF_FN(current_to_prediction)(sf_handle *h);

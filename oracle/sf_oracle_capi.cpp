@@ -6,6 +6,7 @@
 #include "../include/sf.h"
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -178,6 +179,31 @@ int sfo_set_prediction_device(sf_handle *h, const void *d, const void *i) {
     if (!h || !d || !i) return fail(SF_ERR_ARG, "null");
     const size_t n = size_t(h->rows) * h->cols;
     for (int b = 0; b < h->batch; b++) sfo_set_prediction(h, b, (const float *)d + b * n, (const float *)i + b * n);
+    return SF_OK;
+}
+// the CPU oracle has no second stream: the "asynchronous" upload copies at commit time from the caller's buffers
+static const float *g_up_d = nullptr, *g_up_i = nullptr;
+int sfo_upload_current_async(sf_handle *h, const float *d, const float *i) {
+    if (!h || !d || !i) return fail(SF_ERR_ARG, "null");
+    if (g_up_d) return fail(SF_ERR_STATE, "an upload is already pending: call sf_commit_upload first");
+    g_up_d = d;
+    g_up_i = i;
+    return SF_OK;
+}
+int sfo_commit_upload(sf_handle *h) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    if (!g_up_d) return fail(SF_ERR_STATE, "no upload pending");
+    const int e = sfo_set_current_device(h, g_up_d, g_up_i);
+    g_up_d = g_up_i = nullptr;
+    return e;
+}
+int sfo_alloc_pinned(size_t bytes, void **out) {
+    if (!out) return fail(SF_ERR_ARG, "null");
+    *out = std::malloc(bytes ? bytes : 1);
+    return *out ? SF_OK : fail(SF_ERR_NOMEM, "malloc");
+}
+int sfo_free_pinned(void *p) {
+    std::free(p);
     return SF_OK;
 }
 int sfo_current_to_prediction(sf_handle *h) {

@@ -99,6 +99,10 @@ SIGNATURES = {
     "set_prediction": (C.c_int, [_H, C.c_int, _fp, _fp]),
     "set_current_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "set_prediction_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    "upload_current_async": (C.c_int, [_H, _fp, _fp]),
+    "commit_upload": (C.c_int, [_H]),
+    "alloc_pinned": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "free_pinned": (C.c_int, [C.c_void_p]),
     "current_to_prediction": (C.c_int, [_H]),
     "set_segm_state": (C.c_int, [_H, C.c_int, _ip, _fp, _fp]),
     "set_twist_old": (C.c_int, [_H, C.c_int, _fp]),

@@ -142,6 +142,11 @@ struct sf_handle {
     int *pr_dense = nullptr;
     float *pr_surfels = nullptr;
     size_t pr_capacity = 0;
+    // overlapped host -> HBM upload of the next frames (sf_upload_current_async): copy stream, staging, event
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_done = nullptr, compute_done = nullptr;
+    float *up_depth = nullptr, *up_inten = nullptr;
+    bool upload_pending = false;
 };
 
 static thread_local std::string g_err;
@@ -253,6 +258,9 @@ void sf_destroy(sf_handle *h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->evk0) (void)hipEventDestroy(h->evk0);
     if (h->evk1) (void)hipEventDestroy(h->evk1);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->copy_done) (void)hipEventDestroy(h->copy_done);
+    if (h->compute_done) (void)hipEventDestroy(h->compute_done);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -450,6 +458,47 @@ int sf_set_current_device(sf_handle *h, const void *d, const void *i) {
 int sf_set_prediction_device(sf_handle *h, const void *d, const void *i) {
     return h ? copy_batch_device(h, h->k.pyr_pred, d, i) : fail(SF_ERR_ARG, "null");
 }
+// ---- overlapped upload: the next batch of frames crosses PCIe on a second HIP stream while the solver runs ----
+int sf_upload_current_async(sf_handle *h, const float *depth_batch, const float *intensity_batch) {
+    if (!h || !depth_batch || !intensity_batch) return fail(SF_ERR_ARG, "null");
+    if (h->upload_pending) return fail(SF_ERR_STATE, "an upload is already pending: call sf_commit_upload first");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)h->k.n0 * h->k.batch;
+    if (!h->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&h->copy_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->compute_done, hipEventDisableTiming));
+        if (int e = dev_alloc(h, &h->up_depth, n)) return e;
+        if (int e = dev_alloc(h, &h->up_inten, n)) return e;
+    }
+    // the staging block may still be read by the previous commit's copy on the compute stream
+    HIP_TRY(hipStreamWaitEvent(h->copy_stream, h->compute_done, 0));
+    HIP_TRY(hipMemcpyAsync(h->up_depth, depth_batch, n * sizeof(float), hipMemcpyHostToDevice, h->copy_stream));
+    HIP_TRY(hipMemcpyAsync(h->up_inten, intensity_batch, n * sizeof(float), hipMemcpyHostToDevice, h->copy_stream));
+    HIP_TRY(hipEventRecord(h->copy_done, h->copy_stream));
+    h->upload_pending = true;
+    return SF_OK;
+}
+int sf_commit_upload(sf_handle *h) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    if (!h->upload_pending) return fail(SF_ERR_STATE, "no upload pending");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->copy_done, 0));  // device-side dependency: the host does not block
+    if (int e = copy_batch_device(h, h->k.pyr_new, h->up_depth, h->up_inten)) return e;
+    HIP_TRY(hipEventRecord(h->compute_done, h->stream));
+    h->upload_pending = false;
+    return SF_OK;
+}
+int sf_alloc_pinned(size_t bytes, void **out) {
+    if (!out) return fail(SF_ERR_ARG, "null");
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return SF_OK;
+}
+int sf_free_pinned(void *p) {
+    if (p) HIP_TRY(hipHostFree(p));
+    return SF_OK;
+}
+
 int sf_current_to_prediction(sf_handle *h) {
     if (!h) return fail(SF_ERR_ARG, "null");
     HIP_TRY(hipSetDevice(h->device));

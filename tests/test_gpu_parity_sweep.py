@@ -86,3 +86,50 @@ def test_bench_size_batch_duplicates_identical(hip, pair):
     for b in range(8, B):
         assert np.array_equal(T[b], T[b % 8]) and n_irls[b] == n_irls[b % 8] and pix[b] == pix[b % 8], b
     assert len({tuple(T[i].ravel()) for i in range(8)}) == 8  # and the distinct pairs give distinct poses
+
+
+def test_overlapped_upload_equals_direct_upload(hip, pair):
+    """sf_upload_current_async + sf_commit_upload (second HIP stream, page-locked host buffers) hands the solver the
+    same frames as sf_set_current, also when the next upload is in flight during a solve."""
+    import ctypes as C
+
+    B, n0 = 6, 120 * 160
+    prs = [pair(seed=40 + i, rows=120, cols=160) for i in range(3)]
+    fp = C.POINTER(C.c_float)
+    ref = make_solver(hip, 120, 160, config2_params(hip, levels=3), batch=B)
+    s = make_solver(hip, 120, 160, config2_params(hip, levels=3), batch=B)
+    host = []
+    for which in ("old", "new"):
+        pd, pi = C.c_void_p(), C.c_void_p()
+        hip.check(hip.alloc_pinned(4 * n0 * B, C.byref(pd)))
+        hip.check(hip.alloc_pinned(4 * n0 * B, C.byref(pi)))
+        d = np.ctypeslib.as_array(C.cast(pd, fp), shape=(B, n0))
+        i = np.ctypeslib.as_array(C.cast(pi, fp), shape=(B, n0))
+        for b in range(B):
+            d[b] = np.ascontiguousarray(prs[b % 3][which][0].T).ravel()
+            i[b] = np.ascontiguousarray(prs[b % 3][which][1].T).ravel()
+        host.append((C.cast(pd, fp), C.cast(pi, fp), pd, pi))
+    # reference path: frame "old" then "new" through the per-stream setters
+    for b in range(B):
+        ref.set_current(b, *prs[b % 3]["old"])
+    ref.current_to_prediction()
+    for b in range(B):
+        ref.set_current(b, *prs[b % 3]["new"])
+    ref.process_frame(0)
+    # overlapped path: the upload of "new" is issued while the (dummy) solve of "old" runs
+    hip.check(hip.upload_current_async(s.h, host[0][0], host[0][1]))
+    hip.check(hip.commit_upload(s.h))
+    s.current_to_prediction()
+    s.build_pyramid(True)  # some work on the compute stream
+    hip.check(hip.upload_current_async(s.h, host[1][0], host[1][1]))
+    assert hip.upload_current_async(s.h, host[1][0], host[1][1]) == -3  # SF_ERR_STATE: one upload at a time
+    hip.check(hip.commit_upload(s.h))
+    assert hip.commit_upload(s.h) == -3
+    s.process_frame(0)
+    Ta, _, _, _ = ref.batch_results()
+    Tb, _, _, _ = s.batch_results()
+    assert np.array_equal(Ta, Tb)
+    s.synchronize()
+    for hst in host:
+        hip.check(hip.free_pinned(hst[2]))
+        hip.check(hip.free_pinned(hst[3]))

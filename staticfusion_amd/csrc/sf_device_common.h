@@ -15,10 +15,12 @@
 
 #include "../../include/sf.h"
 
+// The frame kernels are compiled twice (sf_frame_kernels.hip): SF_NT = 256, four workgroups per CU -- the throughput
+// variant, thousands of streams -- and SF_NT = 1024, one 16-wave workgroup per CU and stream -- the latency variant,
+// up to a few hundred streams. The host (sf_hip.hip) picks one per handle.
 #ifndef SF_NT
-#define SF_NT 256          // threads per workgroup (4 waves; 4 workgroups resident per CU)
+#define SF_NT 256  // threads per workgroup
 #endif
-#define SF_BLOCKS_PER_CU (1024 / SF_NT)  // 16 waves per CU at <= 128 VGPRs (5 per CU measured 3 % slower: DESIGN.md §9)
 #define SF_NW (SF_NT / 64) // waves per workgroup
 #define SF_NC SF_NUM_CLUSTERS
 #define SF_INVALID_LABEL 255

@@ -1,0 +1,117 @@
+// sf_frame_kernels.hip — the persistent frame kernel (and the isolated IRLS pass kernel) of libsf_hip.so.
+// Compiled twice into the library: -DSF_NT=256 (throughput variant) and -DSF_NT=1024 (latency variant); every
+// workgroup-size dependent constant (waves per workgroup, tile and window sizes, LDS layout) derives from SF_NT.
+// The host side (sf_hip.hip) reaches the kernels through the two extern "C" launchers at the end.
+#include <hip/hip_runtime.h>
+
+#include "sf_device_common.h"
+#include "sf_kmeans.h"
+#include "sf_pyramid.h"
+#include "sf_residuals.h"
+#include "sf_smallmath.h"
+#include "sf_solver.h"
+
+#define SF_BLOCKS_PER_CU (1024 / SF_NT)  // 16 waves per CU at <= 128 VGPRs (5 x 256 per CU measured 3 % slower: DESIGN.md §9)
+#define SF_PASTE2(a, b) a##b
+#define SF_PASTE(a, b) SF_PASTE2(a, b)
+#define SF_VARIANT_FN(name) SF_PASTE(SF_PASTE(name, _nt), SF_NT)
+#define sf_frame_kernel SF_VARIANT_FN(sf_frame_kernel)
+#define sf_irls_pass_kernel SF_VARIANT_FN(sf_irls_pass_kernel)
+
+union FrameShared {
+    KmShared km;
+    SolveShared sv;
+    ResShared rs;
+};
+
+__global__ __launch_bounds__(SF_NT, SF_BLOCKS_PER_CU) void sf_frame_kernel(const KArgs *__restrict__ ka, int stage_mask, int im_count) {
+    __shared__ FrameShared sh;
+    __shared__ int s_next;
+    const KArgs &a = *ka;
+    const int tid = threadIdx.x;
+    for (;;) {
+        if (tid == 0) s_next = atomicAdd(a.queue, 1);
+        __syncthreads();
+        const int b = __builtin_amdgcn_readfirstlane(s_next);  // provably wave-uniform: scalar branches around the barriers
+        __syncthreads();
+        if (b >= a.batch) break;
+        long long t0 = 0, t1 = 0;
+        long long *prof = a.state[b].prof;
+#ifdef SF_NO_STAGE_TIMED
+#define STAGE_TIMED(slot, call) call
+#else
+#define STAGE_TIMED(slot, call)               \
+    do {                                      \
+        call;                                 \
+        if (tid == 0) {                       \
+            t1 = wall_clock64();              \
+            prof[slot] += t1 - t0;            \
+            t0 = t1;                          \
+        }                                     \
+    } while (0)
+#endif
+        const long long t_begin = wall_clock64();
+        t0 = t_begin;
+        if (stage_mask & ST_PYR_OLD) STAGE_TIMED(PF_PYR_OLD, stage_pyramid(a, b, true, tid));
+        if (stage_mask & ST_PYR_NEW) STAGE_TIMED(PF_PYR_NEW, stage_pyramid(a, b, false, tid));
+        if (stage_mask & ST_KMEANS) STAGE_TIMED(PF_KMEANS, stage_kmeans(a, b, *(LDS KmShared *)&sh.km, tid));
+        if (stage_mask & ST_SOLVE) {
+            stage_solve(a, b, *(LDS SolveShared *)&sh.sv, tid);
+            t0 = wall_clock64();
+        }
+        if (stage_mask & ST_RESIDUALS) STAGE_TIMED(PF_RESIDUALS, stage_residuals(a, b, im_count, *(LDS ResShared *)&sh.rs, tid));
+        __syncthreads();
+        if (stage_mask & ST_SEGM_IMAGE) stage_segm_image(a, b, tid);
+        if (stage_mask & ST_PUSH_HISTORY) stage_push_history(a, b, im_count, tid);
+        if (tid == 0) {
+            t1 = wall_clock64();
+            prof[PF_SEGM_HIST] += t1 - t0;
+            prof[PF_TOTAL] += t1 - t_begin;
+        }
+        // NOTE: the loop body must END with a barrier. With a lane-0-only block here the compiler
+        // fuses it with the lane-0-only queue pop at the loop top into an outer loop, and the other
+        // lanes of wave 0 then spin on the barrier of the inner loop forever (observed hang).
+        __syncthreads();
+    }
+}
+
+// the IRLS passes alone (measurement support; never part of a solve)
+__global__ __launch_bounds__(SF_NT, SF_BLOCKS_PER_CU) void sf_irls_pass_kernel(const KArgs *__restrict__ ka, int which, int variant, int reps, int slices) {
+    __shared__ FrameShared sh;
+    __shared__ int s_next;
+    const KArgs &a = *ka;
+    const int tid = threadIdx.x;
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (;;) {
+        if (tid == 0) s_next = atomicAdd(a.queue, 1);
+        __syncthreads();
+        const int item = __builtin_amdgcn_readfirstlane(s_next);
+        __syncthreads();
+        const int b = item / slices, slice = item - b * slices;
+        if (b >= a.batch) {
+            if (tid == 0 && blockIdx.x == 0) {  // shader clock estimate: s_memtime ticks per 100 MHz tick
+                a.state[0].prof[22] = clock64() - c0;
+                a.state[0].prof[23] = wall_clock64() - w0;
+            }
+            break;
+        }
+        if (which == 1) {
+            if (variant == 0) microbench_pass<1, 0>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
+            if (variant == 1) microbench_pass<1, 1>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
+            if (variant == 2) microbench_pass<1, 2>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
+        } else {
+            if (variant == 0) microbench_pass<2, 0>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
+            if (variant == 1) microbench_pass<2, 1>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
+            if (variant == 2) microbench_pass<2, 2>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
+        }
+        __syncthreads();
+    }
+}
+
+
+extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_launch_frame)(int grid, hipStream_t st, const KArgs *ka, int stage_mask, int im_count) {
+    hipLaunchKernelGGL(sf_frame_kernel, dim3(grid), dim3(SF_NT), 0, st, ka, stage_mask, im_count);
+}
+extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_launch_irls_pass)(int grid, hipStream_t st, const KArgs *ka, int which, int variant, int reps, int slices) {
+    hipLaunchKernelGGL(sf_irls_pass_kernel, dim3(grid), dim3(SF_NT), 0, st, ka, which, variant, reps, slices);
+}

@@ -11,108 +11,30 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "sf_device_common.h"
-#include "sf_kmeans.h"
-#include "sf_pyramid.h"
-#include "sf_residuals.h"
 #include "sf_input.h"
 #include "sf_predict.h"
-#include "sf_smallmath.h"
-#include "sf_solver.h"
 
-union FrameShared {
-    KmShared km;
-    SolveShared sv;
-    ResShared rs;
+// the two builds of the frame kernels (sf_frame_kernels.hip, -DSF_NT=256 / -DSF_NT=1024)
+struct FrameVariant {
+    const char *name;
+    int threads, blocks_per_cu;
+    void (*launch_frame)(int grid, hipStream_t st, const KArgs *ka, int stage_mask, int im_count);
+    void (*launch_irls_pass)(int grid, hipStream_t st, const KArgs *ka, int which, int variant, int reps, int slices);
 };
-
-__global__ __launch_bounds__(SF_NT, 4) void sf_frame_kernel(const KArgs *__restrict__ ka, int stage_mask, int im_count) {
-    __shared__ FrameShared sh;
-    __shared__ int s_next;
-    const KArgs &a = *ka;
-    const int tid = threadIdx.x;
-    for (;;) {
-        if (tid == 0) s_next = atomicAdd(a.queue, 1);
-        __syncthreads();
-        const int b = __builtin_amdgcn_readfirstlane(s_next);  // provably wave-uniform: scalar branches around the barriers
-        __syncthreads();
-        if (b >= a.batch) break;
-        long long t0 = 0, t1 = 0;
-        long long *prof = a.state[b].prof;
-#ifdef SF_NO_STAGE_TIMED
-#define STAGE_TIMED(slot, call) call
-#else
-#define STAGE_TIMED(slot, call)               \
-    do {                                      \
-        call;                                 \
-        if (tid == 0) {                       \
-            t1 = wall_clock64();              \
-            prof[slot] += t1 - t0;            \
-            t0 = t1;                          \
-        }                                     \
-    } while (0)
-#endif
-        const long long t_begin = wall_clock64();
-        t0 = t_begin;
-        if (stage_mask & ST_PYR_OLD) STAGE_TIMED(PF_PYR_OLD, stage_pyramid(a, b, true, tid));
-        if (stage_mask & ST_PYR_NEW) STAGE_TIMED(PF_PYR_NEW, stage_pyramid(a, b, false, tid));
-        if (stage_mask & ST_KMEANS) STAGE_TIMED(PF_KMEANS, stage_kmeans(a, b, *(LDS KmShared *)&sh.km, tid));
-        if (stage_mask & ST_SOLVE) {
-            stage_solve(a, b, *(LDS SolveShared *)&sh.sv, tid);
-            t0 = wall_clock64();
-        }
-        if (stage_mask & ST_RESIDUALS) STAGE_TIMED(PF_RESIDUALS, stage_residuals(a, b, im_count, *(LDS ResShared *)&sh.rs, tid));
-        __syncthreads();
-        if (stage_mask & ST_SEGM_IMAGE) stage_segm_image(a, b, tid);
-        if (stage_mask & ST_PUSH_HISTORY) stage_push_history(a, b, im_count, tid);
-        if (tid == 0) {
-            t1 = wall_clock64();
-            prof[PF_SEGM_HIST] += t1 - t0;
-            prof[PF_TOTAL] += t1 - t_begin;
-        }
-        // NOTE: the loop body must END with a barrier. With a lane-0-only block here the compiler
-        // fuses it with the lane-0-only queue pop at the loop top into an outer loop, and the other
-        // lanes of wave 0 then spin on the barrier of the inner loop forever (observed hang).
-        __syncthreads();
-    }
-}
-
-// the IRLS passes alone (measurement support; never part of a solve)
-__global__ __launch_bounds__(SF_NT, 4) void sf_irls_pass_kernel(const KArgs *__restrict__ ka, int which, int variant, int reps, int slices) {
-    __shared__ FrameShared sh;
-    __shared__ int s_next;
-    const KArgs &a = *ka;
-    const int tid = threadIdx.x;
-    const long long c0 = clock64(), w0 = wall_clock64();
-    for (;;) {
-        if (tid == 0) s_next = atomicAdd(a.queue, 1);
-        __syncthreads();
-        const int item = __builtin_amdgcn_readfirstlane(s_next);
-        __syncthreads();
-        const int b = item / slices, slice = item - b * slices;
-        if (b >= a.batch) {
-            if (tid == 0 && blockIdx.x == 0) {  // shader clock estimate: s_memtime ticks per 100 MHz tick
-                a.state[0].prof[22] = clock64() - c0;
-                a.state[0].prof[23] = wall_clock64() - w0;
-            }
-            break;
-        }
-        if (which == 1) {
-            if (variant == 0) microbench_pass<1, 0>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
-            if (variant == 1) microbench_pass<1, 1>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
-            if (variant == 2) microbench_pass<1, 2>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
-        } else {
-            if (variant == 0) microbench_pass<2, 0>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
-            if (variant == 1) microbench_pass<2, 1>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
-            if (variant == 2) microbench_pass<2, 2>(a, b, slice, slices, reps, *(LDS SolveShared *)&sh.sv, tid);
-        }
-        __syncthreads();
-    }
-}
+extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_nt256(int, hipStream_t, const KArgs *, int, int);
+extern "C" __attribute__((visibility("hidden"))) void sf_launch_irls_pass_nt256(int, hipStream_t, const KArgs *, int, int, int, int);
+extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_nt1024(int, hipStream_t, const KArgs *, int, int);
+extern "C" __attribute__((visibility("hidden"))) void sf_launch_irls_pass_nt1024(int, hipStream_t, const KArgs *, int, int, int, int);
+static const FrameVariant VARIANTS[2] = {
+    {"throughput (256 threads, 4 workgroups per CU)", 256, 4, sf_launch_frame_nt256, sf_launch_irls_pass_nt256},
+    {"latency (1024 threads, 1 workgroup per CU)", 1024, 1, sf_launch_frame_nt1024, sf_launch_irls_pass_nt1024},
+};
 
 // =============================================================================================
 //  host side
@@ -121,6 +43,7 @@ struct sf_handle {
     KArgs k{};
     int device = 0;
     int max_blocks = 0;
+    const FrameVariant *fv = &VARIANTS[0];
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
@@ -185,7 +108,7 @@ static int launch(sf_handle *h, int mask, int im_count) {
     const int grid = std::min(h->k.batch, h->max_blocks);
     const bool timed = (mask & ST_SOLVE) != 0;
     if (timed) HIP_TRY(hipEventRecord(h->evk0, h->stream));
-    hipLaunchKernelGGL(sf_frame_kernel, dim3(grid), dim3(SF_NT), 0, h->stream, (const KArgs *)h->d_args, mask, im_count);
+    h->fv->launch_frame(grid, h->stream, (const KArgs *)h->d_args, mask, im_count);
     HIP_TRY(hipGetLastError());
     if (timed) {
         HIP_TRY(hipEventRecord(h->evk1, h->stream));
@@ -321,7 +244,15 @@ int sf_create(const sf_params *p, int rows, int cols, int batch, int device, sf_
     HIP_OR_FREE(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_OR_FREE(hipGetDeviceProperties(&prop, device));
-    h->max_blocks = prop.multiProcessorCount * SF_BLOCKS_PER_CU;
+    // Few streams: one 1024-thread workgroup per stream and CU gives each stream four times the lanes (1.6-1.8x
+    // lower latency, and higher throughput up to ~2 streams per CU); many streams: four 256-thread workgroups per CU.
+    // SF_VARIANT=throughput|latency overrides the choice.
+    h->fv = &VARIANTS[(batch <= 2 * prop.multiProcessorCount) ? 1 : 0];
+    if (const char *v = std::getenv("SF_VARIANT")) {
+        if (!std::strcmp(v, "throughput")) h->fv = &VARIANTS[0];
+        if (!std::strcmp(v, "latency")) h->fv = &VARIANTS[1];
+    }
+    h->max_blocks = prop.multiProcessorCount * h->fv->blocks_per_cu;
     HIP_OR_FREE(hipStreamCreate(&h->own_stream));
     h->stream = h->own_stream;
     HIP_OR_FREE(hipEventCreate(&h->ev0));
@@ -1000,7 +931,7 @@ int sf_microbench_pass(sf_handle *h, int which, int variant, int reps, float *el
     HIP_TRY(hipMemsetAsync(h->k.queue, 0, sizeof(int), h->stream));
     const int grid = std::min(h->k.batch * slices, h->max_blocks);
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(sf_irls_pass_kernel, dim3(grid), dim3(SF_NT), 0, h->stream, (const KArgs *)h->d_args, which, variant, reps, slices);
+    h->fv->launch_irls_pass(grid, h->stream, (const KArgs *)h->d_args, which, variant, reps, slices);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev1));

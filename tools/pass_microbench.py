@@ -2,6 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import argparse
+os.environ.setdefault("SF_VARIANT", "throughput")  # the 256-thread build the numbers in DESIGN.md §5.1 refer to (a batch of 512 would select the other)
 import staticfusion_amd as sf
 from staticfusion_amd.synth import make_batch
 import bench

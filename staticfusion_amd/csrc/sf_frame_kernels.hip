@@ -12,9 +12,14 @@
 #include "sf_solver.h"
 
 #define SF_BLOCKS_PER_CU (1024 / SF_NT)  // 16 waves per CU at <= 128 VGPRs (5 x 256 per CU measured 3 % slower: DESIGN.md §9)
+// __launch_bounds__(threads, 4): the second HIP parameter is the minimum number of WAVES PER SIMD, not workgroups per
+// CU: 4 waves per SIMD = 16 waves per CU = <= 128 VGPRs for every workgroup size
 #define SF_PASTE2(a, b) a##b
 #define SF_PASTE(a, b) SF_PASTE2(a, b)
-#define SF_VARIANT_FN(name) SF_PASTE(SF_PASTE(name, _nt), SF_NT)
+#ifndef SF_VARIANT_TAG
+#define SF_VARIANT_TAG SF_NT
+#endif
+#define SF_VARIANT_FN(name) SF_PASTE(SF_PASTE(name, _nt), SF_VARIANT_TAG)
 #define sf_frame_kernel SF_VARIANT_FN(sf_frame_kernel)
 #define sf_irls_pass_kernel SF_VARIANT_FN(sf_irls_pass_kernel)
 
@@ -24,7 +29,7 @@ union FrameShared {
     ResShared rs;
 };
 
-__global__ __launch_bounds__(SF_NT, SF_BLOCKS_PER_CU) void sf_frame_kernel(const KArgs *__restrict__ ka, int stage_mask, int im_count) {
+__global__ __launch_bounds__(SF_NT, 4) void sf_frame_kernel(const KArgs *__restrict__ ka, int stage_mask, int im_count) {
     __shared__ FrameShared sh;
     __shared__ int s_next;
     const KArgs &a = *ka;
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(SF_NT, SF_BLOCKS_PER_CU) void sf_frame_kernel(const
 }
 
 // the IRLS passes alone (measurement support; never part of a solve)
-__global__ __launch_bounds__(SF_NT, SF_BLOCKS_PER_CU) void sf_irls_pass_kernel(const KArgs *__restrict__ ka, int which, int variant, int reps, int slices) {
+__global__ __launch_bounds__(SF_NT, 4) void sf_irls_pass_kernel(const KArgs *__restrict__ ka, int which, int variant, int reps, int slices) {
     __shared__ FrameShared sh;
     __shared__ int s_next;
     const KArgs &a = *ka;
@@ -114,4 +119,8 @@ extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_launch_fr
 }
 extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_launch_irls_pass)(int grid, hipStream_t st, const KArgs *ka, int which, int variant, int reps, int slices) {
     hipLaunchKernelGGL(sf_irls_pass_kernel, dim3(grid), dim3(SF_NT), 0, st, ka, which, variant, reps, slices);
+}
+extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_variant_geometry)(int *threads, int *blocks_per_cu) {
+    *threads = SF_NT;
+    *blocks_per_cu = SF_BLOCKS_PER_CU;
 }

@@ -23,7 +23,7 @@
 // the two builds of the frame kernels (sf_frame_kernels.hip, -DSF_NT=256 / -DSF_NT=1024)
 struct FrameVariant {
     const char *name;
-    int threads, blocks_per_cu;
+    void (*geometry)(int *threads, int *blocks_per_cu);
     void (*launch_frame)(int grid, hipStream_t st, const KArgs *ka, int stage_mask, int im_count);
     void (*launch_irls_pass)(int grid, hipStream_t st, const KArgs *ka, int which, int variant, int reps, int slices);
 };
@@ -31,9 +31,11 @@ extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_nt256(int,
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_irls_pass_nt256(int, hipStream_t, const KArgs *, int, int, int, int);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_nt1024(int, hipStream_t, const KArgs *, int, int);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_irls_pass_nt1024(int, hipStream_t, const KArgs *, int, int, int, int);
+extern "C" __attribute__((visibility("hidden"))) void sf_variant_geometry_nt256(int *, int *);
+extern "C" __attribute__((visibility("hidden"))) void sf_variant_geometry_nt1024(int *, int *);
 static const FrameVariant VARIANTS[2] = {
-    {"throughput (256 threads, 4 workgroups per CU)", 256, 4, sf_launch_frame_nt256, sf_launch_irls_pass_nt256},
-    {"latency (1024 threads, 1 workgroup per CU)", 1024, 1, sf_launch_frame_nt1024, sf_launch_irls_pass_nt1024},
+    {"throughput", sf_variant_geometry_nt256, sf_launch_frame_nt256, sf_launch_irls_pass_nt256},
+    {"latency", sf_variant_geometry_nt1024, sf_launch_frame_nt1024, sf_launch_irls_pass_nt1024},
 };
 
 // =============================================================================================
@@ -252,7 +254,9 @@ int sf_create(const sf_params *p, int rows, int cols, int batch, int device, sf_
         if (!std::strcmp(v, "throughput")) h->fv = &VARIANTS[0];
         if (!std::strcmp(v, "latency")) h->fv = &VARIANTS[1];
     }
-    h->max_blocks = prop.multiProcessorCount * h->fv->blocks_per_cu;
+    int wg_threads = 0, wg_per_cu = 0;
+    h->fv->geometry(&wg_threads, &wg_per_cu);
+    h->max_blocks = prop.multiProcessorCount * wg_per_cu;
     HIP_OR_FREE(hipStreamCreate(&h->own_stream));
     h->stream = h->own_stream;
     HIP_OR_FREE(hipEventCreate(&h->ev0));

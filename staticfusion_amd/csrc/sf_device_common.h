@@ -103,7 +103,6 @@ struct KArgs {
     float *rec[R_COUNT];  // [plane][batch][n0]
     uint8_t *rec_lab;     // [batch][n0]  label of a valid pixel, SF_INVALID_LABEL otherwise
     uint8_t *rec_null;    // [batch][n0]  Null mask of the last linearisation
-    float *km_sorted[3];  // [coord][batch][n1] K-means partition scratch
     uint8_t *km_lab_tmp;  // unused for now
     float *hist_d, *hist_i;  // [SF_HISTORY][batch][n0]
     float *b_img;            // [batch][n0]

@@ -264,7 +264,7 @@ int sf_create(const sf_params *p, int rows, int cols, int batch, int device, sf_
     HIP_OR_FREE(hipEventCreate(&h->evk0));
     HIP_OR_FREE(hipEventCreate(&h->evk1));
 
-    const size_t B = batch, NT = k.n_tot, N0 = k.n0, N1 = k.ln[1];
+    const size_t B = batch, NT = k.n_tot, N0 = k.n0;
     for (int c = 0; c < 2; c++) {  // depth, intensity; xx / yy are recomputed (level_coord), their table entries stay null
         TRY_OR_FREE(dev_alloc(h, &k.pyr_new[c], B * NT));
         TRY_OR_FREE(dev_alloc(h, &k.pyr_pred[c], B * NT));
@@ -280,7 +280,6 @@ int sf_create(const sf_params *p, int rows, int cols, int batch, int device, sf_
     for (int q = 0; q < R_COUNT; q++) TRY_OR_FREE(dev_alloc(h, &k.rec[q], B * N0));
     TRY_OR_FREE(dev_alloc(h, &k.rec_lab, B * N0));
     TRY_OR_FREE(dev_alloc(h, &k.rec_null, B * N0));
-    for (int c = 0; c < 3; c++) TRY_OR_FREE(dev_alloc(h, &k.km_sorted[c], B * N1));
     TRY_OR_FREE(dev_alloc(h, &k.hist_d, (size_t)SF_HISTORY * B * N0));
     TRY_OR_FREE(dev_alloc(h, &k.hist_i, (size_t)SF_HISTORY * B * N0));
     TRY_OR_FREE(dev_alloc(h, &k.b_img, B * N0));

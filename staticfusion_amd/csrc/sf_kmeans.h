@@ -18,6 +18,8 @@
 
 #include "sf_device_common.h"
 
+#define KM_CHUNK (SF_NT * SF_LOAD_BATCH)  // pixels per chunk of the Lloyd pass: SF_LOAD_BATCH per lane
+
 struct KmShared {
     float cent_a[3 * SF_NC], cent_b[3 * SF_NC];
     union {  // the radix-select histogram (initialisation only) and the centre-distance tables (Lloyd iterations onwards)
@@ -25,12 +27,14 @@ struct KmShared {
         struct {
             vfloat2 cand[SF_NC * SF_NC];    // row l: (distance to, index of) the other centres, ascending distance: one 8-byte LDS read
             float pair_dist[SF_NC * SF_NC];
+            float chunk[3][KM_CHUNK];       // (z, x, y) of one chunk of pixels, stably partitioned by cluster
         };
     };
     vfloat4 cent4[SF_NC];          // (z, x, y, 0) of centre l: one 16-byte LDS read
     int wcnt[SF_NW][SF_NC];        // members per (wave range, label); then exclusive offsets
     int count[SF_NC];
     int off[SF_NC];
+    int ccount[SF_NC];             // members of the current chunk per label
     unsigned conn[SF_NC];
     unsigned useed[SF_NC], vseed[SF_NC];
     unsigned prefix[SF_NC], krank[SF_NC];
@@ -225,39 +229,57 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
 
     KM_MARK(PF_KM_INIT);
     // ------------------------------------------------------------------ Lloyd iterations (K2)
-    const auto srt0 = as_global(a.km_sorted[0] + (size_t)b * n1), srt1 = as_global(a.km_sorted[1] + (size_t)b * n1),
-               srt2 = as_global(a.km_sorted[2] + (size_t)b * n1);
-    const int chunk = ((n1 + SF_NW - 1) / SF_NW + 63) & ~63;  // pixels per wave range, multiple of 64
-    const int w_begin = wave * chunk, w_end = min(n1, w_begin + chunk);
+    // One pass over the level per iteration, in chunks of KM_CHUNK pixels (pixel order): assign, partition the
+    // chunk stably by cluster in LDS, then 72 lanes -- one per (cluster, coordinate) -- extend their running float
+    // sums front to back (KMeans.cpp:215-221: centers_b.col(best_label) += p in pixel order; strictly sequential
+    // per sum, parallel across sums). Nothing but the labels goes back to memory.
+    const int n_chunks = (n1 + KM_CHUNK - 1) / KM_CHUNK;
     int iters = 0;
     for (int it = 0; it < 9; it++) {
         iters++;
         km_sort_centres(s, tid);
         KM_MARK(PF_KM_SORT);
-
-        // pass A: assignment + member counts of this wave range
-        int cnt = 0;  // lane l < 24 holds the count of label l
-        for (int base = w_begin; base < w_end; base += 64 * SF_LOAD_BATCH) {
-            float pz[SF_LOAD_BATCH], px[SF_LOAD_BATCH], py[SF_LOAD_BATCH];
-            int old[SF_LOAD_BATCH];
+        float acc = 0.f;   // lane (c, r) = tid < 72: running sum of coordinate r over the members of cluster c
+        int total = 0;     // lane l < 24 of wave 0: members of cluster l so far
+        float pz[SF_LOAD_BATCH], nz[SF_LOAD_BATCH];
+        int old[SF_LOAD_BATCH], nold[SF_LOAD_BATCH];
 #pragma unroll
-            for (int k = 0; k < SF_LOAD_BATCH; k++) {  // all loads of the batch in flight before the first search
-                const int idx = min(base + k * 64 + lane, n1 - 1);
-                int u, v;
-                split_uv(lc1, idx, u, v);
-                pz[k] = depth[o1 + idx];
-                px[k] = coord_x(lc1, u, pz[k]);
-                py[k] = coord_y(lc1, v, pz[k]);
-                old[k] = labels[o1 + idx];
-            }
+        for (int k = 0; k < SF_LOAD_BATCH; k++) {  // wave w owns pixels [256 w, 256 (w + 1)) of the chunk, k-major
+            const int idx = min(wave * (64 * SF_LOAD_BATCH) + k * 64 + lane, n1 - 1);
+            nz[k] = depth[o1 + idx];
+            nold[k] = labels[o1 + idx];
+        }
+        for (int ch = 0; ch < n_chunks; ch++) {
+            const int base = ch * KM_CHUNK + wave * (64 * SF_LOAD_BATCH);
+            float px[SF_LOAD_BATCH], py[SF_LOAD_BATCH];
             bool valid[SF_LOAD_BATCH];
             int best[SF_LOAD_BATCH];
 #pragma unroll
             for (int k = 0; k < SF_LOAD_BATCH; k++) {
-                valid[k] = (base + k * 64 + lane < w_end) && pz[k] != 0.f;
+                pz[k] = nz[k];
+                old[k] = nold[k];
+            }
+            if (ch + 1 < n_chunks) {  // the next chunk's loads are in flight during this one
+#pragma unroll
+                for (int k = 0; k < SF_LOAD_BATCH; k++) {
+                    const int idx = min(base + KM_CHUNK + k * 64 + lane, n1 - 1);
+                    nz[k] = depth[o1 + idx];
+                    nold[k] = labels[o1 + idx];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < SF_LOAD_BATCH; k++) {
+                const int idx = base + k * 64 + lane;
+                int u, v;
+                split_uv(lc1, min(idx, n1 - 1), u, v);
+                px[k] = coord_x(lc1, u, pz[k]);
+                py[k] = coord_y(lc1, v, pz[k]);
+                valid[k] = (idx < n1) && pz[k] != 0.f;
                 old[k] = valid[k] ? old[k] : 0;  // a safe table row for pixels that are not searched
             }
             km_search_n<SF_LOAD_BATCH>(s, old, pz, px, py, valid, best);
+            // members of this wave's part of the chunk per label (lane l < 24 holds the count of label l)
+            int cnt = 0;
 #pragma unroll
             for (int k = 0; k < SF_LOAD_BATCH; k++) {
                 const int idx = base + k * 64 + lane;
@@ -271,91 +293,69 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
                     rem &= ~m;
                 }
             }
-        }
-        if (lane < SF_NC) s.wcnt[wave][lane] = cnt;
-        __syncthreads();
-        KM_MARK(PF_KM_ASSIGN);
-        if (tid < SF_NC) {
-            int run = 0;
-            for (int w = 0; w < SF_NW; w++) {
-                const int c = s.wcnt[w][tid];
-                s.wcnt[w][tid] = run;
-                run += c;
+            if (lane < SF_NC) s.wcnt[wave][lane] = cnt;
+            __syncthreads();  // also: the previous chunk's sums have consumed s.chunk
+            if (tid < SF_NC) {  // exclusive offsets over the waves, chunk totals
+                int run = 0;
+                for (int w = 0; w < SF_NW; w++) {
+                    const int c = s.wcnt[w][tid];
+                    s.wcnt[w][tid] = run;
+                    run += c;
+                }
+                s.ccount[tid] = run;
             }
-            s.count[tid] = run;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int run = 0;
-            for (int l = 0; l < SF_NC; l++) {
-                s.off[l] = run;
-                run += s.count[l];
+            __syncthreads();
+            if (tid == 0) {
+                int run = 0;
+                for (int l = 0; l < SF_NC; l++) {
+                    s.off[l] = run;
+                    run += s.ccount[l];
+                }
             }
-        }
-        __syncthreads();
-
-        // pass B: stable partition into per-cluster runs
-        int running = (lane < SF_NC) ? (s.off[lane] + s.wcnt[wave][lane]) : 0;
-        for (int base = w_begin; base < w_end; base += 64 * SF_LOAD_BATCH) {
-            float pz[SF_LOAD_BATCH], px[SF_LOAD_BATCH], py[SF_LOAD_BATCH];
-            int labk[SF_LOAD_BATCH];
-#pragma unroll
-            for (int k = 0; k < SF_LOAD_BATCH; k++) {
-                const int idx = min(base + k * 64 + lane, n1 - 1);
-                int u, v;
-                split_uv(lc1, idx, u, v);
-                pz[k] = depth[o1 + idx];
-                px[k] = coord_x(lc1, u, pz[k]);
-                py[k] = coord_y(lc1, v, pz[k]);
-                labk[k] = labels[o1 + idx];
-            }
+            __syncthreads();
+            // stable positions: cluster run start + members in earlier waves + members earlier in this wave
+            int running = (lane < SF_NC) ? (s.off[lane] + s.wcnt[wave][lane]) : 0;
 #pragma unroll
             for (int k = 0; k < SF_LOAD_BATCH; k++) {  // ascending pixel order: ranks stay stable
-                const int idx = base + k * 64 + lane;
-                const bool valid = idx < w_end && pz[k] != 0.f;
-                const int lab = valid ? labk[k] : 0;
-                unsigned long long rem = __ballot(valid);
+                const int lab = valid[k] ? best[k] : 0;
+                unsigned long long rem = __ballot(valid[k]);
                 while (rem) {
                     const int src = __ffsll((long long)rem) - 1;
                     const int l = __builtin_amdgcn_readlane(lab, src);
-                    const unsigned long long m = __ballot(valid && lab == l);
+                    const unsigned long long m = __ballot(valid[k] && lab == l);
                     const int start = __builtin_amdgcn_readlane(running, l);
-                    if (valid && lab == l) {
+                    if (valid[k] && lab == l) {
                         const int pos = start + __popcll(m & ((1ull << lane) - 1ull));
-                        srt0[pos] = pz[k];
-                        srt1[pos] = px[k];
-                        srt2[pos] = py[k];
+                        s.chunk[0][pos] = pz[k];
+                        s.chunk[1][pos] = px[k];
+                        s.chunk[2][pos] = py[k];
                     }
                     if (lane == l) running += __popcll(m);
                     rem &= ~m;
                 }
             }
+            __syncthreads();
+            if (tid < 3 * SF_NC) {  // the ordered sums, continued over this chunk's members
+                const int c = tid / 3, r = tid - 3 * c;
+                const int n = s.ccount[c], o = s.off[c];
+                int j = 0;
+                for (; j + 8 <= n; j += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) v[q] = s.chunk[r][o + j + q];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) acc += v[q];
+                }
+                for (; j < n; j++) acc += s.chunk[r][o + j];
+            }
+            if (tid < SF_NC) total += s.ccount[tid];
         }
         __syncthreads();
-
-        KM_MARK(PF_KM_PARTITION);
-        // sequential float sums, one (cluster, coordinate) per lane (KMeans.cpp:215-221)
+        if (tid < SF_NC) s.count[tid] = total;
+        __syncthreads();
+        KM_MARK(PF_KM_ASSIGN);
         if (tid < 3 * SF_NC) {
-            const int c = tid / 3, r = tid - 3 * c;
-            const gptr<float> src = (r == 0 ? srt0 : (r == 1 ? srt1 : srt2)) + s.off[c];
-            const int n = s.count[c];
-            float acc = 0.f;
-            int j = 0;
-            for (; j + 64 <= n; j += 64) {  // 64 loads in flight (only 72 lanes run here), then strictly ordered adds
-                float v[64];
-#pragma unroll
-                for (int q = 0; q < 64; q++) v[q] = src[j + q];
-#pragma unroll
-                for (int q = 0; q < 64; q++) acc += v[q];
-            }
-            for (; j + 16 <= n; j += 16) {
-                float v[16];
-#pragma unroll
-                for (int q = 0; q < 16; q++) v[q] = src[j + q];
-#pragma unroll
-                for (int q = 0; q < 16; q++) acc += v[q];
-            }
-            for (; j < n; j++) acc += src[j];
+            const int n = s.count[tid / 3];
             if (n > 0) acc /= float(n);
             s.cent_b[tid] = acc;  // cent_b[r + 3c] with tid = 3c + r
         }

@@ -160,21 +160,31 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
         s.prefix[tid] = 0;
     }
     __syncthreads();
-    for (int idx = tid; idx < n1; idx += SF_NT) {
-        const unsigned u = idx / rows_km, v = idx - u * rows_km;
-        unsigned lab = SF_NC;
-        if (depth[o1 + idx] != 0.f) {
-            unsigned min_dist = 1000000u;
-            for (unsigned l = 0; l < SF_NC; l++) {
-                const unsigned dv = v - s.vseed[l], du = u - s.useed[l];  // unsigned wrap-around as in the reference
-                const unsigned q = dv * dv + du * du;
-                if (q < min_dist) {
-                    lab = l;
-                    min_dist = q;
+    for (int base = tid; base < n1; base += SF_NT * SF_LOAD_BATCH) {
+        float dz[SF_LOAD_BATCH];
+#pragma unroll
+        for (int k = 0; k < SF_LOAD_BATCH; k++) dz[k] = depth[o1 + min(base + k * SF_NT, n1 - 1)];
+#pragma unroll
+        for (int k = 0; k < SF_LOAD_BATCH; k++) {
+            const int idx = base + k * SF_NT;
+            if (idx >= n1) continue;
+            int ui, vi;
+            split_uv(lc1, idx, ui, vi);
+            const unsigned u = (unsigned)ui, v = (unsigned)vi;
+            unsigned lab = SF_NC;
+            if (dz[k] != 0.f) {
+                unsigned min_dist = 1000000u;
+                for (unsigned l = 0; l < SF_NC; l++) {
+                    const unsigned dv = v - s.vseed[l], du = u - s.useed[l];  // unsigned wrap-around as in the reference
+                    const unsigned q = dv * dv + du * du;
+                    if (q < min_dist) {
+                        lab = l;
+                        min_dist = q;
+                    }
                 }
             }
+            labels[o1 + idx] = (uint8_t)lab;
         }
-        labels[o1 + idx] = (uint8_t)lab;
     }
     __syncthreads();
     // per-seed median depth: radix select, most significant byte first
@@ -182,12 +192,18 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
         const int shift = 24 - 8 * pass;
         for (int q = tid; q < SF_NC * 256; q += SF_NT) s.hist[q] = 0;
         __syncthreads();
-        for (int idx = tid; idx < n1; idx += SF_NT) {
-            const unsigned lab = labels[o1 + idx];
-            if (lab < SF_NC) {
-                const unsigned bits = __float_as_uint(depth[o1 + idx]);
-                if (pass == 0 || (bits >> (shift + 8)) == s.prefix[lab]) lds_add(&s.hist[lab * 256 + ((bits >> shift) & 255u)], 1u);
+        for (int base = tid; base < n1; base += SF_NT * SF_LOAD_BATCH) {
+            unsigned lb[SF_LOAD_BATCH], bits[SF_LOAD_BATCH];
+#pragma unroll
+            for (int k = 0; k < SF_LOAD_BATCH; k++) {
+                const int idx = min(base + k * SF_NT, n1 - 1);
+                lb[k] = labels[o1 + idx];
+                bits[k] = __float_as_uint(depth[o1 + idx]);
             }
+#pragma unroll
+            for (int k = 0; k < SF_LOAD_BATCH; k++)
+                if (base + k * SF_NT < n1 && lb[k] < SF_NC && (pass == 0 || (bits[k] >> (shift + 8)) == s.prefix[lb[k]]))
+                    lds_add(&s.hist[lb[k] * 256 + ((bits[k] >> shift) & 255u)], 1u);
         }
         __syncthreads();
         if (tid < SF_NC) {
@@ -415,26 +431,42 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
     {
         const int rows0 = a.lrows[0], cols0 = a.lcols[0], n0 = a.ln[0];
         const float dist2_threshold = sqf(0.03f * 120.f / float(rows0));
-        for (int idx = tid; idx < n0; idx += SF_NT) {
-            const int u = idx / rows0, v = idx - u * rows0;
-            if (u >= cols0 - 1 || v >= rows0 - 1) continue;
-            // all ten loads first (independent), then the tests
-            const float dz = depth[idx], dzd = depth[idx + 1], dzr = depth[idx + rows0];
-            const float yc = coord_y(lc0, v, dz), yd = coord_y(lc0, v + 1, dzd), xc = coord_x(lc0, u, dz), xr = coord_x(lc0, u + 1, dzr);
-            const int la = labels[idx], ld = labels[idx + 1], lr = labels[idx + rows0];
-            if (dz == 0.f) continue;
-            if (la != ld && ld != SF_NC) {
-                const float disty = sqf(dz - dzd) + sqf(yc - yd);
-                if (disty < dist2_threshold) {
-                    lds_or(&s.conn[la], 1u << ld);
-                    lds_or(&s.conn[ld], 1u << la);
-                }
+        for (int base = tid; base < n0; base += SF_NT * SF_LOAD_BATCH) {  // SF_LOAD_BATCH pixels per lane: 6 x 4 loads in flight
+            float dz[SF_LOAD_BATCH], dzd[SF_LOAD_BATCH], dzr[SF_LOAD_BATCH];
+            int la[SF_LOAD_BATCH], ld[SF_LOAD_BATCH], lr[SF_LOAD_BATCH], uu[SF_LOAD_BATCH], vv[SF_LOAD_BATCH];
+            bool in[SF_LOAD_BATCH];
+#pragma unroll
+            for (int q = 0; q < SF_LOAD_BATCH; q++) {
+                const int idx = min(base + q * SF_NT, n0 - 1);
+                split_uv(lc0, idx, uu[q], vv[q]);
+                in[q] = (base + q * SF_NT < n0) && uu[q] < cols0 - 1 && vv[q] < rows0 - 1;
+                const int i1 = in[q] ? idx + 1 : idx, i2 = in[q] ? idx + rows0 : idx;  // the last row / column has no neighbour
+                dz[q] = depth[idx];
+                dzd[q] = depth[i1];
+                dzr[q] = depth[i2];
+                la[q] = labels[idx];
+                ld[q] = labels[i1];
+                lr[q] = labels[i2];
             }
-            if (la != lr && lr != SF_NC) {
-                const float distx = sqf(dz - dzr) + sqf(xc - xr);
-                if (distx < dist2_threshold) {
-                    lds_or(&s.conn[la], 1u << lr);
-                    lds_or(&s.conn[lr], 1u << la);
+#pragma unroll
+            for (int q = 0; q < SF_LOAD_BATCH; q++) {
+                if (!in[q] || dz[q] == 0.f) continue;
+                const int u = uu[q], v = vv[q];
+                const float yc = coord_y(lc0, v, dz[q]), yd = coord_y(lc0, v + 1, dzd[q]);
+                const float xc = coord_x(lc0, u, dz[q]), xr = coord_x(lc0, u + 1, dzr[q]);
+                if (la[q] != ld[q] && ld[q] != SF_NC) {
+                    const float disty = sqf(dz[q] - dzd[q]) + sqf(yc - yd);
+                    if (disty < dist2_threshold) {
+                        lds_or(&s.conn[la[q]], 1u << ld[q]);
+                        lds_or(&s.conn[ld[q]], 1u << la[q]);
+                    }
+                }
+                if (la[q] != lr[q] && lr[q] != SF_NC) {
+                    const float distx = sqf(dz[q] - dzr[q]) + sqf(xc - xr);
+                    if (distx < dist2_threshold) {
+                        lds_or(&s.conn[la[q]], 1u << lr[q]);
+                        lds_or(&s.conn[lr[q]], 1u << la[q]);
+                    }
                 }
             }
         }

@@ -15,6 +15,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs an MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def built_libraries():
+    """A fresh checkout has no binaries (they are git-ignored): build the product libraries and the test oracle once.
+    hipcc cross-compiles gfx950 without a GPU; on the GPU box the prebuilt files travel with the snapshot."""
+    import subprocess
+
+    csrc = os.path.join(ROOT, "staticfusion_amd", "csrc")
+    if not (os.path.exists(os.path.join(csrc, "libsf_hip.so")) and os.path.exists(os.path.join(csrc, "libsf_io.so"))):
+        subprocess.check_call(["make", "-C", csrc])
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+
+
 @pytest.fixture(scope="session")
 def ora():
     """The CPU oracle (oracle/liboracle.so), built on demand with gcc."""

@@ -29,6 +29,22 @@
 #define TILE_LU (TILE_U + 2)
 #define TILE_N (TILE_LV * TILE_LU)
 
+// Per-pixel IRLS weights use the hardware reciprocal / reciprocal-square-root (1 ulp) instead of the
+// IEEE division + square root sequences (~10 VALU instructions each; pass 1 is VALU-bound). The
+// linearisation (max weights, records) stays bit-identical to the oracle; the solver result moves by
+// ~1e-7, three orders of magnitude inside the pose tolerance. -DSF_FAST_WEIGHTS=0 restores IEEE.
+#ifndef SF_FAST_WEIGHTS
+#define SF_FAST_WEIGHTS 1
+#endif
+#if SF_FAST_WEIGHTS
+__device__ __forceinline__ float vrsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float vrcpw(float x) { return __builtin_amdgcn_rcpf(x); }
+#else
+__device__ __forceinline__ float vrsq(float x) { return sqrtf(1.f / x); }
+__device__ __forceinline__ float vrcpw(float x) { return 1.f / x; }
+#endif
+
+
 struct LinTile {  // linearisation tile (with halo)
     float t_D[TILE_N], t_I[TILE_N];    // Inter depth / intensity
     float t_dn[TILE_N], t_in[TILE_N];  // new depth / intensity
@@ -262,7 +278,10 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
         s.prior_nonnull[tid] = 0;
         s.valid_cnt[tid] = 0;
     }
-    float max_c = 0.f, max_d = 0.f;
+    // The raw pre-weights w = sqrt(1 / (eps + e)) are needed only through their image maximum (:505-509), and w is a
+    // monotonic (non-increasing) function of e in float arithmetic too -- every step of it is -- so max w = w(min e),
+    // bit for bit: the pass tracks min e and evaluates the division and the square root once, at the end.
+    float min_ec = 3.0e38f, min_ed = 3.0e38f;
     double abs_c = 0.0, abs_d = 0.0;  // initial |res| = |B| sums (reference :588-590), scaled by 1/max afterwards
     int n_valid = 0;
 
@@ -376,12 +395,10 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                     // raw pre-weights (reference :487-502): only their global maxima are needed here
                     const float error_l_c = 10.f * (fabsf(dct_) + fabsf(dcu_) + fabsf(dcv_));
                     const float error_l_d = 200.f * (fabsf(ddt_) + fabsf(ddu_) + fabsf(ddv_));
-                    const float wc = sqrtf(1.f / (1.f + error_l_c));
-                    const float wd = sqrtf(1.f / (0.01f + error_l_d));
-                    max_c = (wc > max_c) ? wc : max_c;
-                    max_d = (wd > max_d) ? wd : max_d;
-                    abs_c += (double)(wc * fabsf(dct_));
-                    abs_d += (double)(wd * fabsf(ddt_));
+                    min_ec = (error_l_c < min_ec) ? error_l_c : min_ec;
+                    min_ed = (error_l_d < min_ed) ? error_l_d : min_ed;
+                    abs_c += (double)(vrsq(1.f + error_l_c) * fabsf(dct_));  // IRLS-side quantity: 1-ulp rsq like the passes
+                    abs_d += (double)(vrsq(0.01f + error_l_d) * fabsf(ddt_));
                     n_valid++;
                 }
                 rec[R_DW][idx] = dw;
@@ -430,8 +447,9 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
     }
 
     // global max of the raw pre-weights (reference :505-509) and the valid-pixel count
-    max_c = wave_max_f32(max_c);
-    max_d = wave_max_f32(max_d);
+    // min of non-negative floats through the max of (largest finite pattern - bits)
+    const float max_c = wave_max_f32(__int_as_float(0x7f7fffff - __float_as_int(min_ec)));
+    const float max_d = wave_max_f32(__int_as_float(0x7f7fffff - __float_as_int(min_ed)));
     n_valid = wave_sum_i32(n_valid);
     abs_c = wave_sum_f64(abs_c);
     abs_d = wave_sum_f64(abs_d);
@@ -444,18 +462,19 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
     }
     __syncthreads();
     if (tid == 0) {
-        float mc = 0.f, md = 0.f;
-        int nv = 0;
+        int tc = 0, td = 0, nv = 0;  // transformed minima, see above
         double ac = 0.0, ad = 0.0;
         for (int w = 0; w < SF_NW; w++) {
-            mc = (s.redf[w][0] > mc) ? s.redf[w][0] : mc;
-            md = (s.redf[w][1] > md) ? s.redf[w][1] : md;
+            tc = max(tc, __float_as_int(s.redf[w][0]));
+            td = max(td, __float_as_int(s.redf[w][1]));
             nv += s.redi[w];
             ac += s.red[w][0];
             ad += s.red[w][1];
         }
         s.init_abs_c = ac;
         s.init_abs_d = ad;
+        const float mc = sqrtf(1.f / (1.f + __int_as_float(0x7f7fffff - tc)));    // = max over validPixels of the raw weights_c
+        const float md = sqrtf(1.f / (0.01f + __int_as_float(0x7f7fffff - td)));  //   "    weights_d (reference :494-509)
         s.n_valid = nv;
         s.inv_max_c = (nv > 0) ? 1.f / mc : 0.f;
         s.inv_max_d = (nv > 0) ? 1.f / md : 0.f;
@@ -559,21 +578,6 @@ __device__ __noinline__ void solve_filter_and_update(const KArgs &a, LDS SolveSh
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float vabs(float x) { return fabsf(x); }
 __device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a, b, c); }
-
-// Per-pixel IRLS weights use the hardware reciprocal / reciprocal-square-root (1 ulp) instead of the
-// IEEE division + square root sequences (~10 VALU instructions each; pass 1 is VALU-bound). The
-// linearisation (max weights, records) stays bit-identical to the oracle; the solver result moves by
-// ~1e-7, three orders of magnitude inside the pose tolerance. -DSF_FAST_WEIGHTS=0 restores IEEE.
-#ifndef SF_FAST_WEIGHTS
-#define SF_FAST_WEIGHTS 1
-#endif
-#if SF_FAST_WEIGHTS
-__device__ __forceinline__ float vrsq(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ float vrcpw(float x) { return __builtin_amdgcn_rcpf(x); }
-#else
-__device__ __forceinline__ float vrsq(float x) { return sqrtf(1.f / x); }
-__device__ __forceinline__ float vrcpw(float x) { return 1.f / x; }
-#endif
 
 // T = float: one pixel per lane and step (packed pixel pairs buy nothing on gfx950, §5.1 of DESIGN.md)
 template <class T>

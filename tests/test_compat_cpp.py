@@ -65,3 +65,21 @@ def test_compat_driver_matches_oracle(tmp_path, ora, pair):
     assert float(got[1]) == pytest.approx(float(d.astype(np.float64).sum()), abs=1e-6)
     assert float(got[2]) == pytest.approx(float(i.astype(np.float64).sum()), abs=1e-6)
     assert int(got[3]) == int(so.input_image(0).astype(np.uint64).sum())
+
+
+def build_c_example(tmp_path):
+    exe = str(tmp_path / "batch_throughput")
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "batch_throughput.c"),
+                           "-o", exe, "-L" + LIBDIR, "-lsf_hip", "-Wl,-rpath," + LIBDIR, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lm"])
+    return exe
+
+
+def test_c_example_compiles_against_the_header(tmp_path):
+    """include/sf.h is a C header: examples/batch_throughput.c builds with a C compiler and links the library"""
+    assert os.path.exists(build_c_example(tmp_path))
+
+
+@pytest.mark.gpu
+def test_c_example_runs(tmp_path):
+    out = subprocess.check_output([build_c_example(tmp_path), "64", "3"]).decode()
+    assert "hip:gfx950" in out and "frames/s" in out

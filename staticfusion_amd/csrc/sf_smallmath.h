@@ -212,6 +212,92 @@ __device__ inline void jacobi_eig6_lds(LDS double *A, LDS double *V) {
     }
 }
 
+// The same two algorithms with the n independent element updates of every step spread over lanes 0..n-1 of one
+// wave (called by the whole wave; every element sees exactly the operations of the one-lane versions above, so the
+// results are bit-identical). LDS accesses of one wave execute in program order; the wave barriers keep the compiler
+// from moving them across the phases.
+__device__ inline void inverse_double_wave6(LDS volatile double *A, LDS volatile double *Ainv, int lane) {
+    const int n = 6;
+    if (lane < 36) Ainv[lane] = (lane / n == lane % n) ? 1.0 : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    for (int c = 0; c < n; c++) {
+        int p = c;  // pivot search: uniform, every lane reads the same column
+        double pv = fabs(A[c * n + c]);
+        for (int r = c + 1; r < n; r++) {
+            const double v = fabs(A[r * n + c]);
+            if (v > pv) {
+                pv = v;
+                p = r;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (p != c && lane < n) {  // lane j swaps column j of rows c and p
+            double t = A[c * n + lane];
+            A[c * n + lane] = A[p * n + lane];
+            A[p * n + lane] = t;
+            t = Ainv[c * n + lane];
+            Ainv[c * n + lane] = Ainv[p * n + lane];
+            Ainv[p * n + lane] = t;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double inv = 1.0 / A[c * n + c];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < n) {
+            A[c * n + lane] *= inv;
+            Ainv[c * n + lane] *= inv;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < n; r++) {
+            if (r == c) continue;
+            const double f = A[r * n + c];  // read by every lane BEFORE lane c overwrites it below
+            __builtin_amdgcn_wave_barrier();
+            if (f != 0.0 && lane < n) {
+                A[r * n + lane] -= f * A[c * n + lane];
+                Ainv[r * n + lane] -= f * Ainv[c * n + lane];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+__device__ inline void jacobi_eig6_wave(LDS volatile double *A, LDS volatile double *V, int lane) {
+    const int n = 6;
+    if (lane < 36) V[lane] = (lane / n == lane % n) ? 1.0 : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0, diag = 0.0;  // uniform: every lane sums the same elements in the same order
+        for (int i = 0; i < n; i++) {
+            diag += A[i * n + i] * A[i * n + i];
+            for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+        }
+        if (off <= 1e-60 || off <= 1e-34 * diag) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                __builtin_amdgcn_wave_barrier();
+                if (lane < n) {  // columns p, q of row `lane`; the eigenvector update is independent of A
+                    const double akp = A[lane * n + p], akq = A[lane * n + q];
+                    A[lane * n + p] = c * akp - s * akq;
+                    A[lane * n + q] = s * akp + c * akq;
+                    const double vkp = V[lane * n + p], vkq = V[lane * n + q];
+                    V[lane * n + p] = c * vkp - s * vkq;
+                    V[lane * n + q] = s * vkp + c * vkq;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < n) {  // rows p, q of column `lane`
+                    const double apk = A[p * n + lane], aqk = A[q * n + lane];
+                    A[p * n + lane] = c * apk - s * aqk;
+                    A[q * n + lane] = s * apk + c * aqk;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+    }
+}
+
 __device__ inline void skew_sq_d(const double w[3], double K[9], double K2[9]) {
     K[0] = 0;     K[1] = -w[2]; K[2] = w[1];
     K[3] = w[2];  K[4] = 0;     K[5] = -w[0];

@@ -505,31 +505,37 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
 // ---------------------------------------------------------------------------------------------
 //  filterEstimateAndComputeT (reference FrontEnd.cpp:713-772) + est_cov (:689). One lane.
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ void solve_filter_and_update(const KArgs &a, LDS SolveShared &s, int level) {
+// Called by the whole wave 0: the 6 x 6 inverse and the Jacobi sweeps use six lanes (same arithmetic per element as
+// one lane would do), everything else runs on lane 0.
+__device__ __noinline__ void solve_filter_and_update(const KArgs &a, LDS SolveShared &s, int level, int lane) {
     // est_cov = AtA.inverse() * res.squaredNorm()
     LDS double *Ad = s.dwork, *Ai = s.dwork + 36, *V = s.dwork + 72;
-    for (int i = 0; i < 36; i++) Ad[i] = (double)s.AtA[i];
-    inverse_double_lds(Ad, Ai, 6);
-    for (int i = 0; i < 36; i++) s.est_cov[i] = (float)Ai[i] * s.res_sqnorm;
+    if (lane < 36) Ad[lane] = (double)s.AtA[lane];
+    __builtin_amdgcn_wave_barrier();
+    inverse_double_wave6(Ad, Ai, lane);
+    if (lane < 36) s.est_cov[lane] = (float)Ai[lane] * s.res_sqnorm;
+    __builtin_amdgcn_wave_barrier();
 
     float twist[6];
     for (int i = 0; i < 6; i++) twist[i] = s.Var[i];
 
     if (a.p.use_motion_filter) {
-        bool finite = true;
         LDS double *S = Ad;  // reuse
-        for (int i = 0; i < 6; i++)
-            for (int j = 0; j <= i; j++) {
-                const double v = (double)s.est_cov[i * 6 + j];
-                if (!isfinite(v)) finite = false;
-                S[i * 6 + j] = v;
-                S[j * 6 + i] = v;
-            }
+        bool finite = true;
+        for (int i = 0; i < 6; i++)  // uniform: every lane looks at the same 21 values
+            for (int j = 0; j <= i; j++)
+                if (!isfinite((double)s.est_cov[i * 6 + j])) finite = false;
         if (!finite) {  // "Eigensolver couldn't find a solution. Pose is not updated"
-            s.status |= SF_STATUS_EIG_SKIPPED;
+            if (lane == 0) s.status |= SF_STATUS_EIG_SKIPPED;
             return;
         }
-        jacobi_eig6_lds(S, V);  // S diagonal = eigenvalues
+        if (lane < 36) {
+            const int i = lane / 6, j = lane - 6 * i;
+            S[lane] = (double)s.est_cov[(i >= j) ? i * 6 + j : j * 6 + i];  // the lower triangle, mirrored
+        }
+        __builtin_amdgcn_wave_barrier();
+        jacobi_eig6_wave(S, V, lane);  // S diagonal = eigenvalues
+        if (lane != 0) return;
         float kai_loc_sub[6], lt[6];
         log_twist_cm(s.T, lt);
         for (int i = 0; i < 6; i++) kai_loc_sub[i] = s.twist_old[i] - lt[i];
@@ -551,6 +557,7 @@ __device__ __noinline__ void solve_filter_and_update(const KArgs &a, LDS SolveSh
             twist[r] = (float)acc;
         }
     }
+    if (lane != 0) return;
 
     double xi[6], E[16];
     for (int i = 0; i < 6; i++) xi[i] = (double)twist[i];
@@ -1045,13 +1052,13 @@ __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level,
         if (__builtin_amdgcn_readfirstlane(s.ctrl)) break;
     }
 
+    if (tid == 0 && tr) {
+        tr->level = level; tr->k = kouter; tr->n_valid = N; tr->irls_iters = iters_done;
+        tr->aver_res = s.aver_res;
+        for (int c = 0; c < 6; c++) tr->var[c] = s.Var[c];
+    }
+    if (wave == 0) solve_filter_and_update(a, s, level, lane);
     if (tid == 0) {
-        if (tr) {
-            tr->level = level; tr->k = kouter; tr->n_valid = N; tr->irls_iters = iters_done;
-            tr->aver_res = s.aver_res;
-            for (int c = 0; c < 6; c++) tr->var[c] = s.Var[c];
-        }
-        solve_filter_and_update(a, s, level);
         if (tr) {
             for (int c = 0; c < 6; c++) tr->twist_level[c] = s.twist_level[c];
             for (int l = 0; l < SF_NC; l++) tr->b_segm[l] = s.b_segm[l];

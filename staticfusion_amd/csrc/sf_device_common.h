@@ -305,10 +305,6 @@ struct SplatGeom {
 // depth / intensity of a target pixel from its fixed-point accumulators: sum(w * value) / sum(w).
 // The integer sums are exact; one int64 -> float conversion and one IEEE float division round twice
 // (<= 1 ulp from the exact quotient, the same order as the reference's own float accumulation).
-__device__ __forceinline__ unsigned acc_weight(long long packed) {
-    const long long ipart = (long long)((unsigned long long)packed << (64 - ACC_W_SHIFT)) >> (64 - ACC_W_SHIFT);
-    return (unsigned)((packed - ipart) >> ACC_W_SHIFT);
-}
 __device__ __forceinline__ void normalise_acc(long long sd, long long packed, float &dw, float &iw) {
     const long long si = (long long)((unsigned long long)packed << (64 - ACC_W_SHIFT)) >> (64 - ACC_W_SHIFT);
     const float wf = (float)(unsigned)((packed - si) >> ACC_W_SHIFT);

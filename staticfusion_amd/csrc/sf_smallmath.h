@@ -174,47 +174,10 @@ __device__ inline void inverse_double_lds(LDS double *A, LDS double *Ainv, int n
     }
 }
 
-// cyclic Jacobi, symmetric 6x6: A is destroyed (diagonal = eigenvalues), V columns = eigenvectors
-__device__ inline void jacobi_eig6_lds(LDS double *A, LDS double *V) {
-    const int n = 6;
-    for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 60; sweep++) {
-        double off = 0.0, diag = 0.0;
-        for (int i = 0; i < n; i++) {
-            diag += A[i * n + i] * A[i * n + i];
-            for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
-        }
-        if (off <= 1e-60 || off <= 1e-34 * diag) break;
-        for (int p = 0; p < n - 1; p++)
-            for (int q = p + 1; q < n; q++) {
-                const double apq = A[p * n + q];
-                if (apq == 0.0) continue;
-                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < n; k++) {
-                    const double akp = A[k * n + p], akq = A[k * n + q];
-                    A[k * n + p] = c * akp - s * akq;
-                    A[k * n + q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < n; k++) {
-                    const double apk = A[p * n + k], aqk = A[q * n + k];
-                    A[p * n + k] = c * apk - s * aqk;
-                    A[q * n + k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < n; k++) {
-                    const double vkp = V[k * n + p], vkq = V[k * n + q];
-                    V[k * n + p] = c * vkp - s * vkq;
-                    V[k * n + q] = s * vkp + c * vkq;
-                }
-            }
-    }
-}
-
-// The same two algorithms with the n independent element updates of every step spread over lanes 0..n-1 of one
-// wave (called by the whole wave; every element sees exactly the operations of the one-lane versions above, so the
-// results are bit-identical). LDS accesses of one wave execute in program order; the wave barriers keep the compiler
+// 6 x 6 Gauss-Jordan inverse and cyclic Jacobi (symmetric 6 x 6: A is destroyed, diagonal = eigenvalues, V columns =
+// eigenvectors) with the n independent element updates of every step spread over lanes 0..n-1 of one wave (called by
+// the whole wave; every element sees exactly the operations a one-lane loop -- inverse_double_lds above, the oracle's
+// jacobi -- performs, so the results are bit-identical). LDS accesses of one wave execute in program order; the wave barriers keep the compiler
 // from moving them across the phases.
 __device__ inline void inverse_double_wave6(LDS volatile double *A, LDS volatile double *Ainv, int lane) {
     const int n = 6;

@@ -107,7 +107,6 @@ struct SolveShared {
 // ---------------------------------------------------------------------------------------------
 // Records are read through GLOBAL address-space pointers (global_load_*, not flat_load_*) and
 // SF_VEC consecutive pixels per lane (8- or 16-byte loads: more bytes in flight per wave).
-#define SF_VEC 2  // pixels per lane and iteration in the streaming passes (pixel pairs -> packed f32 math)
 typedef __attribute__((address_space(1))) const float gcfloat;
 typedef __attribute__((address_space(1))) const uint8_t gcu8;
 typedef __attribute__((address_space(1))) const vfloat2 gcfloat2;

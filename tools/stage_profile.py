@@ -11,11 +11,17 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--workload", default="static")
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--res-factor", type=int, default=2, help="2: QVGA 320x240 (the drivers' setting), 1: VGA 640x480")
 a = ap.parse_args()
 api = sf.load()
+rows, cols = 480 // a.res_factor, 640 // a.res_factor
 p = bench.make_params(api, a.workload)
-pairs = make_batch(8, sphere=(a.workload == "sphere"), distinct=8)
-s = sf.Solver(api, 240, 320, a.batch, p)
+if a.res_factor == 1 and a.workload == "static":
+    p.ctf_levels = 4  # one more level than at QVGA, the same coarsest resolution
+if a.res_factor == 1 and a.workload == "sphere":
+    p.ctf_levels = 6  # the constructor's log2(cols / 40) + 2
+pairs = make_batch(8, sphere=(a.workload == "sphere"), distinct=8, out_rows=rows, out_cols=cols)
+s = sf.Solver(api, rows, cols, a.batch, p)
 for b in range(a.batch):
     s.set_current(b, *pairs[b % 8]["new"]); s.set_prediction(b, *pairs[b % 8]["old"])
 for im in range(5):
@@ -25,7 +31,7 @@ p0 = s.stage_profile(); c0 = s.counters()
 ms = s.timed_process_frames(5, a.steps)
 p1 = s.stage_profile(); c1 = s.counters()
 frames = c1[0] - c0[0]
-print("workload %s batch %d: %.2f ms/step, %.0f frames/s, %.0f it/s" % (a.workload, a.batch, ms / a.steps, frames / (ms * 1e-3), (c1[1] - c0[1]) / (ms * 1e-3)))
+print("workload %s %dx%d batch %d: %.2f ms/step, %.0f frames/s, %.0f it/s" % (a.workload, cols, rows, a.batch, ms / a.steps, frames / (ms * 1e-3), (c1[1] - c0[1]) / (ms * 1e-3)))
 tot = p1["total"] - p0["total"]
 for k in s.STAGES:
     d = p1[k] - p0[k]

@@ -247,6 +247,17 @@ int SF_FN(predict_from_model)(sf_handle *h, int stream, const float *surfels, in
 /* The same with the surfel buffer already in HBM (where a HIP-resident map keeps it); asynchronous on the handle's stream. */
 int SF_FN(predict_from_model_device)(sf_handle *h, int stream, const void *d_surfels, int count, const float pose[16],
                                      const sf_model_params *p);
+/* GlobalModel::initialise (GlobalModel.cpp:200-258) = Reconstruction::computeFeedbackBuffers (Reconstruction.cpp:205-216,
+ * Shaders/vertex_feedback.vert/.geom) + Shaders/init_unstable.vert: the surfel model of the first fused frame, from
+ * what the stream holds after a solve -- RGB and DEPTH_METRIC of the frame loaded last (input stage), its filtered
+ * depth (depthCurrent) and the b image (WEIGHT): one surfel per pixel with 0 < depth <= max_depth, in the reference's
+ * point order (x outer, y inner): world position from the RAW depth, colour bytes encoded into one float, normal
+ * (central differences) and radius from the FILTERED depth, confidence = round(255 b) / 255, init time 1, last time =
+ * `time`. The raw and the filtered point lists are paired by emission index, as the two transform-feedback buffers
+ * are (:212-224). surfels_out: room for rows*cols*12 floats (host); *count = surfels written. The result is what
+ * sf_predict_from_model renders. */
+int SF_FN(init_model_from_frame)(sf_handle *h, int stream, const float pose[16], const sf_model_params *p, int time,
+                                 float *surfels_out, int *count);
 /* depthPrediction / intensityPrediction (column-major float, rows*cols each; either may be NULL). */
 int SF_FN(get_prediction)(sf_handle *h, int stream, float *depth, float *intensity);
 

@@ -540,6 +540,16 @@ int sfo_predict_from_model(sf_handle *h, int stream, const float *surfels, int c
 int sfo_predict_from_model_device(sf_handle *h, int stream, const void *s, int count, const float pose[16], const sf_model_params *p) {
     return sfo_predict_from_model(h, stream, (const float *)s, count, pose, p);
 }
+int sfo_init_model_from_frame(sf_handle *h, int stream, const float pose[16], const sf_model_params *p, int time, float *out, int *count) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!pose || !p || !out || !count) return fail(SF_ERR_ARG, "null");
+    if (!h->have_frame) return fail(SF_ERR_STATE, "sf_init_model_from_frame needs a loaded frame (sf_load_frame + sf_filter_depth)");
+    sfo::ModelParams mp{p->cx, p->cy, p->fx, p->fy, p->max_depth, p->conf_low, p->conf_high, p->time, p->max_time, p->time_delta, p->extract_max_depth};
+    auto &s = *h->s[stream];
+    *count = sfo::init_model_from_frame(h->depth_metric[stream].data(), s.depthCurrent.d.data(), h->color[stream].data(),
+                                        s.b_segm_perpixel.d.data(), h->rows, h->cols, pose, mp, time, out);
+    return SF_OK;
+}
 int sfo_get_prediction(sf_handle *h, int stream, float *depth, float *intensity) {
     if (int e = check_stream(h, stream)) return e;
     auto &s = *h->s[stream];

@@ -142,3 +142,80 @@ void predict_from_model(const float *surfels, int count, const float t_inv[16], 
         }
 }
 }  // namespace sfo
+
+// ------------------------------------------------------------------------------------------------
+//  GlobalModel::initialise (GlobalModel.cpp:200-258): the two vertex_feedback passes (Reconstruction.cpp:205-216,
+//  Shaders/vertex_feedback.vert, vertex_feedback.geom, geometry.glsl:19-41, surfels.glsl:19-35, color.glsl:19-25)
+//  and init_unstable.vert. Choices beyond the ones above: texel fetches clamp to the edge; GLSL round() = roundf.
+// ------------------------------------------------------------------------------------------------
+#include "../include/sf_detmath.h"
+namespace sfo {
+namespace {
+struct FeedbackVertex {
+    V3 pos, normal;
+    float radius;
+};
+// vertex_feedback.vert:40-52 for point (i, j) on a float depth image accessed through D(i, j)
+template <class Depth>
+bool feedback_vertex(const Depth &D, int i, int j, int rows, int cols, const ModelParams &p, FeedbackVertex &out) {
+    const float W = float(cols), H = float(rows);
+    const float tx = float(double(float(i) / W) + 1.0 / double(2 * W));  // FeedbackBuffer.cpp:46-47
+    const float ty = float(double(float(j) / H) + 1.0 / double(2 * H));
+    const float x = tx * W, y = ty * H;                                   // vertex_feedback.vert:40-41
+    const float camz = 1.0f / p.fx, camw = 1.0f / p.fy;                   // FeedbackBuffer.cpp:89-92
+    auto vertex = [&](int ii, int jj, float xx, float yy) {               // geometry.glsl:21-25
+        const float z = D(std::min(std::max(ii, 0), cols - 1), std::min(std::max(jj, 0), rows - 1));
+        return V3{(xx - p.cx) * z * camz, (yy - p.cy) * z * camw, z};
+    };
+    const V3 v = vertex(i, j, x, y);
+    const V3 xf = vertex(i + 1, j, x + 1.f, y), xb = vertex(i - 1, j, x - 1.f, y);  // geometry.glsl:30-34
+    const V3 yf = vertex(i, j + 1, x, y + 1.f), yb = vertex(i, j - 1, x, y - 1.f);
+    auto half_sum = [](V3 a, V3 b) { return V3{(a.x + b.x) / 2.f, (a.y + b.y) / 2.f, (a.z + b.z) / 2.f}; };
+    const V3 del_x = sub(half_sum(xb, v), half_sum(xf, v));               // :36-37
+    const V3 del_y = sub(half_sum(yb, v), half_sum(yf, v));
+    out.pos = v;
+    out.normal = normalize(cross(del_x, del_y));                          // :39
+    const float meanFocal = ((1.0f / std::fabs(camz)) + (1.0f / std::fabs(camw))) / 2.0f;  // surfels.glsl:21
+    const float radius = (v.z / meanFocal) * 1.41421356237f;              // :25
+    out.radius = std::fmin(2.0f * radius, radius / std::fabs(out.normal.z));  // :27-31
+    return !(v.z <= 0.f || v.z > p.max_depth);                            // vertex_feedback.vert:49-56, .geom:34
+}
+}  // namespace
+
+int init_model_from_frame(const float *depth_metric, const float *depth_filtered, const uint8_t *color, const float *b_img, int rows, int cols,
+                          const float pose[16], const ModelParams &p, int time, float *surfels) {
+    auto P = [&](int r, int c) { return pose[r + 4 * c]; };
+    auto Draw = [&](int i, int j) { return depth_metric[size_t(j) * cols + i]; };
+    auto Dfil = [&](int i, int j) { return depth_filtered[j + size_t(i) * rows]; };
+    const size_t cap = size_t(rows) * cols;
+    for (size_t q = 0; q < cap * 12; q++) surfels[q] = 0.f;  // the feedback buffers start zero-filled (FeedbackBuffer.cpp:30-32)
+    int n_raw = 0, n_fil = 0;
+    for (int i = 0; i < cols; i++)        // FeedbackBuffer.cpp:41-49: x outer, y inner
+        for (int j = 0; j < rows; j++) {
+            FeedbackVertex v;
+            if (feedback_vertex(Draw, i, j, rows, cols, p, v)) {  // RAW: position and colour (init_unstable.vert:36,43-45)
+                float *s = surfels + size_t(n_raw++) * 12;
+                s[0] = P(0, 0) * v.pos.x + P(0, 1) * v.pos.y + P(0, 2) * v.pos.z + P(0, 3);
+                s[1] = P(1, 0) * v.pos.x + P(1, 1) * v.pos.y + P(1, 2) * v.pos.z + P(1, 3);
+                s[2] = P(2, 0) * v.pos.x + P(2, 1) * v.pos.y + P(2, 2) * v.pos.z + P(2, 3);
+                const uint8_t *c = color + (size_t(j) * cols + i) * 3;
+                s[4] = float((int(c[0]) << 16) + (int(c[1]) << 8) + int(c[2]));  // encodeColor of the bytes
+                s[5] = 1.0f;         // hist weight
+                s[6] = 1.0f;         // initialisation time
+                s[7] = float(time);  // vertex_feedback.vert:64
+            }
+            if (feedback_vertex(Dfil, i, j, rows, cols, p, v)) {  // FILTERED: normal, radius, and b as its "colour"
+                float *s = surfels + size_t(n_fil++) * 12;
+                const int k = int(std::round(b_img[j + size_t(i) * rows] * 255.0f));  // encodeColor -> decodeColor(...).x
+                s[3] = float(k & 0xFF) / 255.0f;                                        // init_unstable.vert:38-40
+                s[8] = P(0, 0) * v.normal.x + P(0, 1) * v.normal.y + P(0, 2) * v.normal.z;  // :47
+                s[9] = P(1, 0) * v.normal.x + P(1, 1) * v.normal.y + P(1, 2) * v.normal.z;
+                s[10] = P(2, 0) * v.normal.x + P(2, 1) * v.normal.y + P(2, 2) * v.normal.z;
+                s[11] = v.radius;
+            }
+        }
+    // the draw call is sized by the RAW buffer (GlobalModel.cpp:236-237); slots beyond it are not part of the model
+    for (size_t q = size_t(n_raw) * 12; q < cap * 12; q++) surfels[q] = 0.f;
+    return n_raw;
+}
+}  // namespace sfo

@@ -12,3 +12,8 @@ struct ModelParams {
 void predict_from_model(const float *surfels, int count, const float t_inv[16], const ModelParams &p, int rows, int cols,
                         const uint16_t *filtered_mm, const uint8_t *color, const float *b_img, float *depth_pred, float *inten_pred);
 }  // namespace sfo
+namespace sfo {
+// depth_metric / color: rows x cols row-major; depth_filtered / b_img: column-major; pose column-major; returns the count
+int init_model_from_frame(const float *depth_metric, const float *depth_filtered, const uint8_t *color, const float *b_img, int rows, int cols,
+                          const float pose[16], const ModelParams &p, int time, float *surfels);
+}  // namespace sfo

@@ -116,6 +116,7 @@ SIGNATURES = {
     "default_model_params": (C.c_int, [_H, C.POINTER(SfModelParams)]),
     "predict_from_model": (C.c_int, [_H, C.c_int, _fp, C.c_int, _fp, C.POINTER(SfModelParams)]),
     "predict_from_model_device": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int, _fp, C.POINTER(SfModelParams)]),
+    "init_model_from_frame": (C.c_int, [_H, C.c_int, _fp, C.POINTER(SfModelParams), C.c_int, _fp, _ip]),
     "get_prediction": (C.c_int, [_H, C.c_int, _fp, _fp]),
     "build_pyramid": (C.c_int, [_H, C.c_int]),
     "kmeans": (C.c_int, [_H]),
@@ -273,6 +274,15 @@ class Solver:
         T = np.ascontiguousarray(np.asarray(pose, np.float32).T)  # column-major storage
         p = params if params is not None else self.default_model_params()
         self.api.check(self.api.predict_from_model(self.h, stream, s.ctypes.data_as(_fp), s.shape[0], T.ctypes.data_as(_fp), C.byref(p)))
+
+    def init_model_from_frame(self, stream, pose, params=None, time=1):
+        """GlobalModel::initialise on the frame the stream holds -> (count, 12) surfels in the reference's vertex layout"""
+        T = np.ascontiguousarray(np.asarray(pose, np.float32).T)
+        p = params if params is not None else self.default_model_params()
+        out = np.zeros((self.rows * self.cols, 12), np.float32)
+        n = C.c_int32()
+        self.api.check(self.api.init_model_from_frame(self.h, stream, T.ctypes.data_as(_fp), C.byref(p), time, out.ctypes.data_as(_fp), C.byref(n)))
+        return out[: n.value].copy()
 
     def prediction(self, stream=0):
         """(depthPrediction, intensityPrediction) as (rows, cols) arrays"""

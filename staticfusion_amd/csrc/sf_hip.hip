@@ -826,7 +826,7 @@ static int predict_launch(sf_handle *h, int stream, const float *d_surfels, int 
     if (!h->pr_key_low) {
         if (int e = dev_alloc(h, &h->pr_key_low, n)) return e;
         if (int e = dev_alloc(h, &h->pr_key_high, n)) return e;
-        if (int e = dev_alloc(h, &h->pr_dense, 1)) return e;
+        if (int e = dev_alloc(h, &h->pr_dense, 2)) return e;
     }
     PredictArgs a;
     a.surfels = d_surfels;
@@ -872,6 +872,40 @@ int sf_predict_from_model_device(sf_handle *h, int stream, const void *d_surfels
     HIP_TRY(hipSetDevice(h->device));
     if (int e = input_alloc(h)) return e;
     return predict_launch(h, stream, (const float *)d_surfels, count, pose, p);
+}
+int sf_init_model_from_frame(sf_handle *h, int stream, const float pose[16], const sf_model_params *p, int time, float *surfels_out,
+                             int *count) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!pose || !p || !surfels_out || !count) return fail(SF_ERR_ARG, "null");
+    if (!h->have_frame) return fail(SF_ERR_STATE, "sf_init_model_from_frame needs a loaded frame (sf_load_frame + sf_filter_depth)");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = h->k.n0;
+    if (h->pr_capacity < n) {
+        if (int e = dev_alloc(h, &h->pr_surfels, n * 12)) return e;
+        h->pr_capacity = n;
+    }
+    if (!h->pr_dense)
+        if (int e = dev_alloc(h, &h->pr_dense, 2)) return e;
+    HIP_TRY(hipMemsetAsync(h->pr_surfels, 0, n * 12 * sizeof(float), h->stream));  // the feedback buffers start zero-filled
+    InitModelArgs a;
+    a.depth_metric = h->in_depth_metric + (size_t)stream * n;
+    a.depth_filtered = h->k.pyr_new[0] + (size_t)stream * h->k.n_tot;
+    a.color = h->in_color + (size_t)stream * n * 3;
+    a.b_img = h->k.b_img + (size_t)stream * n;
+    a.rows = h->k.rows; a.cols = h->k.cols; a.time = time;
+    for (int q = 0; q < 16; q++) a.pose[q] = pose[q];
+    a.cx = p->cx; a.cy = p->cy; a.fx = p->fx; a.fy = p->fy; a.max_depth = p->max_depth;
+    a.out = h->pr_surfels;
+    a.count = h->pr_dense;
+    hipLaunchKernelGGL(sf_init_model_kernel, dim3(1), dim3(1024), 0, h->stream, a);
+    hipLaunchKernelGGL(sf_init_model_trim_kernel, dim3((unsigned)((n * 12 + 255) / 256)), dim3(256), 0, h->stream, h->pr_surfels,
+                       (const int *)h->pr_dense, (int)n);
+    HIP_TRY(hipGetLastError());
+    int counts[2] = {0, 0};
+    if (int e = d2h(h, counts, h->pr_dense, sizeof counts)) return e;
+    if (int e = d2h(h, surfels_out, h->pr_surfels, n * 12 * sizeof(float))) return e;
+    *count = counts[0];
+    return SF_OK;
 }
 int sf_get_prediction(sf_handle *h, int stream, float *depth, float *intensity) {
     if (int e = check_stream(h, stream)) return e;

@@ -193,3 +193,123 @@ __global__ __launch_bounds__(256) void sf_predict_resolve_kernel(PredictArgs a) 
     const float fr = float(r) * norm_factor, fg = float(g) * norm_factor, fb = float(b) * norm_factor;
     a.inten_pred[idx] = 0.299f * fr + 0.587f * fg + 0.114f * fb;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+//  GlobalModel::initialise (reference GlobalModel.cpp:200-258): the two vertex_feedback passes
+//  (Reconstruction.cpp:205-216, Shaders/vertex_feedback.vert/.geom, geometry.glsl:19-41, surfels.glsl:19-35) and
+//  init_unstable.vert. One 1024-thread workgroup walks the frame in the reference's point order (x outer, y inner =
+//  this repository's column-major index); the two transform-feedback streams are ordered compactions: ballot ranks
+//  per wave + an LDS prefix over the 16 waves + a running base per chunk.
+// ---------------------------------------------------------------------------------------------------------------
+struct InitModelArgs {
+    const float *depth_metric;    // rows x cols row-major (DEPTH_METRIC, raw)
+    const float *depth_filtered;  // column-major (depthCurrent after sf_filter_depth)
+    const uint8_t *color;         // rows x cols x 3
+    const float *b_img;           // column-major
+    int rows, cols, time;
+    float pose[16], cx, cy, fx, fy, max_depth;
+    float *out;                   // rows*cols*12, zero-filled
+    int *count;
+};
+
+struct FbVertex {
+    PV3 pos, normal;
+    float radius;
+};
+template <class Depth>
+__device__ __forceinline__ bool feedback_vertex(const Depth &D, int i, int j, const InitModelArgs &a, FbVertex &out) {
+    const float W = float(a.cols), H = float(a.rows);
+    const float tx = float(double(float(i) / W) + 1.0 / double(2 * W));  // FeedbackBuffer.cpp:46-47
+    const float ty = float(double(float(j) / H) + 1.0 / double(2 * H));
+    const float x = tx * W, y = ty * H;
+    const float camz = 1.0f / a.fx, camw = 1.0f / a.fy;
+    auto vertex = [&](int ii, int jj, float xx, float yy) {
+        const float z = D(min(max(ii, 0), a.cols - 1), min(max(jj, 0), a.rows - 1));
+        return PV3{(xx - a.cx) * z * camz, (yy - a.cy) * z * camw, z};
+    };
+    const PV3 v = vertex(i, j, x, y);
+    const PV3 xf = vertex(i + 1, j, x + 1.f, y), xb = vertex(i - 1, j, x - 1.f, y);
+    const PV3 yf = vertex(i, j + 1, x, y + 1.f), yb = vertex(i, j - 1, x, y - 1.f);
+    auto half_sum = [](PV3 p, PV3 q) { return PV3{(p.x + q.x) / 2.f, (p.y + q.y) / 2.f, (p.z + q.z) / 2.f}; };
+    const PV3 del_x = psub(half_sum(xb, v), half_sum(xf, v));
+    const PV3 del_y = psub(half_sum(yb, v), half_sum(yf, v));
+    out.pos = v;
+    out.normal = pnormalize(pcross(del_x, del_y));
+    const float meanFocal = ((1.0f / fabsf(camz)) + (1.0f / fabsf(camw))) / 2.0f;
+    const float radius = (v.z / meanFocal) * 1.41421356237f;
+    out.radius = fminf(2.0f * radius, radius / fabsf(out.normal.z));
+    return !(v.z <= 0.f || v.z > a.max_depth);
+}
+
+__global__ __launch_bounds__(1024) void sf_init_model_kernel(InitModelArgs a) {
+    __shared__ int wcount[2][16];
+    __shared__ int base[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = a.rows * a.cols;
+    if (tid < 2) base[tid] = 0;
+    __syncthreads();
+    const float *P = a.pose;
+    auto Draw = [&](int i, int j) { return a.depth_metric[(size_t)j * a.cols + i]; };
+    auto Dfil = [&](int i, int j) { return a.depth_filtered[j + (size_t)i * a.rows]; };
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int idx = c0 + tid;  // = j + i * rows: the reference's point order
+        const bool in = idx < n;
+        const int i = in ? idx / a.rows : 0, j = in ? idx - i * a.rows : 0;
+        FbVertex vr, vf;
+        const bool okr = feedback_vertex(Draw, i, j, a, vr) && in;
+        const bool okf = feedback_vertex(Dfil, i, j, a, vf) && in;
+        const unsigned long long mr = __ballot(okr), mf = __ballot(okf);
+        if (lane == 0) {
+            wcount[0][wave] = __popcll(mr);
+            wcount[1][wave] = __popcll(mf);
+        }
+        __syncthreads();
+        int offr = base[0], offf = base[1];
+        for (int w = 0; w < wave; w++) {
+            offr += wcount[0][w];
+            offf += wcount[1][w];
+        }
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        if (okr) {  // RAW: position and colour (init_unstable.vert:36,43-45)
+            float *s = a.out + (size_t)(offr + __popcll(mr & lt)) * 12;
+            s[0] = P[0] * vr.pos.x + P[4] * vr.pos.y + P[8] * vr.pos.z + P[12];
+            s[1] = P[1] * vr.pos.x + P[5] * vr.pos.y + P[9] * vr.pos.z + P[13];
+            s[2] = P[2] * vr.pos.x + P[6] * vr.pos.y + P[10] * vr.pos.z + P[14];
+            const uint8_t *c = a.color + ((size_t)j * a.cols + i) * 3;
+            s[4] = float((int(c[0]) << 16) + (int(c[1]) << 8) + int(c[2]));
+            s[5] = 1.0f;
+            s[6] = 1.0f;
+            s[7] = float(a.time);
+        }
+        if (okf) {  // FILTERED: normal, radius, b as confidence (init_unstable.vert:38-40,47)
+            float *s = a.out + (size_t)(offf + __popcll(mf & lt)) * 12;
+            const int k = (int)roundf(a.b_img[j + (size_t)i * a.rows] * 255.0f);
+            s[3] = float(k & 0xFF) / 255.0f;
+            s[8] = P[0] * vf.normal.x + P[4] * vf.normal.y + P[8] * vf.normal.z;
+            s[9] = P[1] * vf.normal.x + P[5] * vf.normal.y + P[9] * vf.normal.z;
+            s[10] = P[2] * vf.normal.x + P[6] * vf.normal.y + P[10] * vf.normal.z;
+            s[11] = vf.radius;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tr = 0, tf = 0;
+            for (int w = 0; w < 16; w++) {
+                tr += wcount[0][w];
+                tf += wcount[1][w];
+            }
+            base[0] += tr;
+            base[1] += tf;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.count[0] = base[0];
+        a.count[1] = base[1];
+    }
+}
+
+// the draw call is sized by the RAW buffer: slots from count_raw on are not part of the model (zeroed)
+__global__ __launch_bounds__(256) void sf_init_model_trim_kernel(float *out, const int *count, int cap) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q < (size_t)cap * 12 && q >= (size_t)count[0] * 12) out[q] = 0.f;
+}

@@ -147,3 +147,69 @@ def test_hip_prediction_bit_exact_vs_oracle(hip, ora, step, b_value, seed):
     if step == 1:  # a dense model seen from nearby reproduces the scene
         err = np.abs(do - depth1)[(do > 0) & (depth1 > 0) & (depth1 < 4.4)]
         assert np.median(err) < 0.01
+
+
+# ------------------------------------------------------------------------------------------------
+#  GlobalModel::initialise: the surfel model of the first fused frame
+# ------------------------------------------------------------------------------------------------
+def load_view(s, depth, rgb, b_value):
+    prime_stream(s, depth, rgb, b_value)  # sf_load_frame + sf_filter_depth + a b image
+
+
+def test_oracle_init_model_hand_cases(ora):
+    s = make_solver(ora, ROWS, COLS, driver_params(ora))
+    mp = s.default_model_params()
+    depth = np.full((ROWS, COLS), 2.0, np.float32)  # a fronto-parallel wall at 2 m
+    depth[:, :40] = 0.0     # invalid band
+    depth[:20, :] = 25.0    # beyond max_depth = 20 (and beyond the bilateral filter's 4.5 m gate)
+    rgb = np.zeros((ROWS, COLS, 3), np.uint8)
+    rgb[..., 0], rgb[..., 1], rgb[..., 2] = 10, 20, 30
+    load_view(s, depth, rgb, b_value=0.8)
+    surf = s.init_model_from_frame(0, np.eye(4), mp, time=7)
+    mm = s.input_image(capi.IN_DEPTH_MM)
+    assert surf.shape[0] == int(((mm >= 300) & (mm <= 4500)).sum())  # DEPTH_METRIC gates the raw list (depth_metric.frag)
+    assert np.all(surf[:, 2] == np.float32(2.0)) and np.all(surf[:, 4] == np.float32((10 << 16) + (20 << 8) + 30))
+    assert np.all(surf[:, 5] == 1) and np.all(surf[:, 6] == 1) and np.all(surf[:, 7] == 7)
+    assert np.all(surf[:, 3] == np.float32(round(0.8 * 255) / 255.0))  # confidence = b through the 8-bit colour encoding
+    inner = (surf[:, 0] > -0.5) & (surf[:, 0] < 0.5) & (np.abs(surf[:, 1]) < 0.3)
+    assert np.allclose(surf[inner, 8:11], [0, 0, 1], atol=1e-6)         # geometry.glsl:36-39: cross(-x, -y) = +z for a fronto-parallel wall
+    r = 2.0 / (0.5 * (mp.fx + mp.fy)) * np.sqrt(2.0)
+    assert np.allclose(surf[inner, 11], r, rtol=1e-5)                   # surfels.glsl getRadius
+    # first surfel: point order is x outer, y inner; x = i + 0.5
+    i0, j0 = 40, 20
+    assert surf[0, 0] == pytest.approx((i0 + 0.5 - mp.cx) * 2.0 / mp.fx, rel=1e-6) and surf[0, 1] == pytest.approx((j0 + 0.5 - mp.cy) * 2.0 / mp.fy, rel=1e-6)
+    # a pose moves positions and normals
+    T = se3_exp(np.array([0.1, -0.2, 0.3, 0.0, 0.0, np.pi / 2])).astype(np.float32)
+    moved = s.init_model_from_frame(0, T, mp, time=7)
+    assert np.allclose(moved[:, :3], surf[:, :3] @ T[:3, :3].T + T[:3, 3], atol=2e-6)
+    assert np.allclose(moved[inner, 8:11], np.array([0, 0, 1]) @ T[:3, :3].T, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b_value,seed", [(0.9, 1), (0.37, 2)])
+def test_hip_init_model_bit_exact_and_closed_loop(hip, ora, b_value, seed):
+    """GlobalModel::initialise on a synthetic view: HIP == oracle bit for bit (NaN normals at degenerate pixels
+    included); the model predicted from a second pose resembles the second view."""
+    T0 = np.eye(4)
+    T1 = se3_exp(np.array(DEFAULT_XI) * 2.0)
+    depth0, rgb0 = synthetic_view(T0)
+    depth0 = depth0.copy()
+    rng = np.random.default_rng(seed)
+    depth0[rng.random(depth0.shape) < 0.01] = 0.0  # holes: raw and filtered validity differ near them
+    depth1, rgb1 = synthetic_view(T1)
+    models, preds = [], []
+    for api in (hip, ora):
+        s = make_solver(api, ROWS, COLS, driver_params(api))
+        mp = s.default_model_params()
+        load_view(s, depth0, rgb0, b_value)
+        m = s.init_model_from_frame(0, T0.astype(np.float32), mp, time=1)
+        models.append(m)
+        mp.time = mp.max_time = 2  # the next tick: surfels stamped later than max_time are not drawn (splat.vert:57)
+        s.predict_from_model(0, m, T1.astype(np.float32), mp)
+        preds.append(s.prediction())
+    assert models[0].shape == models[1].shape and models[0].tobytes() == models[1].tobytes()
+    assert np.array_equal(preds[0][0], preds[1][0]) and np.array_equal(preds[0][1], preds[1][1])
+    if b_value > 0.25:  # confidence above the high threshold: the model alone draws the prediction
+        d = preds[1][0]
+        both = (d > 0) & (depth1 > 0) & (depth1 < 4.4)
+        assert both.mean() > 0.5 and np.median(np.abs(d - depth1)[both]) < 0.01

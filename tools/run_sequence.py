@@ -15,8 +15,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 
-def run(api, io, directory, assoc_file="rgbd_assoc.txt", res_factor=2, max_frames=None, out_path=None, filter_first=False):
-    """api: an include/sf.h implementation (staticfusion_amd.load() or the test oracle); io: staticfusion_amd.io.Io()."""
+def run(api, io, directory, assoc_file="rgbd_assoc.txt", res_factor=2, max_frames=None, out_path=None, filter_first=False, mode="frame", prediction_poses=None):
+    """api: an include/sf.h implementation (staticfusion_amd.load() or the test oracle); io: staticfusion_amd.io.Io().
+    mode "frame": the prediction is the previous filtered frame. mode "keyframe": frame-to-MODEL tracking against the
+    surfel model of the first frame (GlobalModel::initialise, never fused further): every prediction is rendered from
+    it at the current pose (Reconstruction::getPredictedImages), as the reference does with its growing map.
+    prediction_poses: render the predictions at THESE poses instead of the own estimate (a visibility test flips pixels
+    for a 1e-7 change of the pose, so two implementations are compared frame by frame on identical predictions)."""
     import staticfusion_amd as sf
 
     if not directory.endswith("/"):
@@ -40,7 +45,15 @@ def run(api, io, directory, assoc_file="rgbd_assoc.txt", res_factor=2, max_frame
     s.current_to_prediction()
     s.push_history(0)
     s.set_kb(1.05)
+    model = mp = None
+    if mode == "keyframe":
+        s.filter_depth()
+        mp = s.default_model_params()
+        model = s.init_model_from_frame(0, pose, mp, time=1)  # fuseFrame of the bootstrap frame (imagesequenceassoc.cpp:135)
     for k in range(1, len(ts)):
+        if model is not None:  # getPredictedImages BEFORE the new frame is loaded (:164)
+            mp.time = mp.max_time = k + 1
+            s.predict_from_model(0, model, pose if prediction_poses is None else prediction_poses[k - 1], mp)
         color, depth = io.imread_color(files_color[k]), io.imread_depth16(files_depth[k])  # loadImageFromSequenceAssoc, :149
         s.load_frame(0, color, depth, res_factor)
         s.filter_depth()      # reconstruction->getFilteredDepth(depth_mm, depthCurrent), :165
@@ -48,7 +61,8 @@ def run(api, io, directory, assoc_file="rgbd_assoc.txt", res_factor=2, max_frame
         pose = io.pose_compose(pose, s.T())  # currPose = currPose * T_odometry, Reconstruction.cpp:265
         poses.append(pose.copy())
         lines.append(io.trajectory_line(ts[k], pose, 0))
-        s.current_to_prediction()  # frame-to-frame mode
+        if model is None:
+            s.current_to_prediction()  # frame-to-frame mode
     if out_path:
         with open(out_path, "w") as f:
             f.writelines(lines)
@@ -65,11 +79,12 @@ def main():
     ap.add_argument("--out", default="trajectory.freiburg")
     ap.add_argument("--max-frames", type=int, default=None)
     ap.add_argument("--res-factor", type=int, default=2)
+    ap.add_argument("--mode", choices=["frame", "keyframe"], default="frame")
     a = ap.parse_args()
     if not os.path.isdir(a.dataset):
         print("dataset absent: %s (no datasets ship with this repository; see SURVEY.md §8(d) config 1)" % a.dataset)
         return 2
-    poses, lines, _ = run(sf.load(), sfio.Io(), a.dataset, a.assoc, a.res_factor, a.max_frames, a.out)
+    poses, lines, _ = run(sf.load(), sfio.Io(), a.dataset, a.assoc, a.res_factor, a.max_frames, a.out, mode=a.mode)
     print("%d frames -> %s" % (len(poses), a.out))
     return 0
 

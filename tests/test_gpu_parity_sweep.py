@@ -133,3 +133,50 @@ def test_overlapped_upload_equals_direct_upload(hip, pair):
     for hst in host:
         hip.check(hip.free_pinned(hst[2]))
         hip.check(hip.free_pinned(hst[3]))
+
+
+def test_parameter_setters_and_external_hip_stream(hip, ora, pair):
+    """sf_set_params / sf_set_kb / sf_set_twist_old change the next solve exactly like a handle created with those
+    values (and like the oracle); sf_set_hip_stream runs the handle on a caller-owned hipStream_t."""
+    import ctypes as C
+
+    pr = pair(seed=21, sphere=True, rows=120, cols=160)
+    tw = np.array([0.004, -0.002, 0.003, 0.001, -0.002, 0.0015], np.float32)
+    res = {}
+    for name, api in (("hip", hip), ("ora", ora)):
+        # (a) created with the final values
+        a = make_solver(api, 120, 160, driver_params(api, kb=1.3, max_iter_irls=4, ctf_levels=4), pr)
+        a.set_twist_old(0, tw)
+        a.build_pyramid(True); a.run_solver(True)
+        # (b) created with other values, then changed through the setters
+        b = make_solver(api, 120, 160, driver_params(api, kb=1.05, max_iter_irls=6, ctf_levels=4), pr)
+        p = api.default_params_struct()
+        api.check(api.get_params(b.h, C.byref(p)))
+        p.max_iter_irls = 4
+        b.set_params(p)
+        b.set_kb(1.3)
+        b.set_twist_old(0, tw)
+        b.build_pyramid(True); b.run_solver(True)
+        assert np.array_equal(a.T(), b.T()) and a.stats().n_irls == b.stats().n_irls
+        assert np.array_equal(a.twist_old(), b.twist_old())
+        res[name] = (a.T(), a.stats().n_irls)
+    assert res["hip"][1] == res["ora"][1]
+    rot, trans = pose_delta(res["ora"][0], res["hip"][0])
+    assert rot <= 1e-4 and trans <= 1e-4
+    # without the carried twist the motion filter gives a different answer: the setter is not a no-op
+    c = make_solver(hip, 120, 160, driver_params(hip, kb=1.3, max_iter_irls=4, ctf_levels=4), pr)
+    c.build_pyramid(True); c.run_solver(True)
+    assert not np.array_equal(c.T(), res["hip"][0])
+    assert c.last_solver_kernel_ms() > 0.0
+    # caller-owned stream
+    hiprt = C.CDLL("libamdhip64.so")
+    st = C.c_void_p()
+    assert hiprt.hipStreamCreate(C.byref(st)) == 0
+    d = make_solver(hip, 120, 160, driver_params(hip, kb=1.3, max_iter_irls=4, ctf_levels=4), pr)
+    hip.check(hip.set_hip_stream(d.h, st))
+    d.build_pyramid(True); d.run_solver(True)
+    assert hiprt.hipStreamSynchronize(st) == 0
+    assert np.array_equal(d.T(), c.T())
+    hip.check(hip.set_hip_stream(d.h, None))
+    d.close()
+    assert hiprt.hipStreamDestroy(st) == 0

@@ -104,13 +104,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
+    # Test hooks (tests/test_gpu_parity_sweep.py runs the N > 1 flow on a one-GPU box): SF_BENCH_BACKEND=gloo does the
+    # barrier / reductions over gloo on CPU tensors, SF_BENCH_SINGLE_GPU=1 puts every rank on cuda:0. The driver's runs
+    # use neither: one rank per GPU, RCCL ("nccl").
+    backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("SF_BENCH_SINGLE_GPU") else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    reduce_device = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
 
     import staticfusion_amd as sf
     from staticfusion_amd.synth import make_batch, pose_delta
@@ -121,7 +130,7 @@ def main():
     sphere = args.workload == "sphere"
     pairs = make_batch(args.distinct, base_seed=1234 + 100000 * rank, sphere=sphere, distinct=args.distinct)
 
-    solver = sf.Solver(api, rows, cols, B, params, device=local_rank)
+    solver = sf.Solver(api, rows, cols, B, params, device=dev_index)
     for b in range(B):
         pr = pairs[b % len(pairs)]
         solver.set_current(b, *pr["new"])
@@ -186,7 +195,7 @@ def main():
     im += 1
     stats_last = [solver.stats(b) for b in range(min(B, args.distinct))]
 
-    t_max, iters_all, frames_all = reduce_over_ranks(dist, torch.device("cuda", local_rank), elapsed, iters_total, B * args.steps)
+    t_max, iters_all, frames_all = reduce_over_ranks(dist, reduce_device, elapsed, iters_total, B * args.steps)
 
     if rank == 0:
         levels_n = [solver.level_shape(L)[0] * solver.level_shape(L)[1] for L in range(solver.levels)]

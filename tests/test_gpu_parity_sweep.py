@@ -1,5 +1,7 @@
 """More GPU parity: a randomised parameter sweep, a 30-frame sequence through the input stage with
 carried solver state, and the bench-size batch (every duplicate stream bit-identical)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -180,3 +182,24 @@ def test_parameter_setters_and_external_hip_stream(hip, ora, pair):
     hip.check(hip.set_hip_stream(d.h, None))
     d.close()
     assert hiprt.hipStreamDestroy(st) == 0
+
+
+def test_bench_two_rank_flow_on_one_gpu(tmp_path):
+    """bench.py under torch.distributed.run with two ranks (both on cuda:0, gloo for the barrier / reductions):
+    the N > 1 control flow -- per-rank batches, barrier-bracketed timing, MAX / SUM reductions, one JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, SF_BENCH_BACKEND="gloo", SF_BENCH_SINGLE_GPU="1")
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                   "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "128", "--steps", "2",
+                                   "--warmup", "1", "--distinct", "2"], env=env, cwd=ROOT, stderr=subprocess.STDOUT, timeout=600).decode()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["frames_per_s"] * d["ms_per_step"] * 1e-3 - 2 * 128) < 1e-6 * 256  # whole-job frames per step = both ranks' batches
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only

@@ -624,8 +624,11 @@ int sf_get_lin_plane(sf_handle *h, int stream, int which, float *out, int *rows,
     if (int e = d2h(h, dn.data(), h->k.pyr_new[0] + (size_t)stream * h->k.n_tot + h->k.loff[L], sizeof(float) * n)) return e;
     if (int e = d2h(h, dw.data(), h->k.rec[R_DW] + o, sizeof(float) * n)) return e;
     auto fetch = [&](int plane, std::vector<float> &v) { v.resize(n); return d2h(h, v.data(), h->k.rec[plane] + o, sizeof(float) * n); };
-    std::vector<uint8_t> lab(n);
-    if (int e = d2h(h, lab.data(), h->k.rec_lab + o, n)) return e;
+    std::vector<uint8_t> lab(n);  // validPixels: the sign of the stored warped depth (sf_solver.h, linearise)
+    for (size_t q = 0; q < n; q++) {
+        lab[q] = (dw[q] > 0.f) ? 0 : SF_INVALID_LABEL;
+        dw[q] = std::fabs(dw[q]);
+    }
     switch (which) {
         case SF_LIN_DCU: return d2h(h, out, h->k.rec[R_DCU] + o, sizeof(float) * n);
         case SF_LIN_DCV: return d2h(h, out, h->k.rec[R_DCV] + o, sizeof(float) * n);

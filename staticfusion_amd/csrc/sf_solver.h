@@ -115,6 +115,7 @@ typedef __attribute__((address_space(1))) const unsigned short gcu16;
 typedef __attribute__((address_space(1))) const unsigned int gcu32;
 
 struct RecPtrs {
+    int with_labels;
     gcfloat *p[R_COUNT];
     gcfloat *dnew;  // NEW depth of the level (pyramid plane)
     gcu8 *lab;
@@ -167,7 +168,12 @@ struct RecVec {
 };
 template <int VEC>
 __device__ __forceinline__ void load_rec(const RecPtrs &rp, int idx0, RecVec<VEC> &r) {
-    load_labels<VEC>(rp.lab, idx0, r.lab);
+    if (rp.with_labels) {  // uniform: without segmentation every valid pixel belongs to cluster 0 and the plane is not read
+        load_labels<VEC>(rp.lab, idx0, r.lab);
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) r.lab[j] = 0;
+    }
     load_plane<VEC>(rp.dnew, idx0, r.dn);
 #pragma unroll
     for (int q = 0; q < R_COUNT; q++) load_plane<VEC>(rp.p[q], idx0, r.v[q]);
@@ -400,13 +406,13 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                     abs_d += (double)(vrsq(0.01f + error_l_d) * fabsf(ddt_));
                     n_valid++;
                 }
-                rec[R_DW][idx] = dw;
+                rec[R_DW][idx] = valid ? dw : -dw;  // the SIGN carries validPixels (valid => dw > 0): the passes need no label plane for it
                 rec[R_DCU][idx] = dcu_;
                 rec[R_DCV][idx] = dcv_;
                 rec[R_DCT][idx] = dct_;
                 rec[R_DDU][idx] = ddu_;
                 rec[R_DDV][idx] = ddv_;
-                rec_lab[idx] = valid ? (uint8_t)(seg ? lab : 0) : (uint8_t)SF_INVALID_LABEL;
+                if (seg || dbg) rec_lab[idx] = valid ? (uint8_t)(seg ? lab : 0) : (uint8_t)SF_INVALID_LABEL;
                 if (dbg) {
                     float d_i = 0.f, x_i = 0.f, y_i = 0.f, xw = 0.f, yw = 0.f;
                     const LevelCoord lcd = level_coord(a, L);
@@ -642,7 +648,7 @@ __device__ __forceinline__ void fact_residuals(const PixFact<T> &p, const float 
 // so the streaming loops are branch-free: no exec-mask juggling around the 27 accumulators.
 template <int VEC>
 __device__ __forceinline__ bool sanitize(RecVec<VEC> &r, int j) {
-    const bool ok = r.lab[j] != SF_INVALID_LABEL;
+    const bool ok = r.v[R_DW][j] > 0.f;  // the linearisation stores -dw (or -0) outside validPixels
     r.dn[j] = ok ? r.dn[j] : 1.f;
     r.v[R_DW][j] = ok ? r.v[R_DW][j] : 1.f;
 #pragma unroll
@@ -670,6 +676,7 @@ __device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, c
     for (int q = 0; q < R_COUNT; q++) c.rp.p[q] = uniform_ptr((gcfloat *)(a.rec[q] + rb));
     c.rp.dnew = uniform_ptr((gcfloat *)(a.pyr_new[0] + (size_t)b * a.n_tot + a.loff[L]));
     c.rp.lab = uniform_ptr((gcu8 *)(a.rec_lab + rb));
+    c.rp.with_labels = uniform_i(a.p.segmentation_enabled);
     c.n = uniform_i(s.px_end);
     c.begin = uniform_i(s.px_begin);
     c.N = uniform_i(s.n_valid);

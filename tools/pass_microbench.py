@@ -26,8 +26,9 @@ for which in (1, 2):
         s.microbench_pass(which, variant | (a.slices << 8), 2)
         ms = s.microbench_pass(which, variant | (a.slices << 8), a.reps)
         px = a.batch * a.reps * npx
-        print("pass %d %-16s %8.3f ms  %6.2f Gpx/s  streamed(29 B/px) %7.1f GB/s  algorithmic(30 B/px/pass) %7.1f GB/s" % (
-            which, name, ms, px / ms / 1e6, 29.0 * px / ms / 1e6, 30.0 * px / ms / 1e6))
+        bpp = 29.0 if p.segmentation_enabled else 28.0  # 7 float planes (+ 1 label byte with segmentation)
+        print("pass %d %-16s %8.3f ms  %6.2f Gpx/s  streamed(%d B/px) %7.1f GB/s  algorithmic(30 B/px/pass) %7.1f GB/s" % (
+            which, name, ms, px / ms / 1e6, bpp, bpp * px / ms / 1e6, 30.0 * px / ms / 1e6))
 import ctypes as C
 t = (C.c_int64 * 24)()
 api.check(api.get_stage_profile(s.h, t))

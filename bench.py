@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4096, help="independent streams per GPU (8 MB of HBM each)")
+    ap.add_argument("--batch", type=int, default=16384, help="independent streams per GPU (8.3 MB of HBM each: 136 GB); 16 rounds of the 1024 resident workgroups")
     ap.add_argument("--workload", choices=["static", "sphere"], default="static")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pairs (tiled over the batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

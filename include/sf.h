@@ -261,6 +261,45 @@ int SF_FN(init_model_from_frame)(sf_handle *h, int stream, const float pose[16],
 /* depthPrediction / intensityPrediction (column-major float, rows*cols each; either may be NULL). */
 int SF_FN(get_prediction)(sf_handle *h, int stream, float *depth, float *intensity);
 
+/* ---- the surfel map: GlobalModel + the fusion half of Reconstruction::fuseFrame ---- */
+
+/* One map = one GlobalModel (GlobalModel.cpp) plus Reconstruction's currPose / tick bookkeeping, resident in HBM.
+ * A map belongs to the handle it was created from (its device, its HIP stream, its resolution); any stream of the
+ * handle can be fused into it. capacity = most surfels it can hold (0 -> the reference's MAX_VERTICES = 3072 x 3072,
+ * GlobalModel.cpp:21-22; 2 x 48 B per surfel of HBM); like the reference's transform feedback, a fuse that would
+ * exceed it truncates the map and returns SF_ERR_STATE. */
+typedef struct sf_map sf_map;
+int SF_FN(map_create)(sf_handle *h, int capacity, sf_map **out);
+void SF_FN(map_destroy)(sf_map *m);
+/* Reconstruction::fuseFrame (Reconstruction.cpp:235-325) for the frame stream `stream` holds (sf_load_frame +
+ * sf_filter_depth are the uploads and filterDepth / metriciseDepth of :242-249; the b image of the stream's last solve
+ * is the weightedImage). in_pose = T_odometry of the solve, 4x4 column-major (may be NULL on the first call only).
+ *   first call (tick == 1): currPose *= in_pose; GlobalModel::initialise (= sf_init_model_from_frame)  :255-262
+ *   later calls: lastPose = currPose; currPose *= in_pose; velocity weighting (sf_fusion_weighting in sf_detmath.h)  :264-282
+ *     IndexMap::predictIndices (IndexMap.cpp:117-184; index_map.vert/.frag): 4x-oversampled index image of the model  :284
+ *     GlobalModel::fuse (GlobalModel.cpp:322-492): data association of every (x,y)%2 == tick%2 pixel within a window of
+ *       the index image (data.vert) -> merge into the associated surfel (update.vert: confidence-weighted mean of
+ *       position / colour / normal / radius, log-odds confidence update) or a new unstable surfel (confidence 0.08
+ *       where b > 0.5, else 0)                                                                          :286-298
+ *     IndexMap::predictIndices on the merged model                                                     :300
+ *     GlobalModel::clean (GlobalModel.cpp:494-601; copy_unstable.vert/.geom): drops merged duplicates, free-space
+ *       violations and stale unstable surfels, appends the surviving new ones                          :302-311
+ *   tick++                                                                                             :323
+ * p: intrinsics, max_depth (maxDepthProcessed), conf_high (confidenceThreshold), time_delta; p->time / max_time are
+ * ignored (the map's tick is used). */
+int SF_FN(map_fuse_frame)(sf_handle *h, int stream, sf_map *m, const float *in_pose, float weight_multiplier, const sf_model_params *p);
+/* Reconstruction::getPredictedImages at the map's currPose and tick: sf_predict_from_model_device on the map's buffer. */
+int SF_FN(map_predict)(sf_handle *h, int stream, sf_map *m, const sf_model_params *p);
+/* lastCount(), tick, currPose and the counters of the last fuse: stats[0] points emitted by the data pass, [1] of those
+ * associated with a model surfel, [2] distinct surfels merged, [3] surfels after clean. Any pointer may be NULL. */
+int SF_FN(map_info)(sf_map *m, int *count, int *tick, float pose[16], int stats[4]);
+/* GlobalModel::downloadMap (GlobalModel.cpp:608-636): the first min(count, max_count) surfels, 12 floats each. */
+int SF_FN(map_download)(sf_map *m, float *surfels, int max_count);
+/* Replace the map's state (tests, checkpoints, teacher forcing): count x 12 floats, currPose, tick. */
+int SF_FN(map_upload)(sf_map *m, const float *surfels, int count, const float pose[16], int tick);
+/* The index texture of the last predictIndices (4 rows x 4 cols uint32, row-major; 0 = empty). Debug / tests. */
+int SF_FN(map_get_index_map)(sf_map *m, uint32_t *out);
+
 /* ---- the four methods the drivers call (all streams of the batch) ------------------------- */
 
 /* StaticFusion::createImagePyramid(bool old_im)  FrontEnd.cpp:256-391 */

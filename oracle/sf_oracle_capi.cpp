@@ -15,6 +15,7 @@
 #include "sf_oracle.hpp"
 #include "sf_oracle_input.hpp"
 #include "sf_oracle_predict.hpp"
+#include "sf_oracle_fusion.hpp"
 #include "../include/sf_detmath.h"
 
 struct sf_handle {
@@ -417,6 +418,15 @@ int sfo_batch(const sf_handle *h) { return h ? h->batch : 0; }
 void sfo_test_exp_neg(const float *a, int n, float *out) {
     for (int i = 0; i < n; i++) out[i] = sf_exp_neg(a[i]);
 }
+void sfo_test_exp_det(const float *a, int n, float *out) {
+    for (int i = 0; i < n; i++) out[i] = sf_exp_det(a[i]);
+}
+void sfo_test_log_det(const float *a, int n, float *out) {
+    for (int i = 0; i < n; i++) out[i] = sf_log_det(a[i]);
+}
+float sfo_test_fusion_weighting(const float *last_pose, const float *curr_pose, float multiplier) {
+    return sf_fusion_weighting(last_pose, curr_pose, multiplier);
+}
 
 // ---- input stage (sf_oracle_input.cpp) ----------------------------------------------------
 static int input_alloc(sf_handle *h) {
@@ -556,6 +566,69 @@ int sfo_get_prediction(sf_handle *h, int stream, float *depth, float *intensity)
     const size_t bytes = sizeof(float) * size_t(h->rows) * h->cols;
     if (depth) std::memcpy(depth, s.depthPrediction.d.data(), bytes);
     if (intensity) std::memcpy(intensity, s.intensityPrediction.d.data(), bytes);
+    return SF_OK;
+}
+
+// ---- the surfel map (sf_oracle_fusion.cpp) ----------------------------------------------------
+struct sf_map {
+    sf_handle *h;
+    sfo::SurfelMap m;
+};
+static sfo::ModelParams model_params(const sf_model_params *p, int time) {
+    return sfo::ModelParams{p->cx, p->cy, p->fx, p->fy, p->max_depth, p->conf_low, p->conf_high, time, time, p->time_delta, p->extract_max_depth};
+}
+int sfo_map_create(sf_handle *h, int capacity, sf_map **out) {
+    if (!h || !out || capacity < 0) return fail(SF_ERR_ARG, "bad argument");
+    if (capacity && capacity < h->rows * h->cols) return fail(SF_ERR_ARG, "capacity below rows * cols (the first frame alone can need that many surfels)");
+    sf_map *m = new sf_map{h, {}};
+    m->m.capacity = capacity ? capacity : 3072 * 3072;  // GlobalModel.cpp:21-22
+    *out = m;
+    return SF_OK;
+}
+void sfo_map_destroy(sf_map *m) { delete m; }
+int sfo_map_fuse_frame(sf_handle *h, int stream, sf_map *m, const float *in_pose, float weight_multiplier, const sf_model_params *p) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!m || m->h != h || !p) return fail(SF_ERR_ARG, "bad argument");
+    if (!h->have_frame) return fail(SF_ERR_STATE, "sf_map_fuse_frame needs a loaded frame (sf_load_frame + sf_filter_depth)");
+    if (!in_pose && m->m.tick != 1) return fail(SF_ERR_ARG, "in_pose may be NULL on the first fuse only");
+    auto &s = *h->s[stream];
+    const sfo::FrameImages f{h->depth_metric[stream].data(), s.depthCurrent.d.data(), h->color[stream].data(), s.b_segm_perpixel.d.data(), h->rows, h->cols};
+    if (sfo::fuse_frame(m->m, f, in_pose, weight_multiplier, model_params(p, m->m.tick))) return fail(SF_ERR_STATE, "surfel map capacity exceeded (truncated)");
+    return SF_OK;
+}
+int sfo_map_predict(sf_handle *h, int stream, sf_map *m, const sf_model_params *p) {
+    if (!m || m->h != h || !p) return fail(SF_ERR_ARG, "bad argument");
+    sf_model_params q = *p;
+    q.time = q.max_time = m->m.tick;
+    return sfo_predict_from_model(h, stream, m->m.surfels.data(), m->m.count, m->m.pose, &q);
+}
+int sfo_map_info(sf_map *m, int *count, int *tick, float pose[16], int stats[4]) {
+    if (!m) return fail(SF_ERR_ARG, "null");
+    if (count) *count = m->m.count;
+    if (tick) *tick = m->m.tick;
+    if (pose) std::memcpy(pose, m->m.pose, sizeof m->m.pose);
+    if (stats) std::memcpy(stats, m->m.stats, sizeof m->m.stats);
+    return SF_OK;
+}
+int sfo_map_download(sf_map *m, float *surfels, int max_count) {
+    if (!m || (!surfels && max_count > 0) || max_count < 0) return fail(SF_ERR_ARG, "bad argument");
+    std::memcpy(surfels, m->m.surfels.data(), size_t(std::min(max_count, m->m.count)) * 12 * sizeof(float));
+    return SF_OK;
+}
+int sfo_map_upload(sf_map *m, const float *surfels, int count, const float pose[16], int tick) {
+    if (!m || (!surfels && count > 0) || count < 0 || !pose || tick < 1) return fail(SF_ERR_ARG, "bad argument");
+    if (count > m->m.capacity) return fail(SF_ERR_ARG, "count exceeds the map's capacity");
+    m->m.surfels.assign(surfels, surfels + size_t(count) * 12);
+    m->m.count = count;
+    std::memcpy(m->m.pose, pose, sizeof m->m.pose);
+    m->m.tick = tick;
+    return SF_OK;
+}
+int sfo_map_get_index_map(sf_map *m, uint32_t *out) {
+    if (!m || !out) return fail(SF_ERR_ARG, "null");
+    const size_t n = size_t(m->h->rows) * 4 * m->h->cols * 4;
+    if (m->m.index_map.size() != n) return fail(SF_ERR_STATE, "no index map yet (sf_map_fuse_frame with tick > 1 renders it)");
+    std::memcpy(out, m->m.index_map.data(), n * sizeof(uint32_t));
     return SF_OK;
 }
 

@@ -118,6 +118,14 @@ SIGNATURES = {
     "predict_from_model_device": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int, _fp, C.POINTER(SfModelParams)]),
     "init_model_from_frame": (C.c_int, [_H, C.c_int, _fp, C.POINTER(SfModelParams), C.c_int, _fp, _ip]),
     "get_prediction": (C.c_int, [_H, C.c_int, _fp, _fp]),
+    "map_create": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p)]),
+    "map_destroy": (None, [C.c_void_p]),
+    "map_fuse_frame": (C.c_int, [_H, C.c_int, C.c_void_p, _fp, C.c_float, C.POINTER(SfModelParams)]),
+    "map_predict": (C.c_int, [_H, C.c_int, C.c_void_p, C.POINTER(SfModelParams)]),
+    "map_info": (C.c_int, [C.c_void_p, _ip, _ip, _fp, _ip]),
+    "map_download": (C.c_int, [C.c_void_p, _fp, C.c_int]),
+    "map_upload": (C.c_int, [C.c_void_p, _fp, C.c_int, _fp, C.c_int]),
+    "map_get_index_map": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "build_pyramid": (C.c_int, [_H, C.c_int]),
     "kmeans": (C.c_int, [_H]),
     "run_solver": (C.c_int, [_H, C.c_int]),
@@ -438,3 +446,58 @@ class Solver:
         ms = C.c_float()
         self.api.check(self.api.last_solver_kernel_ms(self.h, C.byref(ms)))
         return ms.value
+
+
+class SurfelMap:
+    """numpy wrapper over one sf_map (GlobalModel + currPose / tick of Reconstruction), SURVEY.md §8(f) rank 4"""
+
+    def __init__(self, solver, capacity=0):
+        self.solver, self.api = solver, solver.api
+        self.m = C.c_void_p()
+        self.api.check(self.api.map_create(solver.h, capacity, C.byref(self.m)))
+
+    def close(self):
+        if self.m:
+            self.api.map_destroy(self.m)
+            self.m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def fuse_frame(self, stream, in_pose, weight_multiplier=1.0, params=None):
+        """Reconstruction::fuseFrame for the frame `stream` holds; in_pose: 4x4 (row, col) T_odometry or None (first call)"""
+        p = params if params is not None else self.solver.default_model_params()
+        T = None if in_pose is None else np.ascontiguousarray(np.asarray(in_pose, np.float32).T)
+        self.api.check(self.api.map_fuse_frame(self.solver.h, stream, self.m, None if T is None else T.ctypes.data_as(_fp),
+                                               weight_multiplier, C.byref(p)))
+
+    def predict(self, stream, params=None):
+        p = params if params is not None else self.solver.default_model_params()
+        self.api.check(self.api.map_predict(self.solver.h, stream, self.m, C.byref(p)))
+
+    def info(self):
+        """dict(count, tick, pose (4x4 row, col), stats)"""
+        n, t = C.c_int32(), C.c_int32()
+        pose = np.zeros(16, np.float32)
+        stats = (C.c_int32 * 4)()
+        self.api.check(self.api.map_info(self.m, C.byref(n), C.byref(t), pose.ctypes.data_as(_fp), stats))
+        return dict(count=n.value, tick=t.value, pose=pose.reshape(4, 4).T.copy(), stats=[int(x) for x in stats])
+
+    def download(self):
+        n = self.info()["count"]
+        out = np.zeros((max(n, 1), 12), np.float32)
+        self.api.check(self.api.map_download(self.m, out.ctypes.data_as(_fp), n))
+        return out[:n].copy()
+
+    def upload(self, surfels, pose, tick):
+        s = np.ascontiguousarray(surfels, dtype=np.float32).reshape(-1, 12)
+        T = np.ascontiguousarray(np.asarray(pose, np.float32).T)
+        self.api.check(self.api.map_upload(self.m, s.ctypes.data_as(_fp), s.shape[0], T.ctypes.data_as(_fp), tick))
+
+    def index_map(self):
+        out = np.zeros((self.solver.rows * 4, self.solver.cols * 4), np.uint32)
+        self.api.check(self.api.map_get_index_map(self.m, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out

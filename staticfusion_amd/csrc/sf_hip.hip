@@ -19,6 +19,7 @@
 #include "sf_device_common.h"
 #include "sf_input.h"
 #include "sf_predict.h"
+#include "sf_fusion.h"
 
 // the two builds of the frame kernels (sf_frame_kernels.hip, -DSF_NT=256 / -DSF_NT=1024)
 struct FrameVariant {
@@ -918,6 +919,201 @@ int sf_get_prediction(sf_handle *h, int stream, float *depth, float *intensity) 
     if (intensity)
         if (int e = d2h(h, intensity, h->k.pyr_pred[1] + (size_t)stream * h->k.n_tot, bytes)) return e;
     return SF_OK;
+}
+
+// ---- the surfel map (sf_fusion.h) ------------------------------------------------------------------
+struct sf_map {
+    sf_handle *h = nullptr;
+    int capacity = 0;
+    float *buf[2] = {nullptr, nullptr};  // the model lives in buf[0] between calls; buf[1] holds the merged model inside a fuse
+    int count = 0, tick = 1;
+    float pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    int stats[4] = {0, 0, 0, 0};
+    unsigned long long *keys = nullptr;
+    unsigned *winner = nullptr, *meta = nullptr, *index_export = nullptr;
+    float *rec = nullptr;
+    unsigned char *flags = nullptr;
+    int *block_counts = nullptr, *result = nullptr;
+    bool have_index = false;
+    std::vector<void *> allocs;
+};
+static int map_alloc_bytes(sf_map *m, void **p, size_t bytes) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes ? bytes : 1);
+    if (e != hipSuccess) return fail(SF_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    m->allocs.push_back(q);
+    *p = q;
+    return SF_OK;
+}
+#define map_alloc(m, p, count) map_alloc_bytes(m, (void **)(p), (size_t)(count) * sizeof(**(p)))
+int sf_map_create(sf_handle *h, int capacity, sf_map **out) {
+    if (!h || !out || capacity < 0) return fail(SF_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n0 = h->k.n0;
+    const size_t cap = capacity ? (size_t)capacity : (size_t)3072 * 3072;  // GlobalModel.cpp:21-22
+    if (cap < n0) return fail(SF_ERR_ARG, "capacity below rows * cols (the first frame alone can need that many surfels)");
+    sf_map *m = new sf_map;
+    m->h = h;
+    m->capacity = (int)cap;
+    const size_t n_cand_max = (size_t)((h->k.rows + 1) / 2) * ((h->k.cols + 1) / 2);
+    int e = SF_OK;
+    if (!e) e = map_alloc(m, &m->buf[0], cap * 12);
+    if (!e) e = map_alloc(m, &m->buf[1], cap * 12);
+    if (!e) e = map_alloc(m, &m->keys, n0 * 16);
+    if (!e) e = map_alloc(m, &m->index_export, n0 * 16);
+    if (!e) e = map_alloc(m, &m->winner, cap);
+    if (!e) e = map_alloc(m, &m->rec, n_cand_max * 12);
+    if (!e) e = map_alloc(m, &m->meta, n_cand_max * 2);
+    if (!e) e = map_alloc(m, &m->flags, cap + n_cand_max);
+    if (!e) e = map_alloc(m, &m->block_counts, (cap + n_cand_max + 1023) / 1024 + 1);
+    if (!e) e = map_alloc(m, &m->result, 8);
+    if (e) {
+        sf_map_destroy(m);
+        return e;
+    }
+    *out = m;
+    return SF_OK;
+}
+void sf_map_destroy(sf_map *m) {
+    if (!m) return;
+    for (void *q : m->allocs) (void)hipFree(q);
+    delete m;
+}
+static void pose_compose(const float *a, const float *b, float *out) {  // Eigen::Matrix4f product, column-major
+    float r[16];
+    for (int c = 0; c < 4; c++)
+        for (int rr = 0; rr < 4; rr++) {
+            float acc = a[rr] * b[4 * c];
+            for (int k = 1; k < 4; k++) acc = acc + a[rr + 4 * k] * b[k + 4 * c];
+            r[rr + 4 * c] = acc;
+        }
+    std::memcpy(out, r, sizeof r);
+}
+int sf_map_fuse_frame(sf_handle *h, int stream, sf_map *m, const float *in_pose, float weight_multiplier, const sf_model_params *p) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!m || m->h != h || !p) return fail(SF_ERR_ARG, "bad argument");
+    if (!h->have_frame) return fail(SF_ERR_STATE, "sf_map_fuse_frame needs a loaded frame (sf_load_frame + sf_filter_depth)");
+    if (!in_pose && m->tick != 1) return fail(SF_ERR_ARG, "in_pose may be NULL on the first fuse only");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = h->k.n0;
+    const float *depth_metric = h->in_depth_metric + (size_t)stream * n;
+    const float *depth_filtered = h->k.pyr_new[0] + (size_t)stream * h->k.n_tot;
+    const uint8_t *color = h->in_color + (size_t)stream * n * 3;
+    const float *b_img = h->k.b_img + (size_t)stream * n;
+    if (m->tick == 1) {  // Reconstruction.cpp:255-262
+        if (in_pose) pose_compose(m->pose, in_pose, m->pose);
+        HIP_TRY(hipMemsetAsync(m->buf[0], 0, n * 12 * sizeof(float), h->stream));
+        InitModelArgs a;
+        a.depth_metric = depth_metric; a.depth_filtered = depth_filtered; a.color = color; a.b_img = b_img;
+        a.rows = h->k.rows; a.cols = h->k.cols; a.time = m->tick;
+        for (int q = 0; q < 16; q++) a.pose[q] = m->pose[q];
+        a.cx = p->cx; a.cy = p->cy; a.fx = p->fx; a.fy = p->fy; a.max_depth = p->max_depth;
+        a.out = m->buf[0];
+        a.count = m->result;
+        hipLaunchKernelGGL(sf_init_model_kernel, dim3(1), dim3(1024), 0, h->stream, a);
+        hipLaunchKernelGGL(sf_init_model_trim_kernel, dim3((unsigned)((n * 12 + 255) / 256)), dim3(256), 0, h->stream, m->buf[0],
+                           (const int *)m->result, (int)n);
+        HIP_TRY(hipGetLastError());
+        int counts[2] = {0, 0};
+        if (int e = d2h(h, counts, m->result, sizeof counts)) return e;
+        m->count = counts[0];
+        m->stats[0] = m->stats[1] = m->stats[2] = 0;
+        m->stats[3] = m->count;
+        m->tick++;
+        return SF_OK;
+    }
+    float last_pose[16];
+    std::memcpy(last_pose, m->pose, sizeof last_pose);
+    pose_compose(m->pose, in_pose, m->pose);                                        // :268
+    FuseArgs a;
+    a.depth_metric = depth_metric; a.depth_filtered = depth_filtered; a.color = color; a.b_img = b_img;
+    a.rows = h->k.rows; a.cols = h->k.cols;
+    for (int q = 0; q < 16; q++) a.pose[q] = m->pose[q];
+    invert_pose(m->pose, a.t_inv);
+    a.cx = p->cx; a.cy = p->cy; a.fx = p->fx; a.fy = p->fy;
+    a.camz = float(1.0 / double(p->fx)); a.camw = float(1.0 / double(p->fy));       // GlobalModel.cpp:365-368
+    a.max_depth = p->max_depth; a.conf_threshold = p->conf_high;
+    a.weighting = sf_fusion_weighting(last_pose, m->pose, weight_multiplier);        // :270-282
+    a.time = m->tick; a.time_delta = p->time_delta;
+    a.src = m->buf[0]; a.dst = m->buf[1];
+    a.count = m->count; a.capacity = m->capacity;
+    a.keys = m->keys; a.winner = m->winner;
+    a.par = m->tick % 2;
+    a.cand_rows = (a.rows - a.par + 1) / 2; a.cand_cols = (a.cols - a.par + 1) / 2;
+    a.n_cand = a.cand_rows * a.cand_cols;
+    a.rec = m->rec; a.meta = m->meta; a.flags = m->flags; a.block_counts = m->block_counts; a.result = m->result;
+    const size_t n_keys = n * 16;
+    const unsigned key_blocks = (unsigned)((n_keys + 255) / 256);
+    const unsigned surfel_blocks = (unsigned)((a.count + 255) / 256);
+    const int n_elems = a.count + a.n_cand;
+    const int n_blocks = (n_elems + 1023) / 1024;
+    HIP_TRY(hipMemsetAsync(m->result, 0, 8 * sizeof(int), h->stream));
+    if (a.count) HIP_TRY(hipMemsetAsync(m->winner, 0xff, (size_t)a.count * sizeof(unsigned), h->stream));
+    hipLaunchKernelGGL(sf_index_clear_kernel, dim3(key_blocks), dim3(256), 0, h->stream, m->keys, n_keys);         // :284
+    if (a.count) hipLaunchKernelGGL(sf_index_splat_kernel, dim3(surfel_blocks), dim3(256), 0, h->stream, a, a.src);
+    if (a.n_cand) hipLaunchKernelGGL(sf_fuse_data_kernel, dim3((a.n_cand + 255) / 256), dim3(256), 0, h->stream, a);  // :286-298
+    if (a.count) hipLaunchKernelGGL(sf_fuse_update_kernel, dim3(surfel_blocks), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(sf_index_clear_kernel, dim3(key_blocks), dim3(256), 0, h->stream, m->keys, n_keys);         // :300
+    if (a.count) hipLaunchKernelGGL(sf_index_splat_kernel, dim3(surfel_blocks), dim3(256), 0, h->stream, a, (const float *)a.dst);
+    if (n_blocks) {                                                                                                  // :302-311
+        hipLaunchKernelGGL(sf_clean_flag_kernel, dim3(n_blocks), dim3(1024), 0, h->stream, a);
+        hipLaunchKernelGGL(sf_clean_scan_kernel, dim3(1), dim3(1024), 0, h->stream, a, n_blocks);
+        hipLaunchKernelGGL(sf_clean_write_kernel, dim3(n_blocks), dim3(1024), 0, h->stream, a, m->buf[0]);
+    }
+    HIP_TRY(hipGetLastError());
+    int res[8];
+    if (int e = d2h(h, res, m->result, sizeof res)) return e;
+    m->count = res[0];
+    m->stats[0] = res[2]; m->stats[1] = res[3]; m->stats[2] = res[4]; m->stats[3] = res[0];
+    m->have_index = true;
+    m->tick++;
+    if (res[1] > m->capacity) return fail(SF_ERR_STATE, "surfel map capacity exceeded (truncated)");
+    return SF_OK;
+}
+int sf_map_predict(sf_handle *h, int stream, sf_map *m, const sf_model_params *p) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!m || m->h != h || !p) return fail(SF_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (int e = input_alloc(h)) return e;
+    sf_model_params q = *p;
+    q.time = q.max_time = m->tick;
+    return predict_launch(h, stream, m->buf[0], m->count, m->pose, &q);
+}
+int sf_map_info(sf_map *m, int *count, int *tick, float pose[16], int stats[4]) {
+    if (!m) return fail(SF_ERR_ARG, "null");
+    if (count) *count = m->count;
+    if (tick) *tick = m->tick;
+    if (pose) std::memcpy(pose, m->pose, sizeof m->pose);
+    if (stats) std::memcpy(stats, m->stats, sizeof m->stats);
+    return SF_OK;
+}
+int sf_map_download(sf_map *m, float *surfels, int max_count) {
+    if (!m || (!surfels && max_count > 0) || max_count < 0) return fail(SF_ERR_ARG, "bad argument");
+    const size_t k = (size_t)std::min(max_count, m->count);
+    if (k) return d2h(m->h, surfels, m->buf[0], k * 12 * sizeof(float));
+    return SF_OK;
+}
+int sf_map_upload(sf_map *m, const float *surfels, int count, const float pose[16], int tick) {
+    if (!m || (!surfels && count > 0) || count < 0 || !pose || tick < 1) return fail(SF_ERR_ARG, "bad argument");
+    if (count > m->capacity) return fail(SF_ERR_ARG, "count exceeds the map's capacity");
+    HIP_TRY(hipSetDevice(m->h->device));
+    if (count) {
+        HIP_TRY(hipMemcpyAsync(m->buf[0], surfels, (size_t)count * 12 * sizeof(float), hipMemcpyHostToDevice, m->h->stream));
+        HIP_TRY(hipStreamSynchronize(m->h->stream));
+    }
+    m->count = count;
+    std::memcpy(m->pose, pose, sizeof m->pose);
+    m->tick = tick;
+    return SF_OK;
+}
+int sf_map_get_index_map(sf_map *m, uint32_t *out) {
+    if (!m || !out) return fail(SF_ERR_ARG, "null");
+    if (!m->have_index) return fail(SF_ERR_STATE, "no index map yet (sf_map_fuse_frame with tick > 1 renders it)");
+    HIP_TRY(hipSetDevice(m->h->device));
+    const size_t n = m->h->k.n0 * 16;
+    hipLaunchKernelGGL(sf_index_export_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->h->stream, m->keys, m->index_export, n);
+    HIP_TRY(hipGetLastError());
+    return d2h(m->h, out, m->index_export, n * sizeof(uint32_t));
 }
 
 int sf_level_rows(const sf_handle *h, int level) { return (h && level >= 0 && level < h->k.levels) ? h->k.lrows[level] : 0; }

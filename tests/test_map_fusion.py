@@ -1,0 +1,313 @@
+"""The surfel map: the fusion half of Reconstruction::fuseFrame (reference
+Reconstruction.cpp:264-311) = IndexMap::predictIndices (IndexMap.cpp:117-184, index_map.vert/.frag) +
+GlobalModel::fuse (GlobalModel.cpp:322-492; data.vert, update.vert) + GlobalModel::clean (:494-601; copy_unstable.vert).
+CPU part: the oracle restatement on hand cases and invariants. GPU part: the HIP kernels against the oracle, bit exact."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from conftest import driver_params, make_solver
+from staticfusion_amd import SurfelMap, SfError, capi
+from staticfusion_amd.synth import se3_exp
+from test_model_prediction import synthetic_view
+
+ROWS, COLS = 240, 320
+XI = np.array([0.010, 0.004, 0.006, 0.002, -0.004, 0.003])  # per-frame camera motion of the synthetic walk
+_fp = C.POINTER(C.c_float)
+
+
+def load_view(s, depth, rgb, b_of_cluster):
+    """what the frame loop leaves in the stream before fuseFrame: the loaded + filtered frame and the b image of the solve"""
+    full_d = np.repeat(np.repeat(np.clip(np.rint(depth[::-1] * 1000), 0, 65535).astype(np.uint16), 2, 0), 2, 1)
+    full_c = np.repeat(np.repeat(rgb[::-1], 2, 0), 2, 1)
+    s.load_frame(0, full_c, full_d, 2)
+    s.filter_depth()
+    yy, xx = np.mgrid[0:ROWS, 0:COLS]
+    labels = ((xx // 40) + 8 * (yy // 40)) % 24
+    s.set_segm_state(0, labels.astype(np.int32), np.asarray(b_of_cluster, np.float32), np.ones(24, np.float32))
+    s.build_segm_image()
+
+
+def walk(api, n_frames, sphere=False, b=None, capacity=0, xi=XI, keep=True):
+    b = np.full(24, 0.9, np.float32) if b is None else b
+    s = make_solver(api, ROWS, COLS, driver_params(api))
+    m = SurfelMap(s, capacity)
+    T = np.eye(4)
+    out = []
+    for k in range(n_frames):
+        depth, rgb = synthetic_view(T, sphere=sphere)
+        load_view(s, depth, rgb, b)
+        err = None
+        try:
+            m.fuse_frame(0, None if k == 0 else se3_exp(xi))
+        except SfError as e:
+            err = str(e)
+        if keep:
+            m.predict(0)
+            out.append(dict(info=m.info(), surfels=m.download(), index=m.index_map() if k else None, pred=s.prediction(), err=err))
+        T = T @ se3_exp(xi)
+    return s, m, out
+
+
+def same_bits(a, b):
+    """bit equality of float arrays, any NaN equal to any NaN (payloads differ between libm and the GPU)"""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return a.shape == b.shape and bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+# ------------------------------------------------------------------------------------------------
+#  CPU: the oracle
+# ------------------------------------------------------------------------------------------------
+def test_deterministic_exp_log_and_velocity_weighting(ora):
+    for name, lo, hi, ref in (("sfo_test_exp_det", -12.0, 12.0, math.exp), ("sfo_test_log_det", 1e-3, 1e3, math.log)):
+        x = np.ascontiguousarray(np.random.default_rng(1).uniform(lo, hi, 20000), np.float32)
+        if name.endswith("log_det"):
+            x = np.concatenate([x, np.float32(1) + np.float32(2.0) ** -np.arange(1, 24, dtype=np.float32), [np.float32(1)]]).astype(np.float32)
+        out = np.zeros_like(x)
+        fn = getattr(ora.lib, name)
+        fn.restype, fn.argtypes = None, [_fp, C.c_int, _fp]
+        fn(x.ctypes.data_as(_fp), x.size, out.ctypes.data_as(_fp))
+        exact = np.array([ref(float(v)) for v in x])
+        ulp = np.spacing(np.abs(exact).astype(np.float32)).astype(np.float64)
+        assert (np.abs(out - exact) / np.maximum(ulp, 1e-45)).max() < 2.5, name
+    fn = ora.lib.sfo_test_log_det
+    edge = np.array([0.0, -1.0, np.inf, np.nan], np.float32)
+    out = np.zeros_like(edge)
+    fn(edge.ctypes.data_as(_fp), 4, out.ctypes.data_as(_fp))
+    assert out[0] == -np.inf and np.isnan(out[1]) and out[2] == np.inf and np.isnan(out[3])
+    # Reconstruction.cpp:270-282: max(|t|, |rotation vector|) of currPose^-1 lastPose, clamped at 0.15, floor 0.5
+    w = ora.lib.sfo_test_fusion_weighting
+    w.restype, w.argtypes = C.c_float, [_fp, _fp, C.c_float]
+    colmajor = lambda T: np.ascontiguousarray(np.asarray(T, np.float32).T).ravel()
+    eye = colmajor(np.eye(4))
+    call = lambda A, B, mul=1.0: w(A.ctypes.data_as(_fp), B.ctypes.data_as(_fp), mul)
+    assert call(eye, eye) == 1.0
+    for xi, want in (((0.03, 0, 0, 0, 0, 0), 1 - 0.03 / 0.15), ((0, 0, 0, 0, 0.06, 0), 1 - 0.06 / 0.15), ((0.01, 0, 0, 0.02, 0.05, 0.01), 1 - math.sqrt(0.02 ** 2 + 0.05 ** 2 + 0.01 ** 2) / 0.15),
+                     ((0.5, 0, 0, 0, 0, 0), 0.5), ((0, 0, 0, 0, 0, 3.0), 0.5)):
+        A = colmajor(se3_exp(np.array([0.2, -0.1, 0.3, 0.4, -0.2, 0.1])))
+        B = colmajor(np.asarray(A.reshape(4, 4).T, np.float64) @ se3_exp(np.array(xi, np.float64)))
+        assert abs(call(A, B) - want) < 2e-5, xi
+        assert abs(call(A, B, 0.5) - 0.5 * want) < 1e-5
+
+
+def test_first_fuse_is_global_model_initialise(ora):
+    s, m, out = walk(ora, 1)
+    info = out[0]["info"]
+    ref = s.init_model_from_frame(0, np.eye(4), time=1)
+    assert info["count"] == ref.shape[0] == info["stats"][3] and info["tick"] == 2
+    assert same_bits(out[0]["surfels"], ref)
+    assert np.array_equal(info["pose"], np.eye(4, dtype=np.float32))
+    with pytest.raises(SfError):
+        m.fuse_frame(0, None)  # in_pose is only optional on the first call
+
+
+def test_refusing_the_same_frame_merges_every_candidate_pixel_with_itself(ora):
+    """a fronto-parallel plane, identity motion, the same frame again: each (x, y) % 2 == 0 pixel finds its own surfel (ray
+    distance 0); update.vert's mean of two equal positions leaves it in place, hist -> 2, last time -> 2, confidence by
+    the log-odds update; copy_unstable removes nothing (no depth differences, no younger duplicates)"""
+    b = np.full(24, 0.9, np.float32)
+    s = make_solver(ora, ROWS, COLS, driver_params(ora))
+    m = SurfelMap(s)
+    rng = np.random.default_rng(5)
+    depth = np.full((ROWS, COLS), 2.0, np.float32)
+    rgb = rng.integers(1, 256, (ROWS, COLS, 3)).astype(np.uint8)
+    load_view(s, depth, rgb, b)
+    m.fuse_frame(0, None)
+    before = m.download()
+    assert before.shape[0] == ROWS * COLS  # every pixel valid: surfel index = y + x * rows
+    assert np.all(before[:, 8:10] == 0) and np.all(np.abs(before[:, 10]) == 1)
+    m.fuse_frame(0, np.eye(4))
+    info, after = m.info(), m.download()
+    n_cand = (ROWS // 2) * (COLS // 2)
+    assert info["tick"] == 3 and info["stats"] == [n_cand, n_cand, n_cand, ROWS * COLS]
+    merged = after[:, 5] == 2
+    yy, xx = np.mgrid[0:ROWS, 0:COLS]
+    cand = ((xx % 2 == 0) & (yy % 2 == 0)).T.ravel()  # x outer, y inner
+    # surfel 0 reads as "no surfel" in the index image (index_map.frag writes the vertex id, 0 is also the clear value):
+    # pixel (0, 0) merges into a neighbour's surfel instead
+    odd_ones = np.nonzero(merged != cand)[0]
+    assert odd_ones.size == 2 and odd_ones[0] == 0 and odd_ones[1] in (1, ROWS, ROWS + 1)
+    assert np.all(after[~merged] == before[~merged])
+    merged = merged & cand
+    assert np.all(after[merged, 7] == 2) and np.all(after[merged, 6] == 1)
+    assert np.abs(after[merged, :3] - before[merged, :3]).max() < 1e-6 and np.all(after[merged, 4] == before[merged, 4])
+    assert np.all(after[merged, 8:11] == before[merged, 8:11]) and np.abs(after[merged, 11] - before[merged, 11]).max() < 1e-8
+    # update.vert:63-68 in float64
+    px = (xx.T.ravel() + 0.5 - 160.0, yy.T.ravel() + 0.5 - 120.0)
+    radial = np.exp(-((np.hypot(*px) / 200.0) ** 2) / 1.44)
+    a = np.minimum(np.float64(np.float32(0.9)), np.minimum(1.0, radial))  # min(probIsStatic, min(weighting, radialConf))
+    a = np.clip(2 * a * a, 0.01, 0.53)
+    c_k = np.clip(before[:, 3].astype(np.float64), 0.01, 0.99)  # round(255 * 0.9) / 255 from GlobalModel::initialise
+    want = 1 - 1 / (1 + (c_k / (1 - c_k)) * (a / (1 - a)))
+    assert np.abs(after[merged, 3] - want[merged]).max() < 2e-6
+    assert np.all(after[merged, 3] > before[merged, 3])  # a static observation raises the confidence
+    # the odd pixels are the candidates of the next tick
+    m.fuse_frame(0, np.eye(4))
+    third = m.download()
+    odd = ((xx % 2 == 1) & (yy % 2 == 1)).T.ravel()
+    assert m.info()["stats"] == [n_cand, n_cand, n_cand, ROWS * COLS] and np.array_equal(third[:, 7] == 3, odd)
+
+
+def test_identical_normals_hit_the_acos_domain_edge(ora):
+    """data.vert:149 accepts a surfel whose |normal.z| >= 0.75 only if acos(dot / (|a| |b|)) < 0.5. For two equal normals the
+    quotient can round above 1, where GLSL's acos is undefined (NaN on the GPUs the reference runs on): the restatement
+    keeps that (cos(0.5) < c <= 1), so re-fusing the very same room view leaves a few candidates unassociated."""
+    b = np.full(24, 0.9, np.float32)
+    s = make_solver(ora, ROWS, COLS, driver_params(ora))
+    m = SurfelMap(s)
+    depth, rgb = synthetic_view(np.eye(4), sphere=False)
+    load_view(s, depth, rgb, b)
+    m.fuse_frame(0, None)
+    m.fuse_frame(0, np.eye(4))
+    emitted, associated, merged_n, count = m.info()["stats"]
+    assert emitted == (ROWS // 2) * (COLS // 2) and 0.85 * emitted < associated < emitted
+    sf = m.download()
+    fresh = sf[sf[:, 6] == 2]
+    assert fresh.shape[0] > 0 and np.all(np.abs(fresh[:, 10]) >= 0.75) and np.all(fresh[:, 3] == np.float32(0.08))
+
+
+def test_static_walk_invariants(ora):
+    s, m, out = walk(ora, 5)
+    for k, o in enumerate(out):
+        info, sf = o["info"], o["surfels"]
+        assert o["err"] is None and info["tick"] == k + 2 and sf.shape[0] == info["count"]
+        assert np.allclose(info["pose"], np.linalg.matrix_power(se3_exp(XI), k), atol=1e-5)
+        if k == 0:
+            continue
+        emitted, associated, merged, count = info["stats"]
+        assert emitted <= (ROWS // 2) * (COLS // 2) and associated >= 0.97 * emitted  # a static scene seen from a known pose
+        assert merged <= associated and count == info["count"]
+        assert not np.isnan(sf).any()
+        assert np.all((sf[:, 3] > 0) & (sf[:, 3] < 1)) and np.all(sf[:, 5] >= 1) and np.all(sf[:, 7] >= 1) and np.all(sf[:, 7] <= k + 1)
+        assert np.all(sf[:, 6] <= sf[:, 7]) and np.abs(np.linalg.norm(sf[:, 8:11], axis=1) - 1).max() < 1e-5
+        # the index image of the second predictIndices: every entry is a surfel of the merged model that projects into its texel
+        idx = o["index"]
+        assert idx.shape == (4 * ROWS, 4 * COLS) and 0.04 < (idx > 0).mean() < 0.08  # one texel of the 4x image per visible surfel
+    # surfels seen again and again gain confidence and history
+    last = out[-1]["surfels"]
+    assert last[:, 5].max() >= 3 and np.median(last[last[:, 5] >= 3, 3]) > np.median(out[0]["surfels"][:, 3])
+    # the prediction rendered from the fused map at the last pose resembles the view rendered from the scene there
+    T_last = np.linalg.matrix_power(se3_exp(XI), len(out) - 1)
+    depth, _ = synthetic_view(T_last, sphere=False)
+    pred = out[-1]["pred"][0]
+    ok = (pred > 0) & (depth > 0) & (depth < 4.4)
+    assert ok.mean() > 0.8 and np.median(np.abs(pred[ok] - depth[ok])) < 5e-3
+
+
+def test_index_image_entries_project_into_their_texel(ora):
+    s = make_solver(ora, ROWS, COLS, driver_params(ora))
+    m = SurfelMap(s)
+    yy, xx = np.mgrid[0:ROWS, 0:COLS]
+    rgb = np.random.default_rng(5).integers(1, 256, (ROWS, COLS, 3)).astype(np.uint8)
+    out = []
+    for k in range(2):  # a slanted plane, approached by 2 cm
+        load_view(s, (2.0 + 0.002 * xx + 0.001 * yy - 0.02 * k).astype(np.float32), rgb, np.full(24, 0.9, np.float32))
+        m.fuse_frame(0, None if k == 0 else se3_exp(np.array([0, 0, 0.02, 0, 0, 0])))
+        out.append(dict(info=m.info(), surfels=m.download(), index=m.index_map() if k else None))
+    idx = out[1]["index"]
+    mp = s.default_model_params()
+    # the second predictIndices runs on the MERGED model, which clean then compacts; without removals the map order is kept
+    sf = out[1]["surfels"]
+    if out[1]["info"]["stats"][3] != out[0]["info"]["count"] + (out[1]["info"]["stats"][0] - out[1]["info"]["stats"][1]):
+        pytest.skip("clean removed surfels: indices of the merged model are not those of the final map")
+    T_inv = np.linalg.inv(out[1]["info"]["pose"].astype(np.float64))
+    ys, xs = np.nonzero(idx)
+    sel = np.random.default_rng(0).choice(ys.size, 4000, replace=False)
+    ids = idx[ys[sel], xs[sel]]
+    p = sf[ids, :3].astype(np.float64) @ T_inv[:3, :3].T + T_inv[:3, 3]
+    u = 4 * mp.fx * p[:, 0] / p[:, 2] + 4 * mp.cx
+    v = 4 * mp.fy * p[:, 1] / p[:, 2] + 4 * mp.cy
+    assert np.all(np.abs(np.floor(u + 1e-3) - xs[sel]) <= 1) and np.all(np.abs(np.floor(v + 1e-3) - ys[sel]) <= 1)
+    assert (np.floor(u) == xs[sel]).mean() > 0.99 and (np.floor(v) == ys[sel]).mean() > 0.99
+
+
+def test_dynamic_pixels_do_not_enter_the_map_and_lower_confidence(ora):
+    b = np.full(24, 0.9, np.float32)
+    b[::2] = 0.1  # every second cluster is believed to move
+    s, m, out = walk(ora, 3, b=b)
+    first = out[0]["surfels"]
+    assert set(np.unique(np.round(first[:, 3], 3))) <= {np.float32(0.102), np.float32(0.902)}  # round(255 b) / 255
+    for o in out[1:]:
+        sf = o["surfels"]
+        fresh = sf[:, 6] > 1  # created after the first frame: only where b > 0.5 (data.vert:177-180), at confidence 0.08
+        assert np.all(sf[fresh & (sf[:, 5] == 1), 3] == np.float32(0.08))
+        assert not np.any(sf[:, 3] == 0)
+    # surfels observed as dynamic (a = clamp(2 * 0.1^2) = 0.02) lose confidence with every merge
+    low = out[2]["surfels"]
+    seen = (low[:, 5] >= 2) & (low[:, 3] < 0.1)
+    assert seen.sum() > 1000 and np.all(low[seen, 3] < np.float32(0.102))
+
+
+def test_capacity_truncates_like_transform_feedback(ora):
+    with pytest.raises(SfError):
+        SurfelMap(make_solver(ora, ROWS, COLS, driver_params(ora)), capacity=1000)  # below rows * cols
+    # a camera that turns away sees new surface: the map wants to grow beyond a capacity of exactly one frame
+    turn = np.array([0.0, 0.0, 0.0, 0.0, 0.12, 0.0])
+    s, m, out = walk(ora, 3, capacity=ROWS * COLS, xi=turn)
+    assert out[0]["err"] is None
+    assert any(o["err"] is not None and "capacity" in o["err"] for o in out[1:])
+    assert all(o["info"]["count"] <= ROWS * COLS for o in out)
+    assert any(o["info"]["count"] == ROWS * COLS for o in out[1:])
+
+
+def test_map_upload_roundtrip_and_prediction_from_the_map(ora):
+    s, m, out = walk(ora, 2)
+    sf, info = out[1]["surfels"], out[1]["info"]
+    m2 = SurfelMap(s)
+    m2.upload(sf, info["pose"], info["tick"])
+    assert same_bits(m2.download(), sf) and m2.info()["tick"] == info["tick"]
+    m2.predict(0)
+    d2, i2 = s.prediction()
+    mp = s.default_model_params()
+    mp.time = mp.max_time = info["tick"]
+    s.predict_from_model(0, sf, info["pose"], mp)
+    d1, i1 = s.prediction()
+    assert same_bits(d1, d2) and same_bits(i1, i2)
+
+
+# ------------------------------------------------------------------------------------------------
+#  GPU: HIP vs oracle
+# ------------------------------------------------------------------------------------------------
+def _compare_walk(hip, ora, **kw):
+    _, _, ref = walk(ora, **kw)
+    _, _, got = walk(hip, **kw)
+    for k, (r, g) in enumerate(zip(ref, got)):
+        assert (r["err"] is None) == (g["err"] is None), (k, r["err"], g["err"])
+        assert r["info"]["count"] == g["info"]["count"] and r["info"]["stats"] == g["info"]["stats"], (k, r["info"], g["info"])
+        assert r["info"]["tick"] == g["info"]["tick"] and np.array_equal(r["info"]["pose"], g["info"]["pose"])
+        if k:
+            assert np.array_equal(r["index"], g["index"]), (k, int((r["index"] != g["index"]).sum()))
+        bad = ~((r["surfels"].view(np.uint32) == g["surfels"].view(np.uint32)) | (np.isnan(r["surfels"]) & np.isnan(g["surfels"])))
+        assert not bad.any(), (k, int(bad.any(1).sum()), np.nonzero(bad.any(1))[0][:5], bad.sum(0))
+        assert same_bits(r["pred"][0], g["pred"][0]) and same_bits(r["pred"][1], g["pred"][1]), k
+    return ref
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sphere", [False, True])
+def test_hip_fusion_matches_oracle_bit_for_bit(hip, ora, sphere):
+    b = np.linspace(0.05, 1.0, 24).astype(np.float32)  # both sides of the b > 0.5 / b > 0.6 gates
+    ref = _compare_walk(hip, ora, n_frames=6, sphere=sphere, b=b)
+    assert ref[-1]["info"]["stats"][1] > 10000 and ref[-1]["info"]["count"] != ref[0]["info"]["count"]
+
+
+@pytest.mark.gpu
+def test_hip_fusion_fast_motion_and_truncation(hip, ora):
+    turn = np.array([0.02, 0.0, 0.01, 0.0, 0.12, 0.01])
+    ref = _compare_walk(hip, ora, n_frames=4, capacity=ROWS * COLS, xi=turn)
+    assert any(o["err"] for o in ref)
+
+
+@pytest.mark.gpu
+def test_hip_map_is_what_predict_from_model_renders(hip):
+    s, m, out = walk(hip, 3)
+    mp = s.default_model_params()
+    mp.time = mp.max_time = out[-1]["info"]["tick"]
+    s.predict_from_model(0, out[-1]["surfels"], out[-1]["info"]["pose"], mp)
+    d, i = s.prediction()
+    assert same_bits(d, out[-1]["pred"][0]) and same_bits(i, out[-1]["pred"][1])
+    other = make_solver(hip, ROWS, COLS, driver_params(hip))
+    with pytest.raises(SfError):  # a map belongs to the handle that made it
+        other.api.check(other.api.map_fuse_frame(other.h, 0, m.m, None, 1.0, C.byref(mp)))

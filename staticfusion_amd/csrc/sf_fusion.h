@@ -15,8 +15,8 @@
 //     candidate's order index: the first fragment passes the depth test, later ones at the same texel fail it.
 //   * merge: one lane per model surfel reads winner[] and the winning candidate's record (update.vert).
 //   * clean: transform feedback = ORDERED stream compaction of [model surfels ..., candidates ...] by the
-//     copy_unstable test: flags + per-1024 block counts, one-workgroup scan of the block counts, ordered scatter
-//     (ballot ranks within a wave, LDS prefix over the 16 waves).
+//     copy_unstable test: flags + per-256 block counts, one-workgroup scan of the block counts, ordered scatter
+//     (ballot ranks within a wave, LDS prefix over the waves of the block).
 // Every float expression repeats the shader's association; no contraction; exp / log are sf_detmath.h's: bit-identical
 // to the CPU oracle (oracle/sf_oracle_fusion.cpp states the choices made where GL leaves room).
 #pragma once
@@ -49,7 +49,7 @@ struct FuseArgs {
     unsigned *meta;   // n_cand x 2: update_id, best
     // clean
     unsigned char *flags;  // [count + n_cand]
-    int *block_counts;     // [ceil((count + n_cand) / 1024)]  (becomes the exclusive offsets)
+    int *block_counts;     // [ceil((count + n_cand) / SF_CLEAN_BLOCK)]  (becomes the exclusive offsets)
     int *result;           // [0] count after clean (clamped), [1] unclamped, [2] emitted, [3] associated, [4] merged surfels
 };
 
@@ -76,16 +76,17 @@ __device__ __forceinline__ PV3 decode_color3(float c) {
     const int k = int(c);
     return {float((k >> 16) & 0xFF) / 255.0f, float((k >> 8) & 0xFF) / 255.0f, float(k & 0xFF) / 255.0f};
 }
-__device__ __forceinline__ unsigned index_at(const FuseArgs &a, float u, float v) {
-    const int W4 = a.cols * 4, H4 = a.rows * 4;
-    const unsigned long long key = a.keys[(size_t)nearest_texel(v, H4) * W4 + nearest_texel(u, W4)];
-    return key == SF_PRED_EMPTY ? 0u : (unsigned)(key & 0xffffffffull);
-}
-
 // ---- IndexMap::predictIndices -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sf_index_clear_kernel(unsigned long long *keys, size_t n) {
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (o < n) keys[o] = SF_PRED_EMPTY;
+}
+// start of a fuse: clear the index image, the update-map winners and the counters in one launch
+__global__ __launch_bounds__(256) void sf_fuse_begin_kernel(unsigned long long *keys, size_t n_keys, unsigned *winner, int count, int *result) {
+    const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (o < n_keys) keys[o] = SF_PRED_EMPTY;
+    if (o < (size_t)count) winner[o] = SF_FUSE_NONE;
+    if (o < 8) result[o] = 0;
 }
 // surfels: the buffer the index image is rendered from (src before the merge, dst after it)
 __global__ __launch_bounds__(256) void sf_index_splat_kernel(FuseArgs a, const float *surfels) {
@@ -134,8 +135,8 @@ __device__ __forceinline__ PV3 index_texel_normal(const FuseArgs &a, const float
 }
 
 // ---- GlobalModel::fuse, data association (data.vert) --------------------------------------------------------------
-__global__ __launch_bounds__(256) void sf_fuse_data_kernel(FuseArgs a) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(64) void sf_fuse_data_kernel(FuseArgs a) {  // 64: 19 200 candidates at QVGA are 300 single-wave workgroups, one per CU
+    const int q = blockIdx.x * 64 + threadIdx.x;
     if (q >= a.n_cand) return;
     const int ic = q / a.cand_rows, jc = q - ic * a.cand_rows;
     const int i = 2 * ic + a.par, j = 2 * jc + a.par;
@@ -182,9 +183,22 @@ __global__ __launch_bounds__(256) void sf_fuse_data_kernel(FuseArgs a) {
         const PV3 ray{xl, yl, 1.f};
         const float ray_len = plength(ray);
         const float nl_len = plength(vNormLocal);
-        for (float u = tx - (scale * indexXStep * windowMultiplier); u < tx + (scale * indexXStep * windowMultiplier); u += indexXStep)
+        // The window steps its texture coordinate in HALF texels (data.vert:133-135): consecutive samples often read the
+        // same texel. The texel sequence of each axis is non-decreasing, a repeated texel offers the same candidate at the
+        // same distance, and only a STRICTLY nearer one replaces the best: repeats are skipped, the result is unchanged.
+        const int W4 = cols * 4, H4 = rows * 4;
+        int prev_tu = -1;
+        for (float u = tx - (scale * indexXStep * windowMultiplier); u < tx + (scale * indexXStep * windowMultiplier); u += indexXStep) {
+            const int tu = nearest_texel(u, W4);
+            if (tu == prev_tu) continue;
+            prev_tu = tu;
+            int prev_tv = -1;
             for (float v = ty - (scale * indexYStep * windowMultiplier); v < ty + (scale * indexYStep * windowMultiplier); v += indexYStep) {
-                const unsigned current = index_at(a, u, v);
+                const int tv = nearest_texel(v, H4);
+                if (tv == prev_tv) continue;
+                prev_tv = tv;
+                const unsigned long long key = a.keys[(size_t)tv * W4 + tu];
+                const unsigned current = key == SF_PRED_EMPTY ? 0u : (unsigned)(key & 0xffffffffull);
                 if (current > 0U) {
                     const IndexTexelD t = index_texel_pos(a, a.src, current);
                     if (fabsf((t.pos.z * lambda) - (vPosLocal.z * lambda)) < 0.05f) {
@@ -205,6 +219,7 @@ __global__ __launch_bounds__(256) void sf_fuse_data_kernel(FuseArgs a) {
                     }
                 }
             }
+        }
         if (counter > 0) {
             update_id = 1;
             t_last = -1.f;
@@ -291,9 +306,10 @@ __device__ __forceinline__ const float *clean_element(const FuseArgs &a, int e, 
     present = a.meta[(size_t)q * 2] > 0;  // data.geom emits only updateId > 0
     return a.rec + (size_t)q * 12;
 }
-__global__ __launch_bounds__(1024) void sf_clean_flag_kernel(FuseArgs a) {
+#define SF_CLEAN_BLOCK 256  // compaction granule: small, so that a QVGA map (93 k elements) still covers the 256 CUs
+__global__ __launch_bounds__(SF_CLEAN_BLOCK) void sf_clean_flag_kernel(FuseArgs a) {
     __shared__ int block_total;
-    const int e = blockIdx.x * 1024 + threadIdx.x;
+    const int e = blockIdx.x * SF_CLEAN_BLOCK + threadIdx.x;
     const int n = a.count + a.n_cand;
     if (threadIdx.x == 0) block_total = 0;
     __syncthreads();
@@ -316,18 +332,44 @@ __global__ __launch_bounds__(1024) void sf_clean_flag_kernel(FuseArgs a) {
             const float conf_v = q[3], t_init_v = q[6], rad_v = q[11];
             float t_last_v = q[7];
             if (ftime - t_last_v < fdelta && localPos.z > 0.f && x > 0.f && y > 0.f && x < W && y < H) {
-                for (float u = x / W - (scale * indexXStep * windowMultiplier); u < x / W + (scale * indexXStep * windowMultiplier); u += indexXStep)
-                    for (float v = y / H - (scale * indexYStep * windowMultiplier); v < y / H + (scale * indexYStep * windowMultiplier); v += indexYStep) {
-                        const unsigned current = index_at(a, u, v);
-                        if (current > 0U) {
-                            const IndexTexelD t = index_texel_pos(a, a.dst, current);
-                            const float dx = t.pos.x - localPos.x, dy = t.pos.y - localPos.y;
-                            if (t.t_init < t_init_v && t.conf > a.conf_threshold && t.pos.z > localPos.z && t.pos.z - localPos.z < 0.01f &&
-                                sqrtf(dx * dx + dy * dy) < rad_v * 1.4f)
-                                count++;
-                            if (t.t_last == ftime && t.conf > 0.4f * a.conf_threshold && t.pos.z > localPos.z && t.pos.z - localPos.z > 0.01f) zCount++;
-                        }
+                // half-texel steps (copy_unstable.vert:62-64): a texel read m_u x m_v times counts m_u x m_v times; evaluate it once
+                const int W4 = a.cols * 4, H4 = a.rows * 4;
+                auto eval = [&](int tu, int tv, int mult) {
+                    const unsigned long long key = a.keys[(size_t)tv * W4 + tu];
+                    const unsigned current = key == SF_PRED_EMPTY ? 0u : (unsigned)(key & 0xffffffffull);
+                    if (current > 0U) {
+                        const IndexTexelD t = index_texel_pos(a, a.dst, current);
+                        const float dx = t.pos.x - localPos.x, dy = t.pos.y - localPos.y;
+                        if (t.t_init < t_init_v && t.conf > a.conf_threshold && t.pos.z > localPos.z && t.pos.z - localPos.z < 0.01f &&
+                            sqrtf(dx * dx + dy * dy) < rad_v * 1.4f)
+                            count += mult;
+                        if (t.t_last == ftime && t.conf > 0.4f * a.conf_threshold && t.pos.z > localPos.z && t.pos.z - localPos.z > 0.01f) zCount += mult;
                     }
+                };
+                auto column = [&](int tu, int mu) {
+                    int prev_tv = -1, mv = 0;
+                    for (float v = y / H - (scale * indexYStep * windowMultiplier); v < y / H + (scale * indexYStep * windowMultiplier); v += indexYStep) {
+                        const int tv = nearest_texel(v, H4);
+                        if (tv != prev_tv) {
+                            if (mv) eval(tu, prev_tv, mu * mv);
+                            prev_tv = tv;
+                            mv = 1;
+                        } else
+                            mv++;
+                    }
+                    if (mv) eval(tu, prev_tv, mu * mv);
+                };
+                int prev_tu = -1, mu = 0;
+                for (float u = x / W - (scale * indexXStep * windowMultiplier); u < x / W + (scale * indexXStep * windowMultiplier); u += indexXStep) {
+                    const int tu = nearest_texel(u, W4);
+                    if (tu != prev_tu) {
+                        if (mu) column(prev_tu, mu);
+                        prev_tu = tu;
+                        mu = 1;
+                    } else
+                        mu++;
+                }
+                if (mu) column(prev_tu, mu);
             }
             if (count > 6 || zCount > 5) test = 0;
             if (t_last_v == -2.f) t_last_v = ftime;
@@ -376,10 +418,10 @@ __global__ __launch_bounds__(1024) void sf_clean_scan_kernel(FuseArgs a, int n_b
     }
 }
 // ordered scatter into src (the buffer the merged model was NOT written to becomes the map again)
-__global__ __launch_bounds__(1024) void sf_clean_write_kernel(FuseArgs a, float *out) {
-    __shared__ int wcount[16];
+__global__ __launch_bounds__(SF_CLEAN_BLOCK) void sf_clean_write_kernel(FuseArgs a, float *out) {
+    __shared__ int wcount[SF_CLEAN_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int e = blockIdx.x * 1024 + tid;
+    const int e = blockIdx.x * SF_CLEAN_BLOCK + tid;
     const int n = a.count + a.n_cand;
     const bool keep = e < n && a.flags[e] != 0;
     const unsigned long long m = __ballot(keep);

@@ -965,7 +965,7 @@ int sf_map_create(sf_handle *h, int capacity, sf_map **out) {
     if (!e) e = map_alloc(m, &m->rec, n_cand_max * 12);
     if (!e) e = map_alloc(m, &m->meta, n_cand_max * 2);
     if (!e) e = map_alloc(m, &m->flags, cap + n_cand_max);
-    if (!e) e = map_alloc(m, &m->block_counts, (cap + n_cand_max + 1023) / 1024 + 1);
+    if (!e) e = map_alloc(m, &m->block_counts, (cap + n_cand_max + SF_CLEAN_BLOCK - 1) / SF_CLEAN_BLOCK + 1);
     if (!e) e = map_alloc(m, &m->result, 8);
     if (e) {
         sf_map_destroy(m);
@@ -1046,19 +1046,19 @@ int sf_map_fuse_frame(sf_handle *h, int stream, sf_map *m, const float *in_pose,
     const unsigned key_blocks = (unsigned)((n_keys + 255) / 256);
     const unsigned surfel_blocks = (unsigned)((a.count + 255) / 256);
     const int n_elems = a.count + a.n_cand;
-    const int n_blocks = (n_elems + 1023) / 1024;
-    HIP_TRY(hipMemsetAsync(m->result, 0, 8 * sizeof(int), h->stream));
-    if (a.count) HIP_TRY(hipMemsetAsync(m->winner, 0xff, (size_t)a.count * sizeof(unsigned), h->stream));
-    hipLaunchKernelGGL(sf_index_clear_kernel, dim3(key_blocks), dim3(256), 0, h->stream, m->keys, n_keys);         // :284
+    const int n_blocks = (n_elems + SF_CLEAN_BLOCK - 1) / SF_CLEAN_BLOCK;
+    const size_t n_begin = std::max(n_keys, (size_t)a.count);
+    hipLaunchKernelGGL(sf_fuse_begin_kernel, dim3((unsigned)((n_begin + 255) / 256)), dim3(256), 0, h->stream, m->keys, n_keys, m->winner, a.count,
+                       m->result);                                                                                   // :284
     if (a.count) hipLaunchKernelGGL(sf_index_splat_kernel, dim3(surfel_blocks), dim3(256), 0, h->stream, a, a.src);
-    if (a.n_cand) hipLaunchKernelGGL(sf_fuse_data_kernel, dim3((a.n_cand + 255) / 256), dim3(256), 0, h->stream, a);  // :286-298
+    if (a.n_cand) hipLaunchKernelGGL(sf_fuse_data_kernel, dim3((a.n_cand + 63) / 64), dim3(64), 0, h->stream, a);  // :286-298
     if (a.count) hipLaunchKernelGGL(sf_fuse_update_kernel, dim3(surfel_blocks), dim3(256), 0, h->stream, a);
     hipLaunchKernelGGL(sf_index_clear_kernel, dim3(key_blocks), dim3(256), 0, h->stream, m->keys, n_keys);         // :300
     if (a.count) hipLaunchKernelGGL(sf_index_splat_kernel, dim3(surfel_blocks), dim3(256), 0, h->stream, a, (const float *)a.dst);
     if (n_blocks) {                                                                                                  // :302-311
-        hipLaunchKernelGGL(sf_clean_flag_kernel, dim3(n_blocks), dim3(1024), 0, h->stream, a);
+        hipLaunchKernelGGL(sf_clean_flag_kernel, dim3(n_blocks), dim3(SF_CLEAN_BLOCK), 0, h->stream, a);
         hipLaunchKernelGGL(sf_clean_scan_kernel, dim3(1), dim3(1024), 0, h->stream, a, n_blocks);
-        hipLaunchKernelGGL(sf_clean_write_kernel, dim3(n_blocks), dim3(1024), 0, h->stream, a, m->buf[0]);
+        hipLaunchKernelGGL(sf_clean_write_kernel, dim3(n_blocks), dim3(SF_CLEAN_BLOCK), 0, h->stream, a, m->buf[0]);
     }
     HIP_TRY(hipGetLastError());
     int res[8];

@@ -286,3 +286,60 @@ def test_sequence_runner_keyframe_model_mode(hip, ora, lib, tmp_path):
     err_frame = pose_delta(pf[9], gts[9])
     assert err_model[0] < 1e-2 and err_model[1] < 3e-2, err_model
     print("pose error after 9 frames: keyframe model", err_model, "frame-to-frame", err_frame)
+
+
+def test_sequence_runner_fusion_mode_on_the_oracle(ora, lib, tmp_path):
+    """CPU-sized: the reference's full loop (solve -> fuseFrame -> getPredictedImages) on 5 synthetic frames."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from run_sequence import run
+    from staticfusion_amd.synth import pose_delta
+
+    root = str(tmp_path / "ds")
+    gts = write_dataset(root, 5, sphere=False)
+    trace = []
+    poses, lines, s = run(ora, lib, root, mode="fusion", trace=trace)
+    assert len(poses) == 5 and len(lines) == 5 and [t["frame"] for t in trace] == [1, 2, 3, 4]
+    assert trace[0]["stats"][0] == 0 and trace[0]["count"] > 70000           # the bootstrap fuse initialises the map
+    assert all(t["stats"][1] > 0.95 * t["stats"][0] > 0 for t in trace[1:])   # then nearly every candidate pixel finds its surfel
+    info = s.map.info()
+    assert info["tick"] == 5 and np.array_equal(info["pose"], poses[-1])
+    acc = np.eye(4, dtype=np.float32)
+    for T in s.increments[1:]:
+        acc = lib.pose_compose(acc, T)
+    assert np.array_equal(acc, poses[-1])                                     # currPose = product of the T_odometry
+    err = pose_delta(poses[-1], gts[-1])
+    assert err[0] < 5e-3 and err[1] < 2e-2, err
+
+
+@pytest.mark.gpu
+def test_sequence_runner_fusion_mode_hip_vs_oracle(hip, ora, lib, tmp_path):
+    """the full loop without OpenGL on the GPU. The per-frame parity is checked with the HIP run fusing at the oracle's
+    T_odometry (its map and therefore its predictions then see the same poses); free-running the two trajectories stay
+    together, and the fused map tracks better than frame-to-frame odometry."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from run_sequence import run
+    from staticfusion_amd.synth import pose_delta
+
+    root = str(tmp_path / "ds")
+    gts = write_dataset(root, 10, sphere=True)
+    tro, trt = [], []
+    po, _, so = run(ora, lib, root, mode="fusion", trace=tro)
+    pt, _, st = run(hip, lib, root, mode="fusion", odometry_override=so.increments, trace=trt)
+    worst = (0.0, 0.0)
+    for a, b in zip(tro, trt):
+        rot, trans = pose_delta(a["T"], b["T"])
+        worst = (max(worst[0], rot), max(worst[1], trans))
+        assert abs(a["count"] - b["count"]) <= 0.002 * a["count"] and abs(a["stats"][1] - b["stats"][1]) <= 0.01 * a["stats"][0], (a, b)
+    print("worst per-frame T_odometry difference HIP vs oracle, teacher-forced fusion:", worst)
+    assert worst[0] <= 1e-4 and worst[1] <= 1e-4, worst
+    assert all(np.array_equal(x, y) for x, y in zip(po, pt))  # same increments in, same poses out
+    pg, _, sg = run(hip, lib, root, mode="fusion")
+    free = pose_delta(po[-1], pg[-1])
+    err_map, err_gt_o = pose_delta(pg[-1], gts[-1]), pose_delta(po[-1], gts[-1])
+    pf, _, _ = run(hip, lib, root, mode="frame")
+    err_frame = pose_delta(pf[-1], gts[-1])
+    print("free-running HIP vs oracle after 9 frames", free, "; error vs ground truth: fused map", err_map, "oracle", err_gt_o, "frame-to-frame", err_frame)
+    assert free[0] < 1e-3 and free[1] < 2e-3, free
+    assert err_map[0] < 1e-2 and err_map[1] < 3e-2, err_map

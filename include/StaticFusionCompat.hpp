@@ -17,8 +17,10 @@
 // C ABI directly with batch > 1.
 #pragma once
 
+#include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "sf.h"
@@ -201,5 +203,105 @@ class StaticFusionCompat {
         p.k_photometric_res = k_photometric_res; p.irls_delta_threshold = irls_delta_threshold;
         p.kc_Cauchy = kc_Cauchy; p.kb = kb; p.lambda_reg = lambda_reg; p.lambda_prior = lambda_prior; p.kz = kz; p.fovh = fovh;
         check(sf_set_params(h_, &p), "set_params");
+    }
+};
+
+// ReconstructionCompat — the reference's `class Reconstruction` (Reconstruction.h:44-235) as the three drivers use it
+// (staticFusion.reconstruction->...), over the HIP surfel map (sf_map_*, include/sf.h) instead of OpenGL. It works on
+// the frame the front end holds: StaticFusionCompat::loadImageFromDecoded + buildSegmImage have already put RGB, depth
+// and the weighted image into the handle, so fuseFrame's three image pointers are accepted for signature compatibility
+// and not read (all three drivers pass exactly the front end's color_full / depth_mm / b_segm_perpixel).
+class ReconstructionCompat {
+   public:
+    // reference: Reconstruction(timeDelta, confidence, depthCut, fileName, clusters), Reconstruction.cpp:21-51; the front
+    // end constructs it with (INT_MAX, 0.25, 4.5, "sf-mesh", 24) (FrontEnd.cpp:165-180). capacity: surfels the map can
+    // hold (0 = the reference's 3072 x 3072).
+    explicit ReconstructionCompat(StaticFusionCompat &front, int timeDelta = 200, float confidence = 10.f, float depthCut = 3.f, int capacity = 0)
+        : front_(front), timeDelta_(timeDelta), confidenceThreshold_(confidence), depthCutoff_(depthCut) {
+        check(sf_map_create(front_.handle(), capacity, &map_), "map_create");
+    }
+    ~ReconstructionCompat() { sf_map_destroy(map_); }
+    ReconstructionCompat(const ReconstructionCompat &) = delete;
+    ReconstructionCompat &operator=(const ReconstructionCompat &) = delete;
+
+    // reference: fuseFrame(rgb, depth, weightedImage, timestamp, inPose, gtPose, weightMultiplier), Reconstruction.cpp:235-325.
+    // Call it where the drivers do: after buildSegmImage and the ring-buffer writes of the frame.
+    void fuseFrame(const unsigned char * /*rgb*/, const unsigned short * /*depth*/, const float * /*weightedImage*/, const int64_t &timestamp,
+                   const sf::Matrix4f *inPose, const sf::Matrix4f *gtPose = nullptr, const float weightMultiplier = 1.f) {
+        check(sf_set_depth_cutoff(front_.handle(), depthCutoff_), "set_depth_cutoff");
+        check(sf_filter_depth(front_.handle()), "filter_depth");  // filterDepth(); metriciseDepth(); (:246-247)
+        const sf_model_params mp = params();
+        check(sf_map_fuse_frame(front_.handle(), 0, map_, inPose ? inPose->m : nullptr, weightMultiplier, &mp), "map_fuse_frame");
+        int tick = 0;
+        sf::Matrix4f pose;
+        check(sf_map_info(map_, nullptr, &tick, pose.m, nullptr), "map_info");
+        poseGraph.push_back(std::make_pair((unsigned long long)(tick - 1), pose));  // :315
+        if (gtPose) gtPoseGraph.push_back(std::make_pair((unsigned long long)(tick - 1), *gtPose));
+        poseLogTimes.push_back(timestamp);                                          // :321
+    }
+    // reference: getPredictedImages(depthPrediction, intensityPrediction), Reconstruction.cpp:628-720
+    void getPredictedImages(sf::MatrixXf &depthPrediction, sf::MatrixXf &intensityPrediction) {
+        const sf_model_params mp = params();
+        check(sf_map_predict(front_.handle(), 0, map_, &mp), "map_predict");
+        check(sf_get_prediction(front_.handle(), 0, depthPrediction.data(), intensityPrediction.data()), "get_prediction");
+    }
+    // reference: getFilteredDepth(depth_mm, depthCurrent), Reconstruction.cpp:722-732 (of the frame the front end loaded last)
+    void getFilteredDepth(const std::vector<uint16_t> & /*depth_mm*/, sf::MatrixXf &depthCurrent) {
+        check(sf_set_depth_cutoff(front_.handle(), depthCutoff_), "set_depth_cutoff");
+        check(sf_filter_depth(front_.handle()), "filter_depth");
+        check(sf_get_current(front_.handle(), 0, depthCurrent.data(), nullptr), "get_current");
+    }
+    // reference: checkIfDenseEnough(), Reconstruction.cpp:762-776 -- the density of the low-confidence image the LAST
+    // getPredictedImages rendered (the call re-renders only the high-confidence target)
+    bool checkIfDenseEnough() {
+        int dense = 0;
+        check(sf_get_prediction_dense(front_.handle(), &dense), "get_prediction_dense");
+        return dense != 0;
+    }
+    sf::Matrix4f getCurrPose() const {
+        sf::Matrix4f pose;
+        check(sf_map_info(map_, nullptr, nullptr, pose.m, nullptr), "map_info");
+        return pose;
+    }
+    int getTick() const {
+        int tick = 0;
+        check(sf_map_info(map_, nullptr, &tick, nullptr, nullptr), "map_info");
+        return tick;
+    }
+    unsigned int lastCount() const {  // getGlobalModel().lastCount()
+        int n = 0;
+        check(sf_map_info(map_, &n, nullptr, nullptr, nullptr), "map_info");
+        return (unsigned int)n;
+    }
+    // GlobalModel::downloadMap (GlobalModel.cpp:608-636): lastCount() x 12 floats
+    std::vector<float> downloadMap() const {
+        std::vector<float> out(size_t(lastCount()) * 12);
+        check(sf_map_download(map_, out.data(), int(out.size() / 12)), "map_download");
+        return out;
+    }
+    const float &getConfidenceThreshold() const { return confidenceThreshold_; }
+    void setConfidenceThreshold(const float &val) { confidenceThreshold_ = val; }
+    void setDepthCutoff(const float &val) { depthCutoff_ = val; }
+    const int &getTimeDelta() const { return timeDelta_; }
+    sf_map *map() { return map_; }
+
+    std::vector<std::pair<unsigned long long, sf::Matrix4f>> poseGraph, gtPoseGraph;  // Reconstruction.h:190-191
+    std::vector<int64_t> poseLogTimes;
+
+   private:
+    StaticFusionCompat &front_;
+    sf_map *map_ = nullptr;
+    int timeDelta_;
+    float confidenceThreshold_, depthCutoff_;
+
+    sf_model_params params() const {
+        sf_model_params mp;
+        check(sf_default_model_params(front_.handle(), &mp), "default_model_params");
+        mp.conf_high = confidenceThreshold_;
+        mp.time_delta = timeDelta_;
+        return mp;
+    }
+    static void check(int rc, const char *what) {
+        if (rc != SF_OK) throw std::runtime_error(std::string(what) + ": " + sf_last_error());
     }
 };

@@ -258,6 +258,11 @@ int SF_FN(predict_from_model_device)(sf_handle *h, int stream, const void *d_sur
  * sf_predict_from_model renders. */
 int SF_FN(init_model_from_frame)(sf_handle *h, int stream, const float pose[16], const sf_model_params *p, int time,
                                  float *surfels_out, int *count);
+/* Reconstruction::denseEnough of the handle's LAST prediction (Reconstruction.cpp:218-233: more than a quarter of the
+ * 1/40-resolution samples of the low-confidence rendering drawn). Reconstruction::checkIfDenseEnough (:762-776) returns
+ * exactly this about the previous frame's getPredictedImages: it re-renders the HIGH-confidence target but reads the
+ * low-confidence one. *dense = 0 before the first prediction. */
+int SF_FN(get_prediction_dense)(sf_handle *h, int *dense);
 /* depthPrediction / intensityPrediction (column-major float, rows*cols each; either may be NULL). */
 int SF_FN(get_prediction)(sf_handle *h, int stream, float *depth, float *intensity);
 

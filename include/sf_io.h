@@ -58,6 +58,12 @@ void sf_io_pose_compose(const float pose[16], const float T[16], float out[16]);
  * quaternion follows Eigen::Quaternionf(Matrix3f). */
 int sf_io_trajectory_line(double timestamp, const float pose[16], int rotate_by_z, char *buf, size_t buf_size);
 
+/* Reconstruction::savePly (reference Reconstruction.cpp:358-455), the map half: binary little-endian PLY of the surfels
+ * whose confidence exceeds conf_threshold -- x y z (float), red green blue (uchar, from the encoded colour), nx ny nz
+ * (float, NEGATED as the reference does), radius (float). surfels: count x 12 floats in the global model's vertex
+ * layout (sf_map_download). Returns the number of vertices written or a negative code. */
+int sf_io_save_ply(const char *path, const float *surfels, int count, float conf_threshold);
+
 const char *sf_io_last_error(void);
 
 #ifdef __cplusplus

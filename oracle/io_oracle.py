@@ -157,3 +157,19 @@ def trajectory_line(timestamp, pose, rotate_by_z):
         ts = "%.6f" % timestamp
     q = _quat(pose)
     return " ".join([ts, _g(pose[0, 3]), _g(pose[1, 3]), _g(pose[2, 3]), _g(q[0]), _g(q[1]), _g(q[2]), _g(q[3])]) + "\n"
+
+
+def save_ply_bytes(surfels, conf_threshold):
+    """Reconstruction::savePly (reference Reconstruction.cpp:358-455): the bytes of the .ply it writes"""
+    s = np.asarray(surfels, f32).reshape(-1, 12)
+    keep = s[s[:, 3] > f32(conf_threshold)]
+    head = ("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z"
+            "\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nproperty float nx\nproperty float ny\nproperty float nz"
+            "\nproperty float radius\nend_header\n" % keep.shape[0]).encode()
+    rec = np.zeros(keep.shape[0], np.dtype([("p", "<f4", 3), ("c", "u1", 3), ("n", "<f4", 3), ("r", "<f4")]))
+    rec["p"] = keep[:, 0:3]
+    col = keep[:, 4].astype(np.int64)
+    rec["c"] = np.stack([(col >> 16) & 0xFF, (col >> 8) & 0xFF, col & 0xFF], 1)
+    rec["n"] = keep[:, 8:11] * f32(-1)
+    rec["r"] = keep[:, 11]
+    return head + rec.tobytes()

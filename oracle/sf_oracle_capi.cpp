@@ -27,6 +27,7 @@ struct sf_handle {
     // input stage (per stream, row-major rows x cols)
     float depth_cutoff = 4.5f;  // FrontEnd.cpp:168
     bool have_frame = false;
+    bool pred_dense = false;
     std::vector<std::vector<uint16_t>> depth_mm, filtered_mm;
     std::vector<std::vector<float>> depth_metric;
     std::vector<std::vector<uint8_t>> color;
@@ -543,7 +544,7 @@ int sfo_predict_from_model(sf_handle *h, int stream, const float *surfels, int c
         for (int c = 0; c < 4; c++) t_inv[r + 4 * c] = float(Ai[r * 4 + c]);
     sfo::ModelParams mp{p->cx, p->cy, p->fx, p->fy, p->max_depth, p->conf_low, p->conf_high, p->time, p->max_time, p->time_delta, p->extract_max_depth};
     auto &s = *h->s[stream];
-    sfo::predict_from_model(surfels, count, t_inv, mp, h->rows, h->cols, h->filtered_mm[stream].data(), h->color[stream].data(),
+    h->pred_dense = sfo::predict_from_model(surfels, count, t_inv, mp, h->rows, h->cols, h->filtered_mm[stream].data(), h->color[stream].data(),
                             s.b_segm_perpixel.d.data(), s.depthPrediction.d.data(), s.intensityPrediction.d.data());
     return SF_OK;
 }
@@ -558,6 +559,11 @@ int sfo_init_model_from_frame(sf_handle *h, int stream, const float pose[16], co
     auto &s = *h->s[stream];
     *count = sfo::init_model_from_frame(h->depth_metric[stream].data(), s.depthCurrent.d.data(), h->color[stream].data(),
                                         s.b_segm_perpixel.d.data(), h->rows, h->cols, pose, mp, time, out);
+    return SF_OK;
+}
+int sfo_get_prediction_dense(sf_handle *h, int *dense) {
+    if (!h || !dense) return fail(SF_ERR_ARG, "null");
+    *dense = h->pred_dense ? 1 : 0;
     return SF_OK;
 }
 int sfo_get_prediction(sf_handle *h, int stream, float *depth, float *intensity) {

@@ -98,7 +98,7 @@ void splat_pass(const float *surfels, int count, const float *t_inv, const Model
 }
 }  // namespace
 
-void predict_from_model(const float *surfels, int count, const float t_inv[16], const ModelParams &p, int rows, int cols,
+bool predict_from_model(const float *surfels, int count, const float t_inv[16], const ModelParams &p, int rows, int cols,
                         const uint16_t *filtered_mm, const uint8_t *color, const float *b_img, float *depth_pred, float *inten_pred) {
     const int n = rows * cols;
     Target low(n), high(n);
@@ -140,6 +140,7 @@ void predict_from_model(const float *surfels, int count, const float t_inv[16], 
             const float r = float(c[0]) * norm_factor, g = float(c[1]) * norm_factor, b = float(c[2]) * norm_factor;  // :686-690
             inten_pred[y + size_t(x) * rows] = 0.299f * r + 0.587f * g + 0.114f * b;                                    // :692
         }
+    return dense;
 }
 }  // namespace sfo
 

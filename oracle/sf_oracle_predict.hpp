@@ -8,8 +8,8 @@ struct ModelParams {
     float extract_max_depth;
 };
 // surfels: count x 12 floats; t_inv: pose.inverse(), column-major; filtered_mm / color: rows x cols row-major;
-// b_img: rows x cols column-major; outputs column-major
-void predict_from_model(const float *surfels, int count, const float t_inv[16], const ModelParams &p, int rows, int cols,
+// b_img: rows x cols column-major; outputs column-major; returns denseEnough of the low-confidence image
+bool predict_from_model(const float *surfels, int count, const float t_inv[16], const ModelParams &p, int rows, int cols,
                         const uint16_t *filtered_mm, const uint8_t *color, const float *b_img, float *depth_pred, float *inten_pred);
 }  // namespace sfo
 namespace sfo {

@@ -118,6 +118,7 @@ SIGNATURES = {
     "predict_from_model_device": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int, _fp, C.POINTER(SfModelParams)]),
     "init_model_from_frame": (C.c_int, [_H, C.c_int, _fp, C.POINTER(SfModelParams), C.c_int, _fp, _ip]),
     "get_prediction": (C.c_int, [_H, C.c_int, _fp, _fp]),
+    "get_prediction_dense": (C.c_int, [_H, _ip]),
     "map_create": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p)]),
     "map_destroy": (None, [C.c_void_p]),
     "map_fuse_frame": (C.c_int, [_H, C.c_int, C.c_void_p, _fp, C.c_float, C.POINTER(SfModelParams)]),
@@ -291,6 +292,12 @@ class Solver:
         n = C.c_int32()
         self.api.check(self.api.init_model_from_frame(self.h, stream, T.ctypes.data_as(_fp), C.byref(p), time, out.ctypes.data_as(_fp), C.byref(n)))
         return out[: n.value].copy()
+
+    def prediction_dense(self):
+        """Reconstruction::denseEnough of the last prediction (what checkIfDenseEnough reports one frame later)"""
+        d = C.c_int32()
+        self.api.check(self.api.get_prediction_dense(self.h, C.byref(d)))
+        return bool(d.value)
 
     def prediction(self, stream=0):
         """(depthPrediction, intensityPrediction) as (rows, cols) arrays"""

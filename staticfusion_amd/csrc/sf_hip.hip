@@ -911,6 +911,16 @@ int sf_init_model_from_frame(sf_handle *h, int stream, const float pose[16], con
     *count = counts[0];
     return SF_OK;
 }
+int sf_get_prediction_dense(sf_handle *h, int *dense) {
+    if (!h || !dense) return fail(SF_ERR_ARG, "null");
+    *dense = 0;
+    if (!h->pr_key_low) return SF_OK;  // nothing rendered yet
+    int sum = 0;
+    if (int e = d2h(h, &sum, h->pr_dense, sizeof sum)) return e;
+    const int rw = h->k.cols / 40, rh = h->k.rows / 40;
+    *dense = (rw * rh > 0) && (float(sum) / float(rh * rw) > 0.25f);
+    return SF_OK;
+}
 int sf_get_prediction(sf_handle *h, int stream, float *depth, float *intensity) {
     if (int e = check_stream(h, stream)) return e;
     const size_t bytes = sizeof(float) * h->k.n0;

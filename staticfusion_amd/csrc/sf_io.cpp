@@ -329,3 +329,36 @@ extern "C" int sf_io_trajectory_line(double timestamp, const float pose[16], int
     std::memcpy(buf, line.c_str(), line.size() + 1);
     return (int)line.size();
 }
+
+extern "C" int sf_io_save_ply(const char *path, const float *surfels, int count, float conf_threshold) {
+    if (!path || (!surfels && count > 0) || count < 0) return fail(SF_IO_ERR_ARG, "bad argument");
+    int valid = 0;
+    for (int i = 0; i < count; i++)
+        if (surfels[size_t(i) * 12 + 3] > conf_threshold) valid++;  // Reconstruction.cpp:371-379
+    std::FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(SF_IO_ERR_FILE, std::string("cannot open ") + path);
+    std::ostringstream hd;  // :382-401
+    hd << "ply" << "\nformat " << "binary_little_endian" << " 1.0" << "\nelement vertex " << valid
+       << "\nproperty float x\nproperty float y\nproperty float z"
+       << "\nproperty uchar red\nproperty uchar green\nproperty uchar blue"
+       << "\nproperty float nx\nproperty float ny\nproperty float nz"
+       << "\nproperty float radius" << "\nend_header\n";
+    const std::string h = hd.str();
+    bool ok = std::fwrite(h.data(), 1, h.size(), f) == h.size();
+    for (int i = 0; i < count && ok; i++) {
+        const float *s = surfels + size_t(i) * 12;
+        if (!(s[3] > conf_threshold)) continue;  // :413
+        unsigned char rec[3 * 4 + 3 + 4 * 4];
+        std::memcpy(rec, s, 12);  // x y z
+        const int col = int(s[4]);  // :432-434
+        rec[12] = (unsigned char)(col >> 16 & 0xFF);
+        rec[13] = (unsigned char)(col >> 8 & 0xFF);
+        rec[14] = (unsigned char)(col & 0xFF);
+        const float n[4] = {s[8] * -1.f, s[9] * -1.f, s[10] * -1.f, s[11]};  // :418-420, radius unchanged
+        std::memcpy(rec + 15, n, 16);
+        ok = std::fwrite(rec, 1, sizeof rec, f) == sizeof rec;
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) return fail(SF_IO_ERR_FILE, std::string("write failed: ") + path);
+    return valid;
+}

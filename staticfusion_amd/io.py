@@ -20,6 +20,7 @@ SIGNATURES = {
     "sf_io_free": (None, [C.c_void_p]),
     "sf_io_pose_compose": (None, [C.POINTER(C.c_float)] * 3),
     "sf_io_trajectory_line": (C.c_int, [C.c_double, C.POINTER(C.c_float), C.c_int, C.c_char_p, C.c_size_t]),
+    "sf_io_save_ply": (C.c_int, [C.c_char_p, C.POINTER(C.c_float), C.c_int, C.c_float]),
     "sf_io_last_error": (C.c_char_p, []),
 }
 
@@ -90,3 +91,8 @@ class Io:
         buf = C.create_string_buffer(256)
         self._check(self.lib.sf_io_trajectory_line(timestamp, a.ctypes.data_as(C.POINTER(C.c_float)), int(rotate_by_z), buf, 256))
         return buf.value.decode()
+
+    def save_ply(self, path, surfels, conf_threshold):
+        """Reconstruction::savePly's point cloud: the surfels above conf_threshold; returns the vertex count"""
+        s = np.ascontiguousarray(surfels, dtype=np.float32).reshape(-1, 12)
+        return self._check(self.lib.sf_io_save_ply(os.fsencode(path), s.ctypes.data_as(C.POINTER(C.c_float)), s.shape[0], conf_threshold))

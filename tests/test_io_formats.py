@@ -343,3 +343,54 @@ def test_sequence_runner_fusion_mode_hip_vs_oracle(hip, ora, lib, tmp_path):
     print("free-running HIP vs oracle after 9 frames", free, "; error vs ground truth: fused map", err_map, "oracle", err_gt_o, "frame-to-frame", err_frame)
     assert free[0] < 1e-3 and free[1] < 2e-3, free
     assert err_map[0] < 1e-2 and err_map[1] < 3e-2, err_map
+
+
+def build_headless(tmp_path):
+    import subprocess
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    libdir = os.path.join(root, "staticfusion_amd", "csrc")
+    exe = str(tmp_path / "staticfusion_headless")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "staticfusion_headless.cpp"),
+                           "-o", exe, "-L" + libdir, "-lsf_hip", "-lsf_io", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_headless_example_builds(tmp_path):
+    assert os.path.exists(build_headless(tmp_path))
+
+
+def test_ply_writer_matches_the_restatement(lib, tmp_path):
+    """Reconstruction::savePly (Reconstruction.cpp:358-455): header text, confidence gate, colour decode, negated normals"""
+    rng = np.random.default_rng(3)
+    s = rng.normal(size=(2000, 12)).astype(np.float32)
+    s[:, 3] = rng.uniform(0, 1, 2000)
+    s[:, 4] = rng.integers(0, 1 << 24, 2000)
+    s[7, 3] = np.float32(0.25)  # not above the threshold
+    path = str(tmp_path / "map.ply")
+    n = lib.save_ply(path, s, 0.25)
+    data = open(path, "rb").read()
+    assert n == int((s[:, 3] > np.float32(0.25)).sum()) and data == io_oracle.save_ply_bytes(s, 0.25)
+    assert data.startswith(b"ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\n" % n)
+    assert len(data) == data.index(b"end_header\n") + 11 + n * 31
+    assert lib.save_ply(str(tmp_path / "empty.ply"), np.zeros((0, 12), np.float32), 0.25) == 0
+
+
+@pytest.mark.gpu
+def test_headless_example_is_the_python_fusion_loop(hip, lib, tmp_path):
+    """examples/staticfusion_headless.cpp (the reference's full image-sequence loop over StaticFusionCompat +
+    ReconstructionCompat) writes the trajectory of tools/run_sequence.py --mode fusion and the PLY of its final map."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from run_sequence import run
+
+    root = str(tmp_path / "ds")
+    write_dataset(root, 8)
+    exe = build_headless(tmp_path)
+    prefix = str(tmp_path / "out")
+    msg = subprocess.check_output([exe, root, prefix]).decode()
+    _, lines, s = run(hip, lib, root, mode="fusion")
+    assert open(prefix + ".freiburg").read() == "".join(lines), msg
+    assert open(prefix + ".ply", "rb").read() == io_oracle.save_ply_bytes(s.map.download(), 0.25), msg
+    assert "8 frames" in msg

@@ -295,6 +295,14 @@ void SF_FN(map_destroy)(sf_map *m);
 int SF_FN(map_fuse_frame)(sf_handle *h, int stream, sf_map *m, const float *in_pose, float weight_multiplier, const sf_model_params *p);
 /* Reconstruction::getPredictedImages at the map's currPose and tick: sf_predict_from_model_device on the map's buffer. */
 int SF_FN(map_predict)(sf_handle *h, int stream, sf_map *m, const sf_model_params *p);
+/* The two calls above for n (stream, map) pairs at once -- the many-sequences-per-GPU form: every kernel of the pass is
+ * launched ONCE for the whole batch (grid.y = pair) and the results come back in one read. streams[q] is fused into /
+ * predicted from maps[q]; in_poses = n x 16 floats (column-major 4x4 each; NULL only if every map is at tick 1). The maps
+ * of a batch must be distinct (predict: the streams too). Results are identical to n single calls. On overflow the other
+ * maps of the batch are still fused; the error names the first truncated entry. */
+int SF_FN(map_fuse_frames)(sf_handle *h, int n, const int *streams, sf_map *const *maps, const float *in_poses, float weight_multiplier,
+                           const sf_model_params *p);
+int SF_FN(map_predict_frames)(sf_handle *h, int n, const int *streams, sf_map *const *maps, const sf_model_params *p);
 /* lastCount(), tick, currPose and the counters of the last fuse: stats[0] points emitted by the data pass, [1] of those
  * associated with a model surfel, [2] distinct surfels merged, [3] surfels after clean. Any pointer may be NULL. */
 int SF_FN(map_info)(sf_map *m, int *count, int *tick, float pose[16], int stats[4]);

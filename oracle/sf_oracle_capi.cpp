@@ -608,6 +608,32 @@ int sfo_map_predict(sf_handle *h, int stream, sf_map *m, const sf_model_params *
     q.time = q.max_time = m->m.tick;
     return sfo_predict_from_model(h, stream, m->m.surfels.data(), m->m.count, m->m.pose, &q);
 }
+int sfo_map_fuse_frames(sf_handle *h, int n, const int *streams, sf_map *const *maps, const float *in_poses, float weight_multiplier,
+                        const sf_model_params *p) {
+    if (!h || n < 0 || (n && (!streams || !maps)) || !p) return fail(SF_ERR_ARG, "bad argument");
+    for (int q = 0; q < n; q++) {
+        if (!maps[q] || maps[q]->h != h) return fail(SF_ERR_ARG, "a map belongs to the handle it was created from");
+        if (!in_poses && maps[q]->m.tick != 1) return fail(SF_ERR_ARG, "in_pose may be NULL on the first fuse only");
+        for (int r = 0; r < q; r++)
+            if (maps[r] == maps[q]) return fail(SF_ERR_ARG, "the same map twice in one batch");
+    }
+    int first_error = SF_OK;
+    for (int q = 0; q < n; q++) {
+        const int e = sfo_map_fuse_frame(h, streams[q], maps[q], in_poses ? in_poses + size_t(q) * 16 : nullptr, weight_multiplier, p);
+        if (e == SF_ERR_STATE && first_error == SF_OK) first_error = e;  // truncated: the rest of the batch is still fused
+        else if (e != SF_OK && e != SF_ERR_STATE) return e;
+    }
+    return first_error == SF_OK ? SF_OK : fail(first_error, "surfel map capacity exceeded (truncated)");
+}
+int sfo_map_predict_frames(sf_handle *h, int n, const int *streams, sf_map *const *maps, const sf_model_params *p) {
+    if (!h || n < 0 || (n && (!streams || !maps)) || !p) return fail(SF_ERR_ARG, "bad argument");
+    for (int q = 0; q < n; q++)
+        for (int r = 0; r < q; r++)
+            if (streams[r] == streams[q]) return fail(SF_ERR_ARG, "the same stream twice in one batch (its prediction would be written twice)");
+    for (int q = 0; q < n; q++)
+        if (int e = sfo_map_predict(h, streams[q], maps[q], p)) return e;
+    return SF_OK;
+}
 int sfo_map_info(sf_map *m, int *count, int *tick, float pose[16], int stats[4]) {
     if (!m) return fail(SF_ERR_ARG, "null");
     if (count) *count = m->m.count;

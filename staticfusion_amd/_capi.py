@@ -123,6 +123,8 @@ SIGNATURES = {
     "map_destroy": (None, [C.c_void_p]),
     "map_fuse_frame": (C.c_int, [_H, C.c_int, C.c_void_p, _fp, C.c_float, C.POINTER(SfModelParams)]),
     "map_predict": (C.c_int, [_H, C.c_int, C.c_void_p, C.POINTER(SfModelParams)]),
+    "map_fuse_frames": (C.c_int, [_H, C.c_int, _ip, C.POINTER(C.c_void_p), _fp, C.c_float, C.POINTER(SfModelParams)]),
+    "map_predict_frames": (C.c_int, [_H, C.c_int, _ip, C.POINTER(C.c_void_p), C.POINTER(SfModelParams)]),
     "map_info": (C.c_int, [C.c_void_p, _ip, _ip, _fp, _ip]),
     "map_download": (C.c_int, [C.c_void_p, _fp, C.c_int]),
     "map_upload": (C.c_int, [C.c_void_p, _fp, C.c_int, _fp, C.c_int]),
@@ -484,6 +486,26 @@ class SurfelMap:
     def predict(self, stream, params=None):
         p = params if params is not None else self.solver.default_model_params()
         self.api.check(self.api.map_predict(self.solver.h, stream, self.m, C.byref(p)))
+
+    @staticmethod
+    def _batch(streams, maps):
+        n = len(maps)
+        assert len(streams) == n
+        return n, (C.c_int32 * n)(*streams), (C.c_void_p * n)(*[m.m.value for m in maps])
+
+    @staticmethod
+    def fuse_frames(solver, streams, maps, in_poses, weight_multiplier=1.0, params=None):
+        """sf_map_fuse_frames: streams[q] into maps[q]; in_poses: list of 4x4 (row, col) or None (all maps at tick 1)"""
+        p = params if params is not None else solver.default_model_params()
+        n, s, m = SurfelMap._batch(streams, maps)
+        T = None if in_poses is None else np.ascontiguousarray(np.stack([np.asarray(t, np.float32).T for t in in_poses]))
+        solver.api.check(solver.api.map_fuse_frames(solver.h, n, s, m, None if T is None else T.ctypes.data_as(_fp), weight_multiplier, C.byref(p)))
+
+    @staticmethod
+    def predict_frames(solver, streams, maps, params=None):
+        p = params if params is not None else solver.default_model_params()
+        n, s, m = SurfelMap._batch(streams, maps)
+        solver.api.check(solver.api.map_predict_frames(solver.h, n, s, m, C.byref(p)))
 
     def info(self):
         """dict(count, tick, pose (4x4 row, col), stats)"""

@@ -51,7 +51,10 @@ struct FuseArgs {
     unsigned char *flags;  // [count + n_cand]
     int *block_counts;     // [ceil((count + n_cand) / SF_CLEAN_BLOCK)]  (becomes the exclusive offsets)
     int *result;           // [0] count after clean (clamped), [1] unclamped, [2] emitted, [3] associated, [4] merged surfels
+    float *out;            // where clean writes the map back (= the buffer src points to)
 };
+// Every kernel takes a TABLE of FuseArgs and works on entry blockIdx.y: one launch serves the maps of many streams
+// (sf_map_fuse_frames); grid.x is sized for the largest map, workgroups beyond a map's own extent leave at once.
 
 __device__ __forceinline__ float gl_minf(float x, float y) { return y < x ? y : x; }
 __device__ __forceinline__ float gl_maxf(float x, float y) { return x < y ? y : x; }
@@ -77,21 +80,25 @@ __device__ __forceinline__ PV3 decode_color3(float c) {
     return {float((k >> 16) & 0xFF) / 255.0f, float((k >> 8) & 0xFF) / 255.0f, float(k & 0xFF) / 255.0f};
 }
 // ---- IndexMap::predictIndices -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sf_index_clear_kernel(unsigned long long *keys, size_t n) {
+__global__ __launch_bounds__(256) void sf_index_clear_kernel(const FuseArgs *tab) {
+    const FuseArgs &a = tab[blockIdx.y];
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (o < n) keys[o] = SF_PRED_EMPTY;
+    if (o < (size_t)a.rows * a.cols * 16) a.keys[o] = SF_PRED_EMPTY;
 }
 // start of a fuse: clear the index image, the update-map winners and the counters in one launch
-__global__ __launch_bounds__(256) void sf_fuse_begin_kernel(unsigned long long *keys, size_t n_keys, unsigned *winner, int count, int *result) {
+__global__ __launch_bounds__(256) void sf_fuse_begin_kernel(const FuseArgs *tab) {
+    const FuseArgs &a = tab[blockIdx.y];
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (o < n_keys) keys[o] = SF_PRED_EMPTY;
-    if (o < (size_t)count) winner[o] = SF_FUSE_NONE;
-    if (o < 8) result[o] = 0;
+    if (o < (size_t)a.rows * a.cols * 16) a.keys[o] = SF_PRED_EMPTY;
+    if (o < (size_t)a.count) a.winner[o] = SF_FUSE_NONE;
+    if (o < 8) a.result[o] = 0;
 }
 // surfels: the buffer the index image is rendered from (src before the merge, dst after it)
-__global__ __launch_bounds__(256) void sf_index_splat_kernel(FuseArgs a, const float *surfels) {
+__global__ __launch_bounds__(256) void sf_index_splat_kernel(const FuseArgs *tab, int merged) {
+    const FuseArgs &a = tab[blockIdx.y];
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= a.count) return;
+    const float *surfels = merged ? a.dst : a.src;
     const float *q = surfels + (size_t)s * 12;
     const PV3 h = xform3(a.t_inv, PV3{q[0], q[1], q[2]});                                       // index_map.vert:38
     if (h.z > a.max_depth || h.z < 0.f || float(a.time) - q[7] > float(a.time_delta)) return;   // :43-48
@@ -107,11 +114,14 @@ __global__ __launch_bounds__(256) void sf_index_splat_kernel(FuseArgs a, const f
     if (!(fx_ >= 0.f && fx_ < float(W4) && fy_ >= 0.f && fy_ < float(H4))) return;
     const float depth = ndc_z * 0.5f + 0.5f;
     const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned)s;
-    atomicMin(a.keys + (size_t)int(fy_) * W4 + int(fx_), key);
+    atomicMin(a.keys + (size_t)int(fx_) * H4 + int(fy_), key);  // column-major key image
 }
-__global__ __launch_bounds__(256) void sf_index_export_kernel(const unsigned long long *keys, unsigned *out, size_t n) {
+__global__ __launch_bounds__(256) void sf_index_export_kernel(const unsigned long long *keys, unsigned *out, int W4, int H4) {  // -> row-major
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (o < n) out[o] = keys[o] == SF_PRED_EMPTY ? 0u : (unsigned)(keys[o] & 0xffffffffull);
+    if (o >= (size_t)W4 * H4) return;
+    const int tv = (int)(o / W4), tu = (int)(o - (size_t)tv * W4);
+    const unsigned long long key = keys[(size_t)tu * H4 + tv];
+    out[o] = key == SF_PRED_EMPTY ? 0u : (unsigned)(key & 0xffffffffull);
 }
 
 // what the index image's other three textures hold for surfel idx (index_map.vert:56-59)
@@ -135,7 +145,8 @@ __device__ __forceinline__ PV3 index_texel_normal(const FuseArgs &a, const float
 }
 
 // ---- GlobalModel::fuse, data association (data.vert) --------------------------------------------------------------
-__global__ __launch_bounds__(64) void sf_fuse_data_kernel(FuseArgs a) {  // 64: 19 200 candidates at QVGA are 300 single-wave workgroups, one per CU
+__global__ __launch_bounds__(64) void sf_fuse_data_kernel(const FuseArgs *tab) {  // 64: 19 200 candidates at QVGA are 300 single-wave workgroups
+    const FuseArgs &a = tab[blockIdx.y];
     const int q = blockIdx.x * 64 + threadIdx.x;
     if (q >= a.n_cand) return;
     const int ic = q / a.cand_rows, jc = q - ic * a.cand_rows;
@@ -186,18 +197,21 @@ __global__ __launch_bounds__(64) void sf_fuse_data_kernel(FuseArgs a) {  // 64: 
         // The window steps its texture coordinate in HALF texels (data.vert:133-135): consecutive samples often read the
         // same texel. The texel sequence of each axis is non-decreasing, a repeated texel offers the same candidate at the
         // same distance, and only a STRICTLY nearer one replaces the best: repeats are skipped, the result is unchanged.
+        // The key image is stored COLUMN-major: the inner (v) loop of a lane walks consecutive keys, and neighbouring
+        // lanes -- vertically neighbouring pixels, the order of the reference's point list -- read neighbouring keys.
         const int W4 = cols * 4, H4 = rows * 4;
         int prev_tu = -1;
         for (float u = tx - (scale * indexXStep * windowMultiplier); u < tx + (scale * indexXStep * windowMultiplier); u += indexXStep) {
             const int tu = nearest_texel(u, W4);
             if (tu == prev_tu) continue;
             prev_tu = tu;
+            const unsigned long long *col = a.keys + (size_t)tu * H4;
             int prev_tv = -1;
             for (float v = ty - (scale * indexYStep * windowMultiplier); v < ty + (scale * indexYStep * windowMultiplier); v += indexYStep) {
                 const int tv = nearest_texel(v, H4);
                 if (tv == prev_tv) continue;
                 prev_tv = tv;
-                const unsigned long long key = a.keys[(size_t)tv * W4 + tu];
+                const unsigned long long key = col[tv];
                 const unsigned current = key == SF_PRED_EMPTY ? 0u : (unsigned)(key & 0xffffffffull);
                 if (current > 0U) {
                     const IndexTexelD t = index_texel_pos(a, a.src, current);
@@ -246,7 +260,8 @@ __global__ __launch_bounds__(64) void sf_fuse_data_kernel(FuseArgs a) {  // 64: 
 }
 
 // ---- GlobalModel::fuse, merge (update.vert): src -> dst for every model surfel ----------------------------------
-__global__ __launch_bounds__(256) void sf_fuse_update_kernel(FuseArgs a) {
+__global__ __launch_bounds__(256) void sf_fuse_update_kernel(const FuseArgs *tab) {
+    const FuseArgs &a = tab[blockIdx.y];
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= a.count) return;
     const float *q = a.src + (size_t)s * 12;
@@ -307,10 +322,12 @@ __device__ __forceinline__ const float *clean_element(const FuseArgs &a, int e, 
     return a.rec + (size_t)q * 12;
 }
 #define SF_CLEAN_BLOCK 256  // compaction granule: small, so that a QVGA map (93 k elements) still covers the 256 CUs
-__global__ __launch_bounds__(SF_CLEAN_BLOCK) void sf_clean_flag_kernel(FuseArgs a) {
+__global__ __launch_bounds__(SF_CLEAN_BLOCK) void sf_clean_flag_kernel(const FuseArgs *tab) {
     __shared__ int block_total;
+    const FuseArgs &a = tab[blockIdx.y];
     const int e = blockIdx.x * SF_CLEAN_BLOCK + threadIdx.x;
     const int n = a.count + a.n_cand;
+    if ((int)blockIdx.x * SF_CLEAN_BLOCK >= n) return;  // a workgroup of a larger map of the batch
     if (threadIdx.x == 0) block_total = 0;
     __syncthreads();
     bool keep = false;
@@ -331,11 +348,16 @@ __global__ __launch_bounds__(SF_CLEAN_BLOCK) void sf_clean_flag_kernel(FuseArgs 
             const float ftime = float(a.time), fdelta = float(a.time_delta);
             const float conf_v = q[3], t_init_v = q[6], rad_v = q[11];
             float t_last_v = q[7];
-            if (ftime - t_last_v < fdelta && localPos.z > 0.f && x > 0.f && y > 0.f && x < W && y < H) {
+            // :108-116 decide without the window for merged candidates (w == -1), zero-confidence points and stale unstable
+            // surfels: whatever the two counts say, the vertex is dropped (unless the time-window override keeps it) -- skip the scan
+            const float t_fixed = t_last_v == -2.f ? ftime : t_last_v;
+            const bool dropped_anyway = (t_fixed == -1.f || ((ftime - t_fixed) > 10.f && conf_v < 0.5f)) || (conf_v == 0.0f);
+            const bool kept_anyway = t_fixed > 0.f && ftime - t_fixed > fdelta;
+            if (!dropped_anyway && !kept_anyway && ftime - t_last_v < fdelta && localPos.z > 0.f && x > 0.f && y > 0.f && x < W && y < H) {
                 // half-texel steps (copy_unstable.vert:62-64): a texel read m_u x m_v times counts m_u x m_v times; evaluate it once
                 const int W4 = a.cols * 4, H4 = a.rows * 4;
                 auto eval = [&](int tu, int tv, int mult) {
-                    const unsigned long long key = a.keys[(size_t)tv * W4 + tu];
+                    const unsigned long long key = a.keys[(size_t)tu * H4 + tv];
                     const unsigned current = key == SF_PRED_EMPTY ? 0u : (unsigned)(key & 0xffffffffull);
                     if (current > 0U) {
                         const IndexTexelD t = index_texel_pos(a, a.dst, current);
@@ -346,7 +368,7 @@ __global__ __launch_bounds__(SF_CLEAN_BLOCK) void sf_clean_flag_kernel(FuseArgs 
                         if (t.t_last == ftime && t.conf > 0.4f * a.conf_threshold && t.pos.z > localPos.z && t.pos.z - localPos.z > 0.01f) zCount += mult;
                     }
                 };
-                auto column = [&](int tu, int mu) {
+                auto column = [&](int tu, int mu) {  // the key image is column-major: consecutive keys
                     int prev_tv = -1, mv = 0;
                     for (float v = y / H - (scale * indexYStep * windowMultiplier); v < y / H + (scale * indexYStep * windowMultiplier); v += indexYStep) {
                         const int tv = nearest_texel(v, H4);
@@ -385,9 +407,11 @@ __global__ __launch_bounds__(SF_CLEAN_BLOCK) void sf_clean_flag_kernel(FuseArgs 
     if (threadIdx.x == 0) a.block_counts[blockIdx.x] = block_total;
 }
 // exclusive scan of the block counts in place (one workgroup), totals into result[0..1]
-__global__ __launch_bounds__(1024) void sf_clean_scan_kernel(FuseArgs a, int n_blocks) {
+__global__ __launch_bounds__(1024) void sf_clean_scan_kernel(const FuseArgs *tab) {
     __shared__ int wsum[16];
     __shared__ int base;
+    const FuseArgs &a = tab[blockIdx.x];  // one workgroup per map
+    const int n_blocks = (a.count + a.n_cand + SF_CLEAN_BLOCK - 1) / SF_CLEAN_BLOCK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) base = 0;
     __syncthreads();
@@ -418,11 +442,14 @@ __global__ __launch_bounds__(1024) void sf_clean_scan_kernel(FuseArgs a, int n_b
     }
 }
 // ordered scatter into src (the buffer the merged model was NOT written to becomes the map again)
-__global__ __launch_bounds__(SF_CLEAN_BLOCK) void sf_clean_write_kernel(FuseArgs a, float *out) {
+__global__ __launch_bounds__(SF_CLEAN_BLOCK) void sf_clean_write_kernel(const FuseArgs *tab) {
     __shared__ int wcount[SF_CLEAN_BLOCK / 64];
+    const FuseArgs &a = tab[blockIdx.y];
+    float *out = a.out;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e = blockIdx.x * SF_CLEAN_BLOCK + tid;
     const int n = a.count + a.n_cand;
+    if ((int)blockIdx.x * SF_CLEAN_BLOCK >= n) return;
     const bool keep = e < n && a.flags[e] != 0;
     const unsigned long long m = __ballot(keep);
     if (lane == 0) wcount[wave] = (int)__popcll(m);

@@ -64,10 +64,18 @@ struct sf_handle {
     uint16_t *stage_depth = nullptr;
     size_t stage_px = 0;
     // model prediction (sf_predict.h), allocated by the first sf_predict_from_model
-    unsigned long long *pr_key_low = nullptr, *pr_key_high = nullptr;
-    int *pr_dense = nullptr;
+    unsigned long long *pr_keys = nullptr;  // per batched map: low and high key image (2 x n0)
+    int *pr_dense = nullptr;                // per batched map: 2 ints (density sum; init-model counts)
+    size_t pr_maps = 0;                     // how many maps the two blocks above are sized for
+    bool pr_rendered = false;
     float *pr_surfels = nullptr;
     size_t pr_capacity = 0;
+    // argument tables of the batched map kernels (sf_predict.h, sf_fusion.h): device block + the host copy it is filled from
+    void *tab_dev = nullptr;
+    size_t tab_bytes = 0;
+    std::vector<unsigned char> tab_host;
+    int *res_dev = nullptr;                 // per batched map: 8 ints of results
+    size_t res_maps = 0;
     // overlapped host -> HBM upload of the next frames (sf_upload_current_async): copy stream, staging, event
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_done = nullptr, compute_done = nullptr;
@@ -825,35 +833,80 @@ static void invert_pose(const float pose[16], float out[16]) {
     for (int r = 0; r < 4; r++)
         for (int c = 0; c < 4; c++) out[r + 4 * c] = float(Ai[r * 4 + c]);
 }
-static int predict_launch(sf_handle *h, int stream, const float *d_surfels, int count, const float pose[16], const sf_model_params *p) {
-    const size_t n = h->k.n0;
-    if (!h->pr_key_low) {
-        if (int e = dev_alloc(h, &h->pr_key_low, n)) return e;
-        if (int e = dev_alloc(h, &h->pr_key_high, n)) return e;
-        if (int e = dev_alloc(h, &h->pr_dense, 2)) return e;
+// device table for a batched launch: grows on demand, filled from a host copy that lives in the handle
+static int upload_table(sf_handle *h, const void *src, size_t bytes, void **dev) {
+    if (h->tab_bytes < bytes) {
+        unsigned char *q = nullptr;
+        if (int e = dev_alloc(h, &q, bytes * 2)) return e;  // the old block is freed with the handle
+        h->tab_dev = q;
+        h->tab_bytes = bytes * 2;
     }
-    PredictArgs a;
-    a.surfels = d_surfels;
-    a.count = count;
-    invert_pose(pose, a.t_inv);  // t_inv = pose.inverse() (IndexMap.cpp:251)
-    a.cx = p->cx; a.cy = p->cy; a.fx = p->fx; a.fy = p->fy;
-    a.max_depth = p->max_depth; a.conf_low = p->conf_low; a.conf_high = p->conf_high; a.extract_max_depth = p->extract_max_depth;
-    a.time = p->time; a.max_time = p->max_time; a.time_delta = p->time_delta;
-    a.rows = h->k.rows; a.cols = h->k.cols;
-    a.key_low = h->pr_key_low; a.key_high = h->pr_key_high; a.dense_count = h->pr_dense;
-    a.filtered_mm = h->in_filtered_mm + (size_t)stream * n;
-    a.color = h->in_color + (size_t)stream * n * 3;
-    a.b_img = h->k.b_img + (size_t)stream * n;
-    a.depth_pred = h->k.pyr_pred[0] + (size_t)stream * h->k.n_tot;
-    a.inten_pred = h->k.pyr_pred[1] + (size_t)stream * h->k.n_tot;
-    if (!(a.conf_low <= a.conf_high)) return fail(SF_ERR_ARG, "conf_low must not exceed conf_high");
-    const int pix_blocks = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(sf_predict_clear_kernel, dim3(pix_blocks), dim3(256), 0, h->stream, a);
-    if (count) hipLaunchKernelGGL(sf_predict_splat_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, a);
-    hipLaunchKernelGGL(sf_predict_dense_kernel, dim3(1), dim3(64), 0, h->stream, a);
-    hipLaunchKernelGGL(sf_predict_resolve_kernel, dim3(pix_blocks), dim3(256), 0, h->stream, a);
-    HIP_TRY(hipGetLastError());
+    h->tab_host.assign((const unsigned char *)src, (const unsigned char *)src + bytes);
+    HIP_TRY(hipMemcpyAsync(h->tab_dev, h->tab_host.data(), bytes, hipMemcpyHostToDevice, h->stream));
+    *dev = h->tab_dev;
     return SF_OK;
+}
+static int predict_scratch(sf_handle *h, size_t n_maps) {
+    if (h->pr_maps >= n_maps) return SF_OK;
+    if (int e = dev_alloc(h, &h->pr_keys, n_maps * 2 * h->k.n0)) return e;
+    if (int e = dev_alloc(h, &h->pr_dense, n_maps * 2)) return e;
+    h->pr_maps = n_maps;
+    return SF_OK;
+}
+static int results_scratch(sf_handle *h, size_t n_maps) {
+    if (h->res_maps >= n_maps) return SF_OK;
+    if (int e = dev_alloc(h, &h->res_dev, n_maps * 8)) return e;
+    h->res_maps = n_maps;
+    return SF_OK;
+}
+struct PredictJob {
+    int stream;
+    const float *d_surfels;
+    int count;
+    const float *pose;
+    int time, max_time;
+};
+// Reconstruction::getPredictedImages for n (stream, surfel buffer, pose) triples in four launches
+static int predict_batch(sf_handle *h, const std::vector<PredictJob> &jobs, const sf_model_params *p) {
+    const size_t n = h->k.n0;
+    if (!(p->conf_low <= p->conf_high)) return fail(SF_ERR_ARG, "conf_low must not exceed conf_high");
+    if (jobs.empty()) return SF_OK;
+    if (int e = predict_scratch(h, jobs.size())) return e;
+    std::vector<PredictArgs> tab(jobs.size());
+    int max_count = 0;
+    for (size_t q = 0; q < jobs.size(); q++) {
+        const PredictJob &j = jobs[q];
+        PredictArgs &a = tab[q];
+        a.surfels = j.d_surfels;
+        a.count = j.count;
+        max_count = std::max(max_count, j.count);
+        invert_pose(j.pose, a.t_inv);  // t_inv = pose.inverse() (IndexMap.cpp:251)
+        a.cx = p->cx; a.cy = p->cy; a.fx = p->fx; a.fy = p->fy;
+        a.max_depth = p->max_depth; a.conf_low = p->conf_low; a.conf_high = p->conf_high; a.extract_max_depth = p->extract_max_depth;
+        a.time = j.time; a.max_time = j.max_time; a.time_delta = p->time_delta;
+        a.rows = h->k.rows; a.cols = h->k.cols;
+        a.key_low = h->pr_keys + q * 2 * n; a.key_high = a.key_low + n; a.dense_count = h->pr_dense + q * 2;
+        a.filtered_mm = h->in_filtered_mm + (size_t)j.stream * n;
+        a.color = h->in_color + (size_t)j.stream * n * 3;
+        a.b_img = h->k.b_img + (size_t)j.stream * n;
+        a.depth_pred = h->k.pyr_pred[0] + (size_t)j.stream * h->k.n_tot;
+        a.inten_pred = h->k.pyr_pred[1] + (size_t)j.stream * h->k.n_tot;
+    }
+    void *dev = nullptr;
+    if (int e = upload_table(h, tab.data(), tab.size() * sizeof(PredictArgs), &dev)) return e;
+    const PredictArgs *d_tab = (const PredictArgs *)dev;
+    const unsigned nm = (unsigned)jobs.size();
+    const unsigned pix_blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(sf_predict_clear_kernel, dim3(pix_blocks, nm), dim3(256), 0, h->stream, d_tab);
+    if (max_count) hipLaunchKernelGGL(sf_predict_splat_kernel, dim3((max_count + 255) / 256, nm), dim3(256), 0, h->stream, d_tab);
+    hipLaunchKernelGGL(sf_predict_dense_kernel, dim3(nm), dim3(64), 0, h->stream, d_tab);
+    hipLaunchKernelGGL(sf_predict_resolve_kernel, dim3(pix_blocks, nm), dim3(256), 0, h->stream, d_tab);
+    HIP_TRY(hipGetLastError());
+    h->pr_rendered = true;
+    return SF_OK;
+}
+static int predict_launch(sf_handle *h, int stream, const float *d_surfels, int count, const float pose[16], const sf_model_params *p) {
+    return predict_batch(h, std::vector<PredictJob>{PredictJob{stream, d_surfels, count, pose, p->time, p->max_time}}, p);
 }
 int sf_predict_from_model(sf_handle *h, int stream, const float *surfels, int count, const float pose[16], const sf_model_params *p) {
     if (int e = check_stream(h, stream)) return e;
@@ -877,6 +930,21 @@ int sf_predict_from_model_device(sf_handle *h, int stream, const void *d_surfels
     if (int e = input_alloc(h)) return e;
     return predict_launch(h, stream, (const float *)d_surfels, count, pose, p);
 }
+// GlobalModel::initialise for n maps: zero-fill (the feedback buffers start zero-filled), the two ordered compactions, trim
+static void init_model_launch(sf_handle *h, const InitModelArgs *d_tab, int n_maps);
+static int init_model_batch(sf_handle *h, const InitModelArgs *args, int n_maps) {
+    void *dev = nullptr;
+    if (int e = upload_table(h, args, (size_t)n_maps * sizeof(InitModelArgs), &dev)) return e;
+    init_model_launch(h, (const InitModelArgs *)dev, n_maps);
+    HIP_TRY(hipGetLastError());
+    return SF_OK;
+}
+static void init_model_launch(sf_handle *h, const InitModelArgs *d_tab, int n_maps) {
+    const unsigned blocks = (unsigned)((h->k.n0 * 12 + 255) / 256);
+    hipLaunchKernelGGL(sf_init_model_zero_kernel, dim3(blocks, n_maps), dim3(256), 0, h->stream, d_tab);
+    hipLaunchKernelGGL(sf_init_model_kernel, dim3(n_maps), dim3(1024), 0, h->stream, d_tab);
+    hipLaunchKernelGGL(sf_init_model_trim_kernel, dim3(blocks, n_maps), dim3(256), 0, h->stream, d_tab);
+}
 int sf_init_model_from_frame(sf_handle *h, int stream, const float pose[16], const sf_model_params *p, int time, float *surfels_out,
                              int *count) {
     if (int e = check_stream(h, stream)) return e;
@@ -888,9 +956,7 @@ int sf_init_model_from_frame(sf_handle *h, int stream, const float pose[16], con
         if (int e = dev_alloc(h, &h->pr_surfels, n * 12)) return e;
         h->pr_capacity = n;
     }
-    if (!h->pr_dense)
-        if (int e = dev_alloc(h, &h->pr_dense, 2)) return e;
-    HIP_TRY(hipMemsetAsync(h->pr_surfels, 0, n * 12 * sizeof(float), h->stream));  // the feedback buffers start zero-filled
+    if (int e = results_scratch(h, 1)) return e;
     InitModelArgs a;
     a.depth_metric = h->in_depth_metric + (size_t)stream * n;
     a.depth_filtered = h->k.pyr_new[0] + (size_t)stream * h->k.n_tot;
@@ -900,13 +966,10 @@ int sf_init_model_from_frame(sf_handle *h, int stream, const float pose[16], con
     for (int q = 0; q < 16; q++) a.pose[q] = pose[q];
     a.cx = p->cx; a.cy = p->cy; a.fx = p->fx; a.fy = p->fy; a.max_depth = p->max_depth;
     a.out = h->pr_surfels;
-    a.count = h->pr_dense;
-    hipLaunchKernelGGL(sf_init_model_kernel, dim3(1), dim3(1024), 0, h->stream, a);
-    hipLaunchKernelGGL(sf_init_model_trim_kernel, dim3((unsigned)((n * 12 + 255) / 256)), dim3(256), 0, h->stream, h->pr_surfels,
-                       (const int *)h->pr_dense, (int)n);
-    HIP_TRY(hipGetLastError());
+    a.count = h->res_dev;
+    if (int e = init_model_batch(h, &a, 1)) return e;
     int counts[2] = {0, 0};
-    if (int e = d2h(h, counts, h->pr_dense, sizeof counts)) return e;
+    if (int e = d2h(h, counts, h->res_dev, sizeof counts)) return e;
     if (int e = d2h(h, surfels_out, h->pr_surfels, n * 12 * sizeof(float))) return e;
     *count = counts[0];
     return SF_OK;
@@ -914,7 +977,7 @@ int sf_init_model_from_frame(sf_handle *h, int stream, const float pose[16], con
 int sf_get_prediction_dense(sf_handle *h, int *dense) {
     if (!h || !dense) return fail(SF_ERR_ARG, "null");
     *dense = 0;
-    if (!h->pr_key_low) return SF_OK;  // nothing rendered yet
+    if (!h->pr_rendered) return SF_OK;  // nothing rendered yet
     int sum = 0;
     if (int e = d2h(h, &sum, h->pr_dense, sizeof sum)) return e;
     const int rw = h->k.cols / 40, rh = h->k.rows / 40;
@@ -943,7 +1006,7 @@ struct sf_map {
     unsigned *winner = nullptr, *meta = nullptr, *index_export = nullptr;
     float *rec = nullptr;
     unsigned char *flags = nullptr;
-    int *block_counts = nullptr, *result = nullptr;
+    int *block_counts = nullptr;
     bool have_index = false;
     std::vector<void *> allocs;
 };
@@ -976,7 +1039,6 @@ int sf_map_create(sf_handle *h, int capacity, sf_map **out) {
     if (!e) e = map_alloc(m, &m->meta, n_cand_max * 2);
     if (!e) e = map_alloc(m, &m->flags, cap + n_cand_max);
     if (!e) e = map_alloc(m, &m->block_counts, (cap + n_cand_max + SF_CLEAN_BLOCK - 1) / SF_CLEAN_BLOCK + 1);
-    if (!e) e = map_alloc(m, &m->result, 8);
     if (e) {
         sf_map_destroy(m);
         return e;
@@ -999,95 +1061,145 @@ static void pose_compose(const float *a, const float *b, float *out) {  // Eigen
         }
     std::memcpy(out, r, sizeof r);
 }
-int sf_map_fuse_frame(sf_handle *h, int stream, sf_map *m, const float *in_pose, float weight_multiplier, const sf_model_params *p) {
-    if (int e = check_stream(h, stream)) return e;
-    if (!m || m->h != h || !p) return fail(SF_ERR_ARG, "bad argument");
+// Reconstruction::fuseFrame for n (stream, map) pairs: at most 3 + 9 launches and one read-back for the whole batch
+int sf_map_fuse_frames(sf_handle *h, int n, const int *streams, sf_map *const *maps, const float *in_poses, float weight_multiplier,
+                       const sf_model_params *p) {
+    if (!h || n < 0 || (n && (!streams || !maps)) || !p) return fail(SF_ERR_ARG, "bad argument");
+    if (n == 0) return SF_OK;
     if (!h->have_frame) return fail(SF_ERR_STATE, "sf_map_fuse_frame needs a loaded frame (sf_load_frame + sf_filter_depth)");
-    if (!in_pose && m->tick != 1) return fail(SF_ERR_ARG, "in_pose may be NULL on the first fuse only");
+    for (int q = 0; q < n; q++) {
+        if (int e = check_stream(h, streams[q])) return e;
+        if (!maps[q] || maps[q]->h != h) return fail(SF_ERR_ARG, "a map belongs to the handle it was created from");
+        if (!in_poses && maps[q]->tick != 1) return fail(SF_ERR_ARG, "in_pose may be NULL on the first fuse only");
+        for (int r = 0; r < q; r++)
+            if (maps[r] == maps[q]) return fail(SF_ERR_ARG, "the same map twice in one batch");
+    }
     HIP_TRY(hipSetDevice(h->device));
-    const size_t n = h->k.n0;
-    const float *depth_metric = h->in_depth_metric + (size_t)stream * n;
-    const float *depth_filtered = h->k.pyr_new[0] + (size_t)stream * h->k.n_tot;
-    const uint8_t *color = h->in_color + (size_t)stream * n * 3;
-    const float *b_img = h->k.b_img + (size_t)stream * n;
-    if (m->tick == 1) {  // Reconstruction.cpp:255-262
-        if (in_pose) pose_compose(m->pose, in_pose, m->pose);
-        HIP_TRY(hipMemsetAsync(m->buf[0], 0, n * 12 * sizeof(float), h->stream));
-        InitModelArgs a;
+    if (int e = results_scratch(h, (size_t)n)) return e;
+    const size_t npx = h->k.n0;
+    std::vector<InitModelArgs> init;
+    std::vector<FuseArgs> fuse;
+    std::vector<int> init_of, fuse_of;  // batch index of each table entry
+    int max_count = 0, max_cand = 0, max_elems = 0;
+    for (int q = 0; q < n; q++) {
+        sf_map *m = maps[q];
+        const int stream = streams[q];
+        const float *in_pose = in_poses ? in_poses + (size_t)q * 16 : nullptr;
+        const float *depth_metric = h->in_depth_metric + (size_t)stream * npx;
+        const float *depth_filtered = h->k.pyr_new[0] + (size_t)stream * h->k.n_tot;
+        const uint8_t *color = h->in_color + (size_t)stream * npx * 3;
+        const float *b_img = h->k.b_img + (size_t)stream * npx;
+        if (m->tick == 1) {  // Reconstruction.cpp:255-262
+            if (in_pose) pose_compose(m->pose, in_pose, m->pose);
+            InitModelArgs a;
+            a.depth_metric = depth_metric; a.depth_filtered = depth_filtered; a.color = color; a.b_img = b_img;
+            a.rows = h->k.rows; a.cols = h->k.cols; a.time = m->tick;
+            for (int k = 0; k < 16; k++) a.pose[k] = m->pose[k];
+            a.cx = p->cx; a.cy = p->cy; a.fx = p->fx; a.fy = p->fy; a.max_depth = p->max_depth;
+            a.out = m->buf[0];
+            a.count = h->res_dev + (size_t)q * 8;
+            init.push_back(a);
+            init_of.push_back(q);
+            continue;
+        }
+        float last_pose[16];
+        std::memcpy(last_pose, m->pose, sizeof last_pose);
+        pose_compose(m->pose, in_pose, m->pose);                                        // :268
+        FuseArgs a;
         a.depth_metric = depth_metric; a.depth_filtered = depth_filtered; a.color = color; a.b_img = b_img;
-        a.rows = h->k.rows; a.cols = h->k.cols; a.time = m->tick;
-        for (int q = 0; q < 16; q++) a.pose[q] = m->pose[q];
-        a.cx = p->cx; a.cy = p->cy; a.fx = p->fx; a.fy = p->fy; a.max_depth = p->max_depth;
-        a.out = m->buf[0];
-        a.count = m->result;
-        hipLaunchKernelGGL(sf_init_model_kernel, dim3(1), dim3(1024), 0, h->stream, a);
-        hipLaunchKernelGGL(sf_init_model_trim_kernel, dim3((unsigned)((n * 12 + 255) / 256)), dim3(256), 0, h->stream, m->buf[0],
-                           (const int *)m->result, (int)n);
-        HIP_TRY(hipGetLastError());
-        int counts[2] = {0, 0};
-        if (int e = d2h(h, counts, m->result, sizeof counts)) return e;
-        m->count = counts[0];
+        a.rows = h->k.rows; a.cols = h->k.cols;
+        for (int k = 0; k < 16; k++) a.pose[k] = m->pose[k];
+        invert_pose(m->pose, a.t_inv);
+        a.cx = p->cx; a.cy = p->cy; a.fx = p->fx; a.fy = p->fy;
+        a.camz = float(1.0 / double(p->fx)); a.camw = float(1.0 / double(p->fy));       // GlobalModel.cpp:365-368
+        a.max_depth = p->max_depth; a.conf_threshold = p->conf_high;
+        a.weighting = sf_fusion_weighting(last_pose, m->pose, weight_multiplier);        // :270-282
+        a.time = m->tick; a.time_delta = p->time_delta;
+        a.src = m->buf[0]; a.dst = m->buf[1]; a.out = m->buf[0];
+        a.count = m->count; a.capacity = m->capacity;
+        a.keys = m->keys; a.winner = m->winner;
+        a.par = m->tick % 2;
+        a.cand_rows = (a.rows - a.par + 1) / 2; a.cand_cols = (a.cols - a.par + 1) / 2;
+        a.n_cand = a.cand_rows * a.cand_cols;
+        a.rec = m->rec; a.meta = m->meta; a.flags = m->flags; a.block_counts = m->block_counts;
+        a.result = h->res_dev + (size_t)q * 8;
+        max_count = std::max(max_count, a.count);
+        max_cand = std::max(max_cand, a.n_cand);
+        max_elems = std::max(max_elems, a.count + a.n_cand);
+        fuse.push_back(a);
+        fuse_of.push_back(q);
+    }
+    // one upload: [init table | fuse table]
+    const size_t init_bytes = (init.size() * sizeof(InitModelArgs) + 255) / 256 * 256;
+    std::vector<unsigned char> blob(init_bytes + fuse.size() * sizeof(FuseArgs));
+    if (!init.empty()) std::memcpy(blob.data(), init.data(), init.size() * sizeof(InitModelArgs));
+    if (!fuse.empty()) std::memcpy(blob.data() + init_bytes, fuse.data(), fuse.size() * sizeof(FuseArgs));
+    void *dev = nullptr;
+    if (int e = upload_table(h, blob.data(), blob.size(), &dev)) return e;
+    if (!init.empty()) init_model_launch(h, (const InitModelArgs *)dev, (int)init.size());
+    if (!fuse.empty()) {
+        const FuseArgs *tab = (const FuseArgs *)((const unsigned char *)dev + init_bytes);
+        const unsigned nm = (unsigned)fuse.size();
+        const size_t n_keys = npx * 16;
+        const unsigned key_blocks = (unsigned)((n_keys + 255) / 256);
+        const unsigned surfel_blocks = (unsigned)((max_count + 255) / 256);
+        const unsigned begin_blocks = std::max(key_blocks, surfel_blocks);
+        const unsigned clean_blocks = (unsigned)((max_elems + SF_CLEAN_BLOCK - 1) / SF_CLEAN_BLOCK);
+        hipLaunchKernelGGL(sf_fuse_begin_kernel, dim3(begin_blocks, nm), dim3(256), 0, h->stream, tab);                        // :284
+        if (max_count) hipLaunchKernelGGL(sf_index_splat_kernel, dim3(surfel_blocks, nm), dim3(256), 0, h->stream, tab, 0);
+        if (max_cand) hipLaunchKernelGGL(sf_fuse_data_kernel, dim3((max_cand + 63) / 64, nm), dim3(64), 0, h->stream, tab);   // :286-298
+        if (max_count) hipLaunchKernelGGL(sf_fuse_update_kernel, dim3(surfel_blocks, nm), dim3(256), 0, h->stream, tab);
+        hipLaunchKernelGGL(sf_index_clear_kernel, dim3(key_blocks, nm), dim3(256), 0, h->stream, tab);                        // :300
+        if (max_count) hipLaunchKernelGGL(sf_index_splat_kernel, dim3(surfel_blocks, nm), dim3(256), 0, h->stream, tab, 1);
+        if (clean_blocks) {                                                                                                    // :302-311
+            hipLaunchKernelGGL(sf_clean_flag_kernel, dim3(clean_blocks, nm), dim3(SF_CLEAN_BLOCK), 0, h->stream, tab);
+            hipLaunchKernelGGL(sf_clean_scan_kernel, dim3(nm), dim3(1024), 0, h->stream, tab);
+            hipLaunchKernelGGL(sf_clean_write_kernel, dim3(clean_blocks, nm), dim3(SF_CLEAN_BLOCK), 0, h->stream, tab);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<int> res((size_t)n * 8);
+    if (int e = d2h(h, res.data(), h->res_dev, res.size() * sizeof(int))) return e;
+    int overflow = -1;
+    for (int q : init_of) {
+        sf_map *m = maps[q];
+        m->count = res[(size_t)q * 8];
         m->stats[0] = m->stats[1] = m->stats[2] = 0;
         m->stats[3] = m->count;
         m->tick++;
-        return SF_OK;
     }
-    float last_pose[16];
-    std::memcpy(last_pose, m->pose, sizeof last_pose);
-    pose_compose(m->pose, in_pose, m->pose);                                        // :268
-    FuseArgs a;
-    a.depth_metric = depth_metric; a.depth_filtered = depth_filtered; a.color = color; a.b_img = b_img;
-    a.rows = h->k.rows; a.cols = h->k.cols;
-    for (int q = 0; q < 16; q++) a.pose[q] = m->pose[q];
-    invert_pose(m->pose, a.t_inv);
-    a.cx = p->cx; a.cy = p->cy; a.fx = p->fx; a.fy = p->fy;
-    a.camz = float(1.0 / double(p->fx)); a.camw = float(1.0 / double(p->fy));       // GlobalModel.cpp:365-368
-    a.max_depth = p->max_depth; a.conf_threshold = p->conf_high;
-    a.weighting = sf_fusion_weighting(last_pose, m->pose, weight_multiplier);        // :270-282
-    a.time = m->tick; a.time_delta = p->time_delta;
-    a.src = m->buf[0]; a.dst = m->buf[1];
-    a.count = m->count; a.capacity = m->capacity;
-    a.keys = m->keys; a.winner = m->winner;
-    a.par = m->tick % 2;
-    a.cand_rows = (a.rows - a.par + 1) / 2; a.cand_cols = (a.cols - a.par + 1) / 2;
-    a.n_cand = a.cand_rows * a.cand_cols;
-    a.rec = m->rec; a.meta = m->meta; a.flags = m->flags; a.block_counts = m->block_counts; a.result = m->result;
-    const size_t n_keys = n * 16;
-    const unsigned key_blocks = (unsigned)((n_keys + 255) / 256);
-    const unsigned surfel_blocks = (unsigned)((a.count + 255) / 256);
-    const int n_elems = a.count + a.n_cand;
-    const int n_blocks = (n_elems + SF_CLEAN_BLOCK - 1) / SF_CLEAN_BLOCK;
-    const size_t n_begin = std::max(n_keys, (size_t)a.count);
-    hipLaunchKernelGGL(sf_fuse_begin_kernel, dim3((unsigned)((n_begin + 255) / 256)), dim3(256), 0, h->stream, m->keys, n_keys, m->winner, a.count,
-                       m->result);                                                                                   // :284
-    if (a.count) hipLaunchKernelGGL(sf_index_splat_kernel, dim3(surfel_blocks), dim3(256), 0, h->stream, a, a.src);
-    if (a.n_cand) hipLaunchKernelGGL(sf_fuse_data_kernel, dim3((a.n_cand + 63) / 64), dim3(64), 0, h->stream, a);  // :286-298
-    if (a.count) hipLaunchKernelGGL(sf_fuse_update_kernel, dim3(surfel_blocks), dim3(256), 0, h->stream, a);
-    hipLaunchKernelGGL(sf_index_clear_kernel, dim3(key_blocks), dim3(256), 0, h->stream, m->keys, n_keys);         // :300
-    if (a.count) hipLaunchKernelGGL(sf_index_splat_kernel, dim3(surfel_blocks), dim3(256), 0, h->stream, a, (const float *)a.dst);
-    if (n_blocks) {                                                                                                  // :302-311
-        hipLaunchKernelGGL(sf_clean_flag_kernel, dim3(n_blocks), dim3(SF_CLEAN_BLOCK), 0, h->stream, a);
-        hipLaunchKernelGGL(sf_clean_scan_kernel, dim3(1), dim3(1024), 0, h->stream, a, n_blocks);
-        hipLaunchKernelGGL(sf_clean_write_kernel, dim3(n_blocks), dim3(SF_CLEAN_BLOCK), 0, h->stream, a, m->buf[0]);
+    for (int q : fuse_of) {
+        sf_map *m = maps[q];
+        const int *r = res.data() + (size_t)q * 8;
+        m->count = r[0];
+        m->stats[0] = r[2]; m->stats[1] = r[3]; m->stats[2] = r[4]; m->stats[3] = r[0];
+        m->have_index = true;
+        m->tick++;
+        if (r[1] > m->capacity && overflow < 0) overflow = q;
     }
-    HIP_TRY(hipGetLastError());
-    int res[8];
-    if (int e = d2h(h, res, m->result, sizeof res)) return e;
-    m->count = res[0];
-    m->stats[0] = res[2]; m->stats[1] = res[3]; m->stats[2] = res[4]; m->stats[3] = res[0];
-    m->have_index = true;
-    m->tick++;
-    if (res[1] > m->capacity) return fail(SF_ERR_STATE, "surfel map capacity exceeded (truncated)");
+    if (overflow >= 0) return fail(SF_ERR_STATE, "surfel map capacity exceeded (truncated): batch entry " + std::to_string(overflow));
     return SF_OK;
 }
-int sf_map_predict(sf_handle *h, int stream, sf_map *m, const sf_model_params *p) {
-    if (int e = check_stream(h, stream)) return e;
-    if (!m || m->h != h || !p) return fail(SF_ERR_ARG, "bad argument");
+int sf_map_fuse_frame(sf_handle *h, int stream, sf_map *m, const float *in_pose, float weight_multiplier, const sf_model_params *p) {
+    return sf_map_fuse_frames(h, 1, &stream, &m, in_pose, weight_multiplier, p);
+}
+// Reconstruction::getPredictedImages for n (stream, map) pairs at each map's currPose and tick, in four launches
+int sf_map_predict_frames(sf_handle *h, int n, const int *streams, sf_map *const *maps, const sf_model_params *p) {
+    if (!h || n < 0 || (n && (!streams || !maps)) || !p) return fail(SF_ERR_ARG, "bad argument");
+    std::vector<PredictJob> jobs((size_t)n);
+    for (int q = 0; q < n; q++) {
+        if (int e = check_stream(h, streams[q])) return e;
+        if (!maps[q] || maps[q]->h != h) return fail(SF_ERR_ARG, "a map belongs to the handle it was created from");
+        for (int r = 0; r < q; r++)
+            if (streams[r] == streams[q]) return fail(SF_ERR_ARG, "the same stream twice in one batch (its prediction would be written twice)");
+        jobs[(size_t)q] = PredictJob{streams[q], maps[q]->buf[0], maps[q]->count, maps[q]->pose, maps[q]->tick, maps[q]->tick};
+    }
     HIP_TRY(hipSetDevice(h->device));
     if (int e = input_alloc(h)) return e;
-    sf_model_params q = *p;
-    q.time = q.max_time = m->tick;
-    return predict_launch(h, stream, m->buf[0], m->count, m->pose, &q);
+    return predict_batch(h, jobs, p);
+}
+int sf_map_predict(sf_handle *h, int stream, sf_map *m, const sf_model_params *p) {
+    return sf_map_predict_frames(h, 1, &stream, &m, p);
 }
 int sf_map_info(sf_map *m, int *count, int *tick, float pose[16], int stats[4]) {
     if (!m) return fail(SF_ERR_ARG, "null");
@@ -1121,7 +1233,8 @@ int sf_map_get_index_map(sf_map *m, uint32_t *out) {
     if (!m->have_index) return fail(SF_ERR_STATE, "no index map yet (sf_map_fuse_frame with tick > 1 renders it)");
     HIP_TRY(hipSetDevice(m->h->device));
     const size_t n = m->h->k.n0 * 16;
-    hipLaunchKernelGGL(sf_index_export_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->h->stream, m->keys, m->index_export, n);
+    hipLaunchKernelGGL(sf_index_export_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->h->stream, m->keys, m->index_export, m->h->k.cols * 4,
+                       m->h->k.rows * 4);
     HIP_TRY(hipGetLastError());
     return d2h(m->h, out, m->index_export, n * sizeof(uint32_t));
 }

@@ -71,7 +71,9 @@ __device__ __forceinline__ bool surfel_fragment(const PredictArgs &a, PV3 h, PV3
     return depth >= 0.f && depth <= 1.f;
 }
 
-__global__ __launch_bounds__(256) void sf_predict_clear_kernel(PredictArgs a) {
+// Every kernel takes a TABLE of PredictArgs and works on entry blockIdx.y (one launch renders the maps of many streams).
+__global__ __launch_bounds__(256) void sf_predict_clear_kernel(const PredictArgs *tab) {
+    const PredictArgs &a = tab[blockIdx.y];
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o < a.rows * a.cols) {
         a.key_low[o] = SF_PRED_EMPTY;
@@ -81,7 +83,8 @@ __global__ __launch_bounds__(256) void sf_predict_clear_kernel(PredictArgs a) {
 }
 
 // one lane per surfel: sprite extent (splat.vert:64-85), then one atomicMin per surviving fragment
-__global__ __launch_bounds__(256) void sf_predict_splat_kernel(PredictArgs a) {
+__global__ __launch_bounds__(256) void sf_predict_splat_kernel(const PredictArgs *tab) {
+    const PredictArgs &a = tab[blockIdx.y];
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= a.count) return;
     PV3 h, n;
@@ -135,7 +138,8 @@ __device__ __forceinline__ void resolve_pixel(const PredictArgs &a, unsigned lon
 }
 
 // Resize to (cols/40) x (rows/40) + denseEnough: counts the sampled low-confidence pixels with all channels > 0
-__global__ __launch_bounds__(64) void sf_predict_dense_kernel(PredictArgs a) {
+__global__ __launch_bounds__(64) void sf_predict_dense_kernel(const PredictArgs *tab) {
+    const PredictArgs &a = tab[blockIdx.x];  // one wave per map
     const int rw = a.cols / 40, rh = a.rows / 40;
     int sum = 0;
     for (int q = threadIdx.x; q < rw * rh; q += 64) {
@@ -152,7 +156,8 @@ __global__ __launch_bounds__(64) void sf_predict_dense_kernel(PredictArgs a) {
 }
 
 // per pixel: resolve both targets, fill-in, extract depth, intensity (lanes along y: the outputs are column-major)
-__global__ __launch_bounds__(256) void sf_predict_resolve_kernel(PredictArgs a) {
+__global__ __launch_bounds__(256) void sf_predict_resolve_kernel(const PredictArgs *tab) {
+    const PredictArgs &a = tab[blockIdx.y];
     const int idx = blockIdx.x * 256 + threadIdx.x;  // y + x * rows
     if (idx >= a.rows * a.cols) return;
     const int x = idx / a.rows, y = idx - x * a.rows;
@@ -241,9 +246,10 @@ __device__ __forceinline__ bool feedback_vertex(const Depth &D, int i, int j, co
     return !(v.z <= 0.f || v.z > a.max_depth);
 }
 
-__global__ __launch_bounds__(1024) void sf_init_model_kernel(InitModelArgs a) {
+__global__ __launch_bounds__(1024) void sf_init_model_kernel(const InitModelArgs *tab) {
     __shared__ int wcount[2][16];
     __shared__ int base[2];
+    const InitModelArgs &a = tab[blockIdx.x];  // one workgroup per map
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = a.rows * a.cols;
     if (tid < 2) base[tid] = 0;
@@ -308,8 +314,14 @@ __global__ __launch_bounds__(1024) void sf_init_model_kernel(InitModelArgs a) {
     }
 }
 
-// the draw call is sized by the RAW buffer: slots from count_raw on are not part of the model (zeroed)
-__global__ __launch_bounds__(256) void sf_init_model_trim_kernel(float *out, const int *count, int cap) {
+__global__ __launch_bounds__(256) void sf_init_model_zero_kernel(const InitModelArgs *tab) {
+    const InitModelArgs &a = tab[blockIdx.y];
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (q < (size_t)cap * 12 && q >= (size_t)count[0] * 12) out[q] = 0.f;
+    if (q < (size_t)a.rows * a.cols * 12) a.out[q] = 0.f;
+}
+// the draw call is sized by the RAW buffer: slots from count_raw on are not part of the model (zeroed)
+__global__ __launch_bounds__(256) void sf_init_model_trim_kernel(const InitModelArgs *tab) {
+    const InitModelArgs &a = tab[blockIdx.y];
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q < (size_t)a.rows * a.cols * 12 && q >= (size_t)a.count[0] * 12) a.out[q] = 0.f;
 }

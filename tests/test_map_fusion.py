@@ -18,16 +18,17 @@ XI = np.array([0.010, 0.004, 0.006, 0.002, -0.004, 0.003])  # per-frame camera m
 _fp = C.POINTER(C.c_float)
 
 
-def load_view(s, depth, rgb, b_of_cluster):
+def load_view(s, depth, rgb, b_of_cluster, stream=0, finish=True):
     """what the frame loop leaves in the stream before fuseFrame: the loaded + filtered frame and the b image of the solve"""
     full_d = np.repeat(np.repeat(np.clip(np.rint(depth[::-1] * 1000), 0, 65535).astype(np.uint16), 2, 0), 2, 1)
     full_c = np.repeat(np.repeat(rgb[::-1], 2, 0), 2, 1)
-    s.load_frame(0, full_c, full_d, 2)
-    s.filter_depth()
+    s.load_frame(stream, full_c, full_d, 2)
     yy, xx = np.mgrid[0:ROWS, 0:COLS]
     labels = ((xx // 40) + 8 * (yy // 40)) % 24
-    s.set_segm_state(0, labels.astype(np.int32), np.asarray(b_of_cluster, np.float32), np.ones(24, np.float32))
-    s.build_segm_image()
+    s.set_segm_state(stream, labels.astype(np.int32), np.asarray(b_of_cluster, np.float32), np.ones(24, np.float32))
+    if finish:  # both act on every stream of the handle
+        s.filter_depth()
+        s.build_segm_image()
 
 
 def walk(api, n_frames, sphere=False, b=None, capacity=0, xi=XI, keep=True):
@@ -267,9 +268,73 @@ def test_map_upload_roundtrip_and_prediction_from_the_map(ora):
     assert same_bits(d1, d2) and same_bits(i1, i2)
 
 
+def batch_walk(api, n_frames, batched):
+    """three sequences in one handle (static room, moving sphere, faster motion), the third one starting a frame late so that
+    one batch mixes GlobalModel::initialise with fusion; batched: one sf_map_fuse_frames / sf_map_predict_frames per frame"""
+    s = make_solver(api, ROWS, COLS, driver_params(api), batch=3)
+    maps = [SurfelMap(s) for _ in range(3)]
+    xis = [XI, XI * np.array([1, -1, 1, -1, 1, -1]), XI * 2.5]
+    spheres = [False, True, False]
+    bs = [np.linspace(0.05, 1.0, 24).astype(np.float32), np.full(24, 0.9, np.float32), np.linspace(1.0, 0.3, 24).astype(np.float32)]
+    T = [np.eye(4) for _ in range(3)]
+    out = []
+    for k in range(n_frames):
+        live = [q for q in range(3) if not (q == 2 and k == 0)]
+        for q in range(3):
+            depth, rgb = synthetic_view(T[q], sphere=spheres[q])
+            load_view(s, depth, rgb, bs[q], stream=q, finish=(q == 2))
+        poses = [se3_exp(xis[q]) for q in live]
+        if batched:
+            SurfelMap.fuse_frames(s, live, [maps[q] for q in live], poses)
+            SurfelMap.predict_frames(s, live, [maps[q] for q in live])
+        else:
+            for q, Tq in zip(live, poses):
+                maps[q].fuse_frame(q, Tq)
+                maps[q].predict(q)
+        out.append([dict(info=maps[q].info(), surfels=maps[q].download(), pred=s.prediction(q)) for q in live])
+        for q in live:
+            T[q] = T[q] @ se3_exp(xis[q])
+    return out
+
+
+def same_batch_results(a, b):
+    for k, (fa, fb) in enumerate(zip(a, b)):
+        assert len(fa) == len(fb)
+        for q, (x, y) in enumerate(zip(fa, fb)):
+            assert x["info"]["count"] == y["info"]["count"] and x["info"]["stats"] == y["info"]["stats"] and x["info"]["tick"] == y["info"]["tick"], (k, q)
+            assert np.array_equal(x["info"]["pose"], y["info"]["pose"]), (k, q)
+            assert same_bits(x["surfels"], y["surfels"]), (k, q)
+            assert same_bits(x["pred"][0], y["pred"][0]) and same_bits(x["pred"][1], y["pred"][1]), (k, q)
+
+
+def test_batched_calls_equal_single_calls_on_the_oracle(ora):
+    a, b = batch_walk(ora, 3, batched=True), batch_walk(ora, 3, batched=False)
+    same_batch_results(a, b)
+    assert a[1][0]["info"]["tick"] == 3 and a[1][2]["info"]["tick"] == 2  # the late sequence is one tick behind
+    s = make_solver(ora, ROWS, COLS, driver_params(ora), batch=2)
+    m = SurfelMap(s)
+    depth, rgb = synthetic_view(np.eye(4), sphere=False)
+    for q in range(2):
+        load_view(s, depth, rgb, np.full(24, 0.9, np.float32), stream=q, finish=(q == 1))
+    with pytest.raises(SfError):
+        SurfelMap.fuse_frames(s, [0, 1], [m, m], None)   # the same map twice
+    m2 = SurfelMap(s)
+    with pytest.raises(SfError):
+        SurfelMap.predict_frames(s, [0, 0], [m, m2])     # the same stream's prediction written twice
+
+
 # ------------------------------------------------------------------------------------------------
 #  GPU: HIP vs oracle
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_hip_batched_fusion_equals_single_calls_and_the_oracle(hip, ora):
+    """sf_map_fuse_frames / sf_map_predict_frames: one launch per kernel for three sequences, one of them initialising while the
+    others fuse -- bit-identical to three single calls and to the oracle"""
+    batched = batch_walk(hip, 4, batched=True)
+    same_batch_results(batched, batch_walk(hip, 4, batched=False))
+    same_batch_results(batched, batch_walk(ora, 4, batched=True))
+
+
 def _compare_walk(hip, ora, **kw):
     _, _, ref = walk(ora, **kw)
     _, _, got = walk(hip, **kw)

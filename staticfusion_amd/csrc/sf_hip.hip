@@ -898,7 +898,7 @@ static int predict_batch(sf_handle *h, const std::vector<PredictJob> &jobs, cons
     const unsigned nm = (unsigned)jobs.size();
     const unsigned pix_blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(sf_predict_clear_kernel, dim3(pix_blocks, nm), dim3(256), 0, h->stream, d_tab);
-    if (max_count) hipLaunchKernelGGL(sf_predict_splat_kernel, dim3((max_count + 255) / 256, nm), dim3(256), 0, h->stream, d_tab);
+    if (max_count) hipLaunchKernelGGL(sf_predict_splat_kernel, dim3((max_count + SF_SPLAT_NT - 1) / SF_SPLAT_NT, nm), dim3(SF_SPLAT_NT), 0, h->stream, d_tab);
     hipLaunchKernelGGL(sf_predict_dense_kernel, dim3(nm), dim3(64), 0, h->stream, d_tab);
     hipLaunchKernelGGL(sf_predict_resolve_kernel, dim3(pix_blocks, nm), dim3(256), 0, h->stream, d_tab);
     HIP_TRY(hipGetLastError());

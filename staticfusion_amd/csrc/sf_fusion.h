@@ -41,7 +41,9 @@ struct FuseArgs {
     const float *src;   // surfels in (count x 12)
     float *dst;         // surfels out
     int count, capacity;
-    unsigned long long *keys;  // 4 rows x 4 cols
+    unsigned long long *keys;  // 4 rows x 4 cols, column-major
+    unsigned long long *occ;   // occupancy bits of the key image: column tu owns occ_words words, bit tv of them = a surfel was drawn there
+    int occ_words;             // ceil(4 rows / 64)
     unsigned *winner;          // [count]
     // candidates: pixels (2 i' + par, 2 j' + par), order index q = j' + i' * cand_rows
     int par, cand_rows, cand_cols, n_cand;
@@ -84,12 +86,14 @@ __global__ __launch_bounds__(256) void sf_index_clear_kernel(const FuseArgs *tab
     const FuseArgs &a = tab[blockIdx.y];
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (o < (size_t)a.rows * a.cols * 16) a.keys[o] = SF_PRED_EMPTY;
+    if (o < (size_t)a.cols * 4 * a.occ_words) a.occ[o] = 0ull;
 }
 // start of a fuse: clear the index image, the update-map winners and the counters in one launch
 __global__ __launch_bounds__(256) void sf_fuse_begin_kernel(const FuseArgs *tab) {
     const FuseArgs &a = tab[blockIdx.y];
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (o < (size_t)a.rows * a.cols * 16) a.keys[o] = SF_PRED_EMPTY;
+    if (o < (size_t)a.cols * 4 * a.occ_words) a.occ[o] = 0ull;
     if (o < (size_t)a.count) a.winner[o] = SF_FUSE_NONE;
     if (o < 8) a.result[o] = 0;
 }
@@ -115,6 +119,7 @@ __global__ __launch_bounds__(256) void sf_index_splat_kernel(const FuseArgs *tab
     const float depth = ndc_z * 0.5f + 0.5f;
     const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned)s;
     atomicMin(a.keys + (size_t)int(fx_) * H4 + int(fy_), key);  // column-major key image
+    atomicOr(a.occ + (size_t)int(fx_) * a.occ_words + (int(fy_) >> 6), 1ull << (int(fy_) & 63));
 }
 __global__ __launch_bounds__(256) void sf_index_export_kernel(const unsigned long long *keys, unsigned *out, int W4, int H4) {  // -> row-major
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -142,6 +147,40 @@ __device__ __forceinline__ IndexTexelD index_texel_pos(const FuseArgs &a, const 
 __device__ __forceinline__ PV3 index_texel_normal(const FuseArgs &a, const float *surfels, unsigned idx) {
     const float *q = surfels + (size_t)idx * 12;
     return pnormalize(rotate3(a.t_inv, PV3{q[8], q[9], q[10]}));
+}
+
+// ---- the association windows (data.vert:133-135, copy_unstable.vert:62-64) ----------------------------------------
+// Both shaders step a texture coordinate in HALF texels by repeated float addition: 17 x 17 samples over about 9 x 9 texels
+// of the 4x index image, of which ~6 % hold a surfel. The kernels repeat the float sequence of each axis once (so that the
+// texels visited and how often are exactly the shader's), then look only at OCCUPIED texels: the index splat keeps one
+// occupancy bit per texel (column-major like the keys), a column of the window is one or two 64-bit loads, and only set
+// bits cost a key load and a surfel gather. Texels of one axis are consecutive integers (the coordinate advances half a
+// texel per step), so a run list is (first texel, count <= 12, 5-bit multiplicities <= 17).
+struct AxisRuns {
+    int lo, n;                 // texels lo .. lo + n - 1
+    unsigned long long mult;   // 5-bit field k: how many samples fell on texel lo + k
+};
+__device__ __forceinline__ AxisRuns axis_runs(float centre, float reach, float step, int size) {
+    AxisRuns r{0, 0, 0ull};
+    int prev = -1;
+    for (float w = centre - reach; w < centre + reach; w += step) {  // the shader's loop, verbatim
+        const int t = nearest_texel(w, size);
+        if (t != prev) {
+            if (r.n == 0) r.lo = t;
+            r.n = t - r.lo + 1;
+            prev = t;
+        }
+        r.mult += 1ull << (5 * (t - r.lo));
+    }
+    return r;
+}
+// occupancy bits of texels v.lo .. v.lo + v.n - 1 of column tu (bit k = texel v.lo + k)
+__device__ __forceinline__ unsigned occupancy_bits(const FuseArgs &a, int tu, const AxisRuns &v) {
+    const unsigned long long *col = a.occ + (size_t)tu * a.occ_words;
+    const int w0 = v.lo >> 6, b0 = v.lo & 63, w1 = (v.lo + v.n - 1) >> 6;
+    unsigned long long bits = col[w0] >> b0;
+    if (w1 != w0) bits |= col[w1] << (64 - b0);  // b0 > 0 here
+    return (unsigned)bits & ((1u << v.n) - 1u);
 }
 
 // ---- GlobalModel::fuse, data association (data.vert) --------------------------------------------------------------
@@ -194,24 +233,18 @@ __global__ __launch_bounds__(64) void sf_fuse_data_kernel(const FuseArgs *tab) {
         const PV3 ray{xl, yl, 1.f};
         const float ray_len = plength(ray);
         const float nl_len = plength(vNormLocal);
-        // The window steps its texture coordinate in HALF texels (data.vert:133-135): consecutive samples often read the
-        // same texel. The texel sequence of each axis is non-decreasing, a repeated texel offers the same candidate at the
-        // same distance, and only a STRICTLY nearer one replaces the best: repeats are skipped, the result is unchanged.
-        // The key image is stored COLUMN-major: the inner (v) loop of a lane walks consecutive keys, and neighbouring
-        // lanes -- vertically neighbouring pixels, the order of the reference's point list -- read neighbouring keys.
+        // a repeated texel offers the same candidate at the same distance and only a STRICTLY nearer one replaces the best:
+        // every distinct texel is looked at once, in the shader's order (u outer, v inner, ascending)
         const int W4 = cols * 4, H4 = rows * 4;
-        int prev_tu = -1;
-        for (float u = tx - (scale * indexXStep * windowMultiplier); u < tx + (scale * indexXStep * windowMultiplier); u += indexXStep) {
-            const int tu = nearest_texel(u, W4);
-            if (tu == prev_tu) continue;
-            prev_tu = tu;
-            const unsigned long long *col = a.keys + (size_t)tu * H4;
-            int prev_tv = -1;
-            for (float v = ty - (scale * indexYStep * windowMultiplier); v < ty + (scale * indexYStep * windowMultiplier); v += indexYStep) {
-                const int tv = nearest_texel(v, H4);
-                if (tv == prev_tv) continue;
-                prev_tv = tv;
-                const unsigned long long key = col[tv];
+        const AxisRuns ur = axis_runs(tx, scale * indexXStep * windowMultiplier, indexXStep, W4);
+        const AxisRuns vr = axis_runs(ty, scale * indexYStep * windowMultiplier, indexYStep, H4);
+        for (int cu = 0; cu < ur.n; cu++) {
+            const int tu = ur.lo + cu;
+            unsigned bits = occupancy_bits(a, tu, vr);
+            while (bits) {
+                const int k = __ffs((int)bits) - 1;
+                bits &= bits - 1u;
+                const unsigned long long key = a.keys[(size_t)tu * H4 + vr.lo + k];
                 const unsigned current = key == SF_PRED_EMPTY ? 0u : (unsigned)(key & 0xffffffffull);
                 if (current > 0U) {
                     const IndexTexelD t = index_texel_pos(a, a.src, current);
@@ -354,44 +387,29 @@ __global__ __launch_bounds__(SF_CLEAN_BLOCK) void sf_clean_flag_kernel(const Fus
             const bool dropped_anyway = (t_fixed == -1.f || ((ftime - t_fixed) > 10.f && conf_v < 0.5f)) || (conf_v == 0.0f);
             const bool kept_anyway = t_fixed > 0.f && ftime - t_fixed > fdelta;
             if (!dropped_anyway && !kept_anyway && ftime - t_last_v < fdelta && localPos.z > 0.f && x > 0.f && y > 0.f && x < W && y < H) {
-                // half-texel steps (copy_unstable.vert:62-64): a texel read m_u x m_v times counts m_u x m_v times; evaluate it once
+                // a texel sampled m_u x m_v times counts m_u x m_v times: each occupied texel is evaluated once with that weight
                 const int W4 = a.cols * 4, H4 = a.rows * 4;
-                auto eval = [&](int tu, int tv, int mult) {
-                    const unsigned long long key = a.keys[(size_t)tu * H4 + tv];
-                    const unsigned current = key == SF_PRED_EMPTY ? 0u : (unsigned)(key & 0xffffffffull);
-                    if (current > 0U) {
-                        const IndexTexelD t = index_texel_pos(a, a.dst, current);
-                        const float dx = t.pos.x - localPos.x, dy = t.pos.y - localPos.y;
-                        if (t.t_init < t_init_v && t.conf > a.conf_threshold && t.pos.z > localPos.z && t.pos.z - localPos.z < 0.01f &&
-                            sqrtf(dx * dx + dy * dy) < rad_v * 1.4f)
-                            count += mult;
-                        if (t.t_last == ftime && t.conf > 0.4f * a.conf_threshold && t.pos.z > localPos.z && t.pos.z - localPos.z > 0.01f) zCount += mult;
+                const AxisRuns ur = axis_runs(x / W, scale * indexXStep * windowMultiplier, indexXStep, W4);
+                const AxisRuns vr = axis_runs(y / H, scale * indexYStep * windowMultiplier, indexYStep, H4);
+                for (int cu = 0; cu < ur.n; cu++) {
+                    const int tu = ur.lo + cu, mu = (int)((ur.mult >> (5 * cu)) & 31ull);
+                    unsigned bits = occupancy_bits(a, tu, vr);
+                    while (bits) {
+                        const int k = __ffs((int)bits) - 1;
+                        bits &= bits - 1u;
+                        const int mult = mu * (int)((vr.mult >> (5 * k)) & 31ull);
+                        const unsigned long long key = a.keys[(size_t)tu * H4 + vr.lo + k];
+                        const unsigned current = key == SF_PRED_EMPTY ? 0u : (unsigned)(key & 0xffffffffull);
+                        if (current > 0U) {
+                            const IndexTexelD t = index_texel_pos(a, a.dst, current);
+                            const float dx = t.pos.x - localPos.x, dy = t.pos.y - localPos.y;
+                            if (t.t_init < t_init_v && t.conf > a.conf_threshold && t.pos.z > localPos.z && t.pos.z - localPos.z < 0.01f &&
+                                sqrtf(dx * dx + dy * dy) < rad_v * 1.4f)
+                                count += mult;
+                            if (t.t_last == ftime && t.conf > 0.4f * a.conf_threshold && t.pos.z > localPos.z && t.pos.z - localPos.z > 0.01f) zCount += mult;
+                        }
                     }
-                };
-                auto column = [&](int tu, int mu) {  // the key image is column-major: consecutive keys
-                    int prev_tv = -1, mv = 0;
-                    for (float v = y / H - (scale * indexYStep * windowMultiplier); v < y / H + (scale * indexYStep * windowMultiplier); v += indexYStep) {
-                        const int tv = nearest_texel(v, H4);
-                        if (tv != prev_tv) {
-                            if (mv) eval(tu, prev_tv, mu * mv);
-                            prev_tv = tv;
-                            mv = 1;
-                        } else
-                            mv++;
-                    }
-                    if (mv) eval(tu, prev_tv, mu * mv);
-                };
-                int prev_tu = -1, mu = 0;
-                for (float u = x / W - (scale * indexXStep * windowMultiplier); u < x / W + (scale * indexXStep * windowMultiplier); u += indexXStep) {
-                    const int tu = nearest_texel(u, W4);
-                    if (tu != prev_tu) {
-                        if (mu) column(prev_tu, mu);
-                        prev_tu = tu;
-                        mu = 1;
-                    } else
-                        mu++;
                 }
-                if (mu) column(prev_tu, mu);
             }
             if (count > 6 || zCount > 5) test = 0;
             if (t_last_v == -2.f) t_last_v = ftime;

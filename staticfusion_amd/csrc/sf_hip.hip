@@ -1002,7 +1002,7 @@ struct sf_map {
     int count = 0, tick = 1;
     float pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     int stats[4] = {0, 0, 0, 0};
-    unsigned long long *keys = nullptr;
+    unsigned long long *keys = nullptr, *occ = nullptr;
     unsigned *winner = nullptr, *meta = nullptr, *index_export = nullptr;
     float *rec = nullptr;
     unsigned char *flags = nullptr;
@@ -1033,6 +1033,7 @@ int sf_map_create(sf_handle *h, int capacity, sf_map **out) {
     if (!e) e = map_alloc(m, &m->buf[0], cap * 12);
     if (!e) e = map_alloc(m, &m->buf[1], cap * 12);
     if (!e) e = map_alloc(m, &m->keys, n0 * 16);
+    if (!e) e = map_alloc(m, &m->occ, (size_t)h->k.cols * 4 * ((h->k.rows * 4 + 63) / 64));
     if (!e) e = map_alloc(m, &m->index_export, n0 * 16);
     if (!e) e = map_alloc(m, &m->winner, cap);
     if (!e) e = map_alloc(m, &m->rec, n_cand_max * 12);
@@ -1118,6 +1119,7 @@ int sf_map_fuse_frames(sf_handle *h, int n, const int *streams, sf_map *const *m
         a.src = m->buf[0]; a.dst = m->buf[1]; a.out = m->buf[0];
         a.count = m->count; a.capacity = m->capacity;
         a.keys = m->keys; a.winner = m->winner;
+        a.occ = m->occ; a.occ_words = (a.rows * 4 + 63) / 64;
         a.par = m->tick % 2;
         a.cand_rows = (a.rows - a.par + 1) / 2; a.cand_cols = (a.cols - a.par + 1) / 2;
         a.n_cand = a.cand_rows * a.cand_cols;

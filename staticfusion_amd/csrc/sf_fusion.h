@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void sf_index_splat_kernel(const FuseArgs *tab
     const FuseArgs &a = tab[blockIdx.y];
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= a.count) return;
-    const float *surfels = merged ? a.dst : a.src;
-    const float *q = surfels + (size_t)s * 12;
+    const auto surfels = as_global(merged ? (const float *)a.dst : a.src);  // typed global pointers: global_load, not flat_load
+    const auto q = surfels + (size_t)s * 12;
     const PV3 h = xform3(a.t_inv, PV3{q[0], q[1], q[2]});                                       // index_map.vert:38
     if (h.z > a.max_depth || h.z < 0.f || float(a.time) - q[7] > float(a.time_delta)) return;   // :43-48
     const int W4 = a.cols * 4, H4 = a.rows * 4;
@@ -118,8 +118,9 @@ __global__ __launch_bounds__(256) void sf_index_splat_kernel(const FuseArgs *tab
     if (!(fx_ >= 0.f && fx_ < float(W4) && fy_ >= 0.f && fy_ < float(H4))) return;
     const float depth = ndc_z * 0.5f + 0.5f;
     const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned)s;
-    atomicMin(a.keys + (size_t)int(fx_) * H4 + int(fy_), key);  // column-major key image
-    atomicOr(a.occ + (size_t)int(fx_) * a.occ_words + (int(fy_) >> 6), 1ull << (int(fy_) & 63));
+    __hip_atomic_fetch_min(as_global(a.keys) + (size_t)int(fx_) * H4 + int(fy_), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // column-major key image
+    __hip_atomic_fetch_or(as_global(a.occ) + (size_t)int(fx_) * a.occ_words + (int(fy_) >> 6), 1ull << (int(fy_) & 63), __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT);
 }
 __global__ __launch_bounds__(256) void sf_index_export_kernel(const unsigned long long *keys, unsigned *out, int W4, int H4) {  // -> row-major
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -135,8 +136,9 @@ struct IndexTexelD {
     float conf, t_init, t_last;
     PV3 normal;
 };
-__device__ __forceinline__ IndexTexelD index_texel_pos(const FuseArgs &a, const float *surfels, unsigned idx) {
-    const float *q = surfels + (size_t)idx * 12;
+template <class P>
+__device__ __forceinline__ IndexTexelD index_texel_pos(const FuseArgs &a, P surfels, unsigned idx) {
+    const auto q = surfels + (size_t)idx * 12;
     IndexTexelD t;
     t.pos = xform3(a.t_inv, PV3{q[0], q[1], q[2]});
     t.conf = q[3];
@@ -144,8 +146,9 @@ __device__ __forceinline__ IndexTexelD index_texel_pos(const FuseArgs &a, const 
     t.t_last = q[7];
     return t;
 }
-__device__ __forceinline__ PV3 index_texel_normal(const FuseArgs &a, const float *surfels, unsigned idx) {
-    const float *q = surfels + (size_t)idx * 12;
+template <class P>
+__device__ __forceinline__ PV3 index_texel_normal(const FuseArgs &a, P surfels, unsigned idx) {
+    const auto q = surfels + (size_t)idx * 12;
     return pnormalize(rotate3(a.t_inv, PV3{q[8], q[9], q[10]}));
 }
 
@@ -176,7 +179,7 @@ __device__ __forceinline__ AxisRuns axis_runs(float centre, float reach, float s
 }
 // occupancy bits of texels v.lo .. v.lo + v.n - 1 of column tu (bit k = texel v.lo + k)
 __device__ __forceinline__ unsigned occupancy_bits(const FuseArgs &a, int tu, const AxisRuns &v) {
-    const unsigned long long *col = a.occ + (size_t)tu * a.occ_words;
+    const auto col = as_global(a.occ) + (size_t)tu * a.occ_words;
     const int w0 = v.lo >> 6, b0 = v.lo & 63, w1 = (v.lo + v.n - 1) >> 6;
     unsigned long long bits = col[w0] >> b0;
     if (w1 != w0) bits |= col[w1] << (64 - b0);  // b0 > 0 here
@@ -238,20 +241,22 @@ __global__ __launch_bounds__(64) void sf_fuse_data_kernel(const FuseArgs *tab) {
         const int W4 = cols * 4, H4 = rows * 4;
         const AxisRuns ur = axis_runs(tx, scale * indexXStep * windowMultiplier, indexXStep, W4);
         const AxisRuns vr = axis_runs(ty, scale * indexYStep * windowMultiplier, indexYStep, H4);
+        const auto g_keys = as_global((const unsigned long long *)a.keys);
+        const auto g_src = as_global(a.src);
         for (int cu = 0; cu < ur.n; cu++) {
             const int tu = ur.lo + cu;
             unsigned bits = occupancy_bits(a, tu, vr);
             while (bits) {
                 const int k = __ffs((int)bits) - 1;
                 bits &= bits - 1u;
-                const unsigned long long key = a.keys[(size_t)tu * H4 + vr.lo + k];
+                const unsigned long long key = g_keys[(size_t)tu * H4 + vr.lo + k];
                 const unsigned current = key == SF_PRED_EMPTY ? 0u : (unsigned)(key & 0xffffffffull);
                 if (current > 0U) {
-                    const IndexTexelD t = index_texel_pos(a, a.src, current);
+                    const IndexTexelD t = index_texel_pos(a, g_src, current);
                     if (fabsf((t.pos.z * lambda) - (vPosLocal.z * lambda)) < 0.05f) {
                         const float dist = plength(pcross(ray, t.pos)) / ray_len;
                         if (dist < bestDist) {
-                            const PV3 tn = index_texel_normal(a, a.src, current);
+                            const PV3 tn = index_texel_normal(a, g_src, current);
                             bool angle_ok = fabsf(tn.z) < 0.75f;
                             if (!angle_ok) {
                                 const float cs = pdot(tn, vNormLocal) / (plength(tn) * nl_len);
@@ -297,14 +302,14 @@ __global__ __launch_bounds__(256) void sf_fuse_update_kernel(const FuseArgs *tab
     const FuseArgs &a = tab[blockIdx.y];
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= a.count) return;
-    const float *q = a.src + (size_t)s * 12;
-    float *o = a.dst + (size_t)s * 12;
-    const unsigned w_ = a.winner[s];
+    const auto q = as_global(a.src) + (size_t)s * 12;
+    const auto o = as_global(a.dst) + (size_t)s * 12;
+    const unsigned w_ = as_global((const unsigned *)a.winner)[s];
     float v[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) v[k] = q[k];
     if (w_ != SF_FUSE_NONE) {
-        const float *d = a.rec + (size_t)w_ * 12;
+        const auto d = as_global((const float *)a.rec) + (size_t)w_ * 12;
         float c_k = v[3];
         float aa = d[3];
         const float hist = v[5];
@@ -345,14 +350,14 @@ __global__ __launch_bounds__(256) void sf_fuse_update_kernel(const FuseArgs *tab
 }
 
 // ---- GlobalModel::clean (copy_unstable.vert): element e of [merged model (in dst) ..., candidates ...] ------------
-__device__ __forceinline__ const float *clean_element(const FuseArgs &a, int e, bool &present) {
+__device__ __forceinline__ gptr<const float> clean_element(const FuseArgs &a, int e, bool &present) {
     if (e < a.count) {
         present = true;
-        return a.dst + (size_t)e * 12;
+        return as_global((const float *)a.dst) + (size_t)e * 12;
     }
     const int q = e - a.count;
-    present = a.meta[(size_t)q * 2] > 0;  // data.geom emits only updateId > 0
-    return a.rec + (size_t)q * 12;
+    present = as_global((const unsigned *)a.meta)[(size_t)q * 2] > 0;  // data.geom emits only updateId > 0
+    return as_global((const float *)a.rec) + (size_t)q * 12;
 }
 #define SF_CLEAN_BLOCK 256  // compaction granule: small, so that a QVGA map (93 k elements) still covers the 256 CUs
 __global__ __launch_bounds__(SF_CLEAN_BLOCK) void sf_clean_flag_kernel(const FuseArgs *tab) {
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(SF_CLEAN_BLOCK) void sf_clean_flag_kernel(const Fus
     bool keep = false;
     if (e < n) {
         bool present;
-        const float *q = clean_element(a, e, present);
+        const auto q = clean_element(a, e, present);
         if (present) {
             int test = 1;
             const PV3 localPos = xform3(a.t_inv, PV3{q[0], q[1], q[2]});
@@ -391,6 +396,8 @@ __global__ __launch_bounds__(SF_CLEAN_BLOCK) void sf_clean_flag_kernel(const Fus
                 const int W4 = a.cols * 4, H4 = a.rows * 4;
                 const AxisRuns ur = axis_runs(x / W, scale * indexXStep * windowMultiplier, indexXStep, W4);
                 const AxisRuns vr = axis_runs(y / H, scale * indexYStep * windowMultiplier, indexYStep, H4);
+                const auto g_keys = as_global((const unsigned long long *)a.keys);
+                const auto g_dst = as_global((const float *)a.dst);
                 for (int cu = 0; cu < ur.n; cu++) {
                     const int tu = ur.lo + cu, mu = (int)((ur.mult >> (5 * cu)) & 31ull);
                     unsigned bits = occupancy_bits(a, tu, vr);
@@ -398,10 +405,10 @@ __global__ __launch_bounds__(SF_CLEAN_BLOCK) void sf_clean_flag_kernel(const Fus
                         const int k = __ffs((int)bits) - 1;
                         bits &= bits - 1u;
                         const int mult = mu * (int)((vr.mult >> (5 * k)) & 31ull);
-                        const unsigned long long key = a.keys[(size_t)tu * H4 + vr.lo + k];
+                        const unsigned long long key = g_keys[(size_t)tu * H4 + vr.lo + k];
                         const unsigned current = key == SF_PRED_EMPTY ? 0u : (unsigned)(key & 0xffffffffull);
                         if (current > 0U) {
-                            const IndexTexelD t = index_texel_pos(a, a.dst, current);
+                            const IndexTexelD t = index_texel_pos(a, g_dst, current);
                             const float dx = t.pos.x - localPos.x, dy = t.pos.y - localPos.y;
                             if (t.t_init < t_init_v && t.conf > a.conf_threshold && t.pos.z > localPos.z && t.pos.z - localPos.z < 0.01f &&
                                 sqrtf(dx * dx + dy * dy) < rad_v * 1.4f)
@@ -478,9 +485,13 @@ __global__ __launch_bounds__(SF_CLEAN_BLOCK) void sf_clean_write_kernel(const Fu
     pos += (int)__popcll(m & ((1ull << lane) - 1ull));
     if (pos >= a.capacity) return;
     bool present;
-    const float *q = clean_element(a, e, present);
-    float *o = out + (size_t)pos * 12;
-#pragma unroll
-    for (int k = 0; k < 12; k++) o[k] = q[k];
-    if (q[7] == -2.f) o[7] = float(a.time);  // copy_unstable.vert:101-104
+    const auto q = clean_element(a, e, present);
+    const auto o4 = (gptr<vfloat4>)(as_global(out) + (size_t)pos * 12);  // 48-byte records, 16-byte aligned: three 16-byte moves
+    const auto q4 = (gptr<const vfloat4>)q;
+    const vfloat4 v0 = q4[0], v2 = q4[2];
+    vfloat4 v1 = q4[1];
+    if (v1.w == -2.f) v1.w = float(a.time);  // copy_unstable.vert:101-104
+    o4[0] = v0;
+    o4[1] = v1;
+    o4[2] = v2;
 }

@@ -44,7 +44,7 @@ __device__ __forceinline__ PV3 pcross(PV3 a, PV3 b) { return {a.y * b.z - b.y * 
 
 // camera-frame position, normal and radius of surfel s (splat.vert:55,68); false if culled by :57
 __device__ __forceinline__ bool surfel_to_camera(const PredictArgs &a, int s, float conf_threshold, PV3 &h, PV3 &n, float &rad) {
-    const float *q = a.surfels + (size_t)s * 12;
+    const auto q = as_global(a.surfels) + (size_t)s * 12;  // typed global pointer: global_load, not flat_load
     const float *T = a.t_inv;
     const PV3 vp{q[0], q[1], q[2]};
     const float conf = q[3], tlast = q[7];
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(SF_SPLAT_NT) void sf_predict_splat_kernel(const Pre
     bool high = false;
     int i0 = 0, i1 = -1, j0 = 0, j1 = -1;
     if (valid) {
-        high = !(a.surfels[(size_t)s * 12 + 3] < a.conf_high);
+        high = !(as_global(a.surfels)[(size_t)s * 12 + 3] < a.conf_high);
         const float fcols = float(a.cols), frows = float(a.rows);
         const float ndc_x = ((((a.fx * h.x) / h.z) + a.cx) - (fcols * 0.5f)) / (fcols * 0.5f);
         const float ndc_y = ((((a.fy * h.y) / h.z) + a.cy) - (frows * 0.5f)) / (frows * 0.5f);
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(SF_SPLAT_NT) void sf_predict_splat_kernel(const Pre
                     if (high) atomicMin(&tile[1][t], key);
                 } else {
                     const int o = j + i * a.rows;
-                    atomicMin(a.key_low + o, key);
-                    if (high) atomicMin(a.key_high + o, key);
+                    __hip_atomic_fetch_min(as_global(a.key_low) + o, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (high) __hip_atomic_fetch_min(as_global(a.key_high) + o, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
     if (!tiled) return;
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(SF_SPLAT_NT) void sf_predict_splat_kernel(const Pre
         const int i = bi0 + (wide ? q % bw : q / bh), j = bj0 + (wide ? q / bw : q % bh);
         const int o = j + i * a.rows;
         const unsigned long long kl = tile[0][q], kh = tile[1][q];
-        if (kl != SF_PRED_EMPTY) atomicMin(a.key_low + o, kl);
-        if (kh != SF_PRED_EMPTY) atomicMin(a.key_high + o, kh);
+        if (kl != SF_PRED_EMPTY) __hip_atomic_fetch_min(as_global(a.key_low) + o, kl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (kh != SF_PRED_EMPTY) __hip_atomic_fetch_min(as_global(a.key_high) + o, kh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -195,7 +195,7 @@ __device__ __forceinline__ void resolve_pixel(const PredictArgs &a, unsigned lon
     float rad, depth;
     surfel_to_camera(a, s, -1.0e30f, h, n, rad);
     surfel_fragment(a, h, n, rad, i, j, z, depth);
-    const int c = (int)a.surfels[(size_t)s * 12 + 4];  // color.glsl decodeColor; the RGBA8 target holds the bytes
+    const int c = (int)as_global(a.surfels)[(size_t)s * 12 + 4];  // color.glsl decodeColor; the RGBA8 target holds the bytes
     r = (c >> 16) & 0xFF;
     g = (c >> 8) & 0xFF;
     b = c & 0xFF;

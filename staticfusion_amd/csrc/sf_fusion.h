@@ -98,29 +98,56 @@ __global__ __launch_bounds__(256) void sf_fuse_begin_kernel(const FuseArgs *tab)
     if (o < 8) a.result[o] = 0;
 }
 // surfels: the buffer the index image is rendered from (src before the merge, dst after it)
+__device__ __forceinline__ long long sf_op_or64(long long a, long long b) { return a | b; }
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
+    long long s = (long long)v;
+    SF_DPP_REDUCE(s, dpp_i64, sf_op_or64)
+    const int lo = __builtin_amdgcn_readlane((int)(s & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(s >> 32), 63);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
 __global__ __launch_bounds__(256) void sf_index_splat_kernel(const FuseArgs *tab, int merged) {
     const FuseArgs &a = tab[blockIdx.y];
+    if ((int)blockIdx.x * 256 >= a.count) return;  // a workgroup of a larger map of the batch
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= a.count) return;
-    const auto surfels = as_global(merged ? (const float *)a.dst : a.src);  // typed global pointers: global_load, not flat_load
-    const auto q = surfels + (size_t)s * 12;
-    const PV3 h = xform3(a.t_inv, PV3{q[0], q[1], q[2]});                                       // index_map.vert:38
-    if (h.z > a.max_depth || h.z < 0.f || float(a.time) - q[7] > float(a.time_delta)) return;   // :43-48
     const int W4 = a.cols * 4, H4 = a.rows * 4;
-    const float camx = a.cx * 4.f, camy = a.cy * 4.f, camz = a.fx * 4.f, camw = a.fy * 4.f;     // IndexMap.cpp:136-139
-    const float fcols = float(a.cols) * 4.f, frows = float(a.rows) * 4.f;
-    const float ndc_x = ((((camz * h.x) / h.z) + camx) - (fcols * 0.5f)) / (fcols * 0.5f);      // :51-52
-    const float ndc_y = ((((camw * h.y) / h.z) + camy) - (frows * 0.5f)) / (frows * 0.5f);
-    const float ndc_z = h.z / a.max_depth;                                                      // :57
-    if (!(ndc_x >= -1.f && ndc_x <= 1.f && ndc_y >= -1.f && ndc_y <= 1.f && ndc_z >= -1.f && ndc_z <= 1.f)) return;
-    const float xw = (ndc_x + 1.f) * (fcols * 0.5f), yw = (ndc_y + 1.f) * (frows * 0.5f);
-    const float fx_ = floorf(xw), fy_ = floorf(yw);
-    if (!(fx_ >= 0.f && fx_ < float(W4) && fy_ >= 0.f && fy_ < float(H4))) return;
-    const float depth = ndc_z * 0.5f + 0.5f;
-    const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned)s;
-    __hip_atomic_fetch_min(as_global(a.keys) + (size_t)int(fx_) * H4 + int(fy_), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // column-major key image
-    __hip_atomic_fetch_or(as_global(a.occ) + (size_t)int(fx_) * a.occ_words + (int(fy_) >> 6), 1ull << (int(fy_) & 63), __ATOMIC_RELAXED,
-                          __HIP_MEMORY_SCOPE_AGENT);
+    bool draw = s < a.count;
+    int px = 0, py = 0;
+    if (draw) {
+        const auto surfels = as_global(merged ? (const float *)a.dst : a.src);  // typed global pointers: global_load, not flat_load
+        const auto q = surfels + (size_t)s * 12;
+        const PV3 h = xform3(a.t_inv, PV3{q[0], q[1], q[2]});                                       // index_map.vert:38
+        draw = !(h.z > a.max_depth || h.z < 0.f || float(a.time) - q[7] > float(a.time_delta));     // :43-48
+        const float camx = a.cx * 4.f, camy = a.cy * 4.f, camz = a.fx * 4.f, camw = a.fy * 4.f;     // IndexMap.cpp:136-139
+        const float fcols = float(a.cols) * 4.f, frows = float(a.rows) * 4.f;
+        const float ndc_x = ((((camz * h.x) / h.z) + camx) - (fcols * 0.5f)) / (fcols * 0.5f);      // :51-52
+        const float ndc_y = ((((camw * h.y) / h.z) + camy) - (frows * 0.5f)) / (frows * 0.5f);
+        const float ndc_z = h.z / a.max_depth;                                                      // :57
+        draw = draw && (ndc_x >= -1.f && ndc_x <= 1.f && ndc_y >= -1.f && ndc_y <= 1.f && ndc_z >= -1.f && ndc_z <= 1.f);
+        const float xw = (ndc_x + 1.f) * (fcols * 0.5f), yw = (ndc_y + 1.f) * (frows * 0.5f);
+        const float fx_ = floorf(xw), fy_ = floorf(yw);
+        draw = draw && (fx_ >= 0.f && fx_ < float(W4) && fy_ >= 0.f && fy_ < float(H4));
+        if (draw) {
+            px = int(fx_);
+            py = int(fy_);
+            const float depth = ndc_z * 0.5f + 0.5f;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned)s;
+            __hip_atomic_fetch_min(as_global(a.keys) + (size_t)px * H4 + py, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // column-major key image
+        }
+    }
+    // occupancy bits: the lanes of a wave are neighbours in the map's point order, a dozen of them share one 64-bit word of a
+    // column -- OR their bits on the DPP network and let one lane per distinct word do the atomic
+    const int word = draw ? px * a.occ_words + (py >> 6) : -1;
+    const unsigned long long bit = draw ? 1ull << (py & 63) : 0ull;
+    const int lane = threadIdx.x & 63;
+    unsigned long long rem = __ballot(draw);
+    while (rem) {
+        const int src = __ffsll((long long)rem) - 1;
+        const int w = __builtin_amdgcn_readlane(word, src);
+        const bool mine = word == w;
+        const unsigned long long bits = wave_or_u64(mine ? bit : 0ull);
+        if (lane == src) __hip_atomic_fetch_or(as_global(a.occ) + w, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rem &= ~__ballot(mine);
+    }
 }
 __global__ __launch_bounds__(256) void sf_index_export_kernel(const unsigned long long *keys, unsigned *out, int W4, int H4) {  // -> row-major
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -366,6 +366,29 @@ def test_hip_fusion_fast_motion_and_truncation(hip, ora):
 
 
 @pytest.mark.gpu
+def test_hip_fusion_on_a_permuted_map(hip, ora):
+    """the kernels lean on the map's point order for locality only: a map whose surfels were shuffled (uploaded that way on both
+    sides) fuses to the same bits as the oracle's"""
+    res = []
+    for api in (hip, ora):
+        s, m, out = walk(api, 2)
+        sf_, info = out[1]["surfels"], out[1]["info"]
+        perm = np.random.default_rng(3).permutation(sf_.shape[0])
+        m.upload(sf_[perm], info["pose"], info["tick"])
+        T = np.linalg.matrix_power(se3_exp(XI), 2)
+        for k in range(2):
+            depth, rgb = synthetic_view(T, sphere=False)
+            load_view(s, depth, rgb, np.linspace(0.05, 1.0, 24).astype(np.float32))
+            m.fuse_frame(0, se3_exp(XI))
+            T = T @ se3_exp(XI)
+        m.predict(0)
+        res.append((m.info(), m.download(), m.index_map(), s.prediction()))
+    (ih, sh, xh, ph), (io_, so, xo, po) = res
+    assert ih["count"] == io_["count"] and ih["stats"] == io_["stats"] and ih["stats"][1] > 15000
+    assert same_bits(sh, so) and np.array_equal(xh, xo) and same_bits(ph[0], po[0]) and same_bits(ph[1], po[1])
+
+
+@pytest.mark.gpu
 def test_hip_map_is_what_predict_from_model_renders(hip):
     s, m, out = walk(hip, 3)
     mp = s.default_model_params()

@@ -149,6 +149,35 @@ def test_hip_prediction_bit_exact_vs_oracle(hip, ora, step, b_value, seed):
         assert np.median(err) < 0.01
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["shuffled", "column", "reversed"])
+def test_hip_prediction_any_buffer_order(hip, ora, order):
+    """the splat resolves a workgroup's fragments in an LDS tile when its surfels are neighbours (tall box for the map's
+    column order, wide box for a row-ordered buffer) and falls back to per-fragment global atomics when they are not
+    (shuffled): the same images as the oracle in every case (ties go to the lower index OF THAT ORDER on both sides)"""
+    depth0, rgb0 = synthetic_view(np.eye(4))
+    T1 = se3_exp(np.array(DEFAULT_XI) * 2.0)
+    depth1, rgb1 = synthetic_view(T1)
+    out = []
+    for api in (hip, ora):
+        s = make_solver(api, ROWS, COLS, driver_params(api))
+        mp = s.default_model_params()
+        prime_stream(s, depth1, rgb1, 0.3)
+        surf = surfels_from_frame(depth0, rgb0, np.eye(4), mp, step=1, seed=7)
+        if order == "shuffled":
+            surf = surf[np.random.default_rng(11).permutation(surf.shape[0])]
+        elif order == "column":  # the reference's point order: x outer, y inner
+            px = np.round(surf[:, 0] / surf[:, 2] * mp.fx + mp.cx - 0.0).astype(int)
+            py = np.round(surf[:, 1] / surf[:, 2] * mp.fy + mp.cy - 0.0).astype(int)
+            surf = surf[np.lexsort((py, px))]
+        else:
+            surf = surf[::-1].copy()
+        s.predict_from_model(0, surf, T1.astype(np.float32), mp)
+        out.append(s.prediction())
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert (out[1][0] > 0).mean() > 0.5
+
+
 # ------------------------------------------------------------------------------------------------
 #  GlobalModel::initialise: the surfel model of the first fused frame
 # ------------------------------------------------------------------------------------------------

@@ -366,6 +366,47 @@ def test_hip_fusion_fast_motion_and_truncation(hip, ora):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols", [(120, 160), (117, 160), (116, 201)])  # every pyramid level must hold a multiple of 4 pixels
+def test_hip_fusion_other_frame_sizes(hip, ora, rows, cols):
+    """odd and small frames: the candidate grid ((x, y) % 2 == tick % 2) has a different extent for even and odd ticks, the
+    occupancy words of a column end inside a word, the window clamps at all four borders"""
+    res = []
+    for api in (hip, ora):
+        p = driver_params(api)
+        p.ctf_levels = 2
+        s = make_solver(api, rows, cols, p)
+        m = SurfelMap(s)
+        T = np.eye(4)
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        labels = (((xx // 20) + 8 * (yy // 20)) % 24).astype(np.int32)
+        frames = []
+        for k in range(4):
+            depth, rgb = synthetic_view(T, sphere=True)
+            depth, rgb = depth[::2, ::2][:rows, :cols], rgb[::2, ::2][:rows, :cols]
+            if depth.shape != (rows, cols):  # wider than the half-resolution view: tile it
+                depth = np.tile(depth, (1, 2))[:rows, :cols]
+                rgb = np.tile(rgb, (1, 2, 1))[:rows, :cols]
+            full_d = np.repeat(np.repeat(np.clip(np.rint(depth[::-1] * 1000), 0, 65535).astype(np.uint16), 2, 0), 2, 1)
+            full_c = np.repeat(np.repeat(rgb[::-1], 2, 0), 2, 1)
+            s.load_frame(0, np.ascontiguousarray(full_c), np.ascontiguousarray(full_d), 2)
+            s.filter_depth()
+            s.set_segm_state(0, labels, np.linspace(0.05, 1.0, 24).astype(np.float32), np.ones(24, np.float32))
+            s.build_segm_image()
+            m.fuse_frame(0, None if k == 0 else se3_exp(XI * 0.5))
+            m.predict(0)
+            frames.append((m.info(), m.download(), m.index_map() if k else None, s.prediction()))
+            T = T @ se3_exp(XI * 0.5)
+        res.append(frames)
+    for k, ((ih, sh, xh, ph), (io_, so, xo, po)) in enumerate(zip(*res)):
+        assert ih["count"] == io_["count"] and ih["stats"] == io_["stats"], (k, ih, io_)
+        assert same_bits(sh, so), k
+        if k:
+            assert np.array_equal(xh, xo), k
+        assert same_bits(ph[0], po[0]) and same_bits(ph[1], po[1]), k
+    assert res[1][-1][0]["stats"][1] > 0.5 * res[1][-1][0]["stats"][0] > 0
+
+
+@pytest.mark.gpu
 def test_hip_fusion_on_a_permuted_map(hip, ora):
     """the kernels lean on the map's point order for locality only: a map whose surfels were shuffled (uploaded that way on both
     sides) fuses to the same bits as the oracle's"""

@@ -105,18 +105,15 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) 
     const int lo = __builtin_amdgcn_readlane((int)(s & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(s >> 32), 63);
     return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
-__global__ __launch_bounds__(256) void sf_index_splat_kernel(const FuseArgs *tab, int merged) {
-    const FuseArgs &a = tab[blockIdx.y];
-    if ((int)blockIdx.x * 256 >= a.count) return;  // a workgroup of a larger map of the batch
-    const int s = blockIdx.x * 256 + threadIdx.x;
+// index_map.vert + the depth test for surfel s at world position p with last-seen time t_last; every lane of the wave calls it
+// (live = false: nothing to draw)
+__device__ __forceinline__ void index_splat_lane(const FuseArgs &a, int s, bool live, PV3 p, float t_last) {
     const int W4 = a.cols * 4, H4 = a.rows * 4;
-    bool draw = s < a.count;
+    bool draw = live;
     int px = 0, py = 0;
     if (draw) {
-        const auto surfels = as_global(merged ? (const float *)a.dst : a.src);  // typed global pointers: global_load, not flat_load
-        const auto q = surfels + (size_t)s * 12;
-        const PV3 h = xform3(a.t_inv, PV3{q[0], q[1], q[2]});                                       // index_map.vert:38
-        draw = !(h.z > a.max_depth || h.z < 0.f || float(a.time) - q[7] > float(a.time_delta));     // :43-48
+        const PV3 h = xform3(a.t_inv, p);                                                           // index_map.vert:38
+        draw = !(h.z > a.max_depth || h.z < 0.f || float(a.time) - t_last > float(a.time_delta));   // :43-48
         const float camx = a.cx * 4.f, camy = a.cy * 4.f, camz = a.fx * 4.f, camw = a.fy * 4.f;     // IndexMap.cpp:136-139
         const float fcols = float(a.cols) * 4.f, frows = float(a.rows) * 4.f;
         const float ndc_x = ((((camz * h.x) / h.z) + camx) - (fcols * 0.5f)) / (fcols * 0.5f);      // :51-52
@@ -148,6 +145,15 @@ __global__ __launch_bounds__(256) void sf_index_splat_kernel(const FuseArgs *tab
         if (lane == src) __hip_atomic_fetch_or(as_global(a.occ) + w, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         rem &= ~__ballot(mine);
     }
+}
+// the index image of the model as it stands (a.src): first predictIndices
+__global__ __launch_bounds__(256) void sf_index_splat_kernel(const FuseArgs *tab) {
+    const FuseArgs &a = tab[blockIdx.y];
+    if ((int)blockIdx.x * 256 >= a.count) return;  // a workgroup of a larger map of the batch
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const bool live = s < a.count;
+    const auto q = as_global(a.src) + (size_t)(live ? s : 0) * 12;  // typed global pointers: global_load, not flat_load
+    index_splat_lane(a, s, live, PV3{q[0], q[1], q[2]}, q[7]);
 }
 __global__ __launch_bounds__(256) void sf_index_export_kernel(const unsigned long long *keys, unsigned *out, int W4, int H4) {  // -> row-major
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -325,13 +331,15 @@ __global__ __launch_bounds__(64) void sf_fuse_data_kernel(const FuseArgs *tab) {
 }
 
 // ---- GlobalModel::fuse, merge (update.vert): src -> dst for every model surfel ----------------------------------
+// ... and, in the same pass, the index image of the MERGED model (second predictIndices, Reconstruction.cpp:300): the key image
+// was cleared by sf_index_clear_kernel after the association read it
 __global__ __launch_bounds__(256) void sf_fuse_update_kernel(const FuseArgs *tab) {
     const FuseArgs &a = tab[blockIdx.y];
+    if ((int)blockIdx.x * 256 >= a.count) return;  // a workgroup of a larger map of the batch
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= a.count) return;
-    const auto q = as_global(a.src) + (size_t)s * 12;
-    const auto o = as_global(a.dst) + (size_t)s * 12;
-    const unsigned w_ = as_global((const unsigned *)a.winner)[s];
+    const bool live = s < a.count;
+    const auto q = as_global(a.src) + (size_t)(live ? s : 0) * 12;
+    const unsigned w_ = live ? as_global((const unsigned *)a.winner)[s] : SF_FUSE_NONE;
     float v[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) v[k] = q[k];
@@ -349,31 +357,27 @@ __global__ __launch_bounds__(256) void sf_fuse_update_kernel(const FuseArgs *tab
         if (d[11] < (1.0f + 0.5f) * v[11]) {
             const float w = hist * c_k, den = hist * c_k + aa;
             const PV3 oldCol = decode_color3(v[4]), newCol = decode_color3(d[4]);
-            o[0] = ((w * v[0]) + (aa * d[0])) / den;
-            o[1] = ((w * v[1]) + (aa * d[1])) / den;
-            o[2] = ((w * v[2]) + (aa * d[2])) / den;
-            o[3] = c_k1;
-            o[4] = encode_color3(((w * oldCol.x) + (aa * newCol.x)) / den, ((w * oldCol.y) + (aa * newCol.y)) / den,
-                                 ((w * oldCol.z) + (aa * newCol.z)) / den);
-            o[5] = hist + 1.0f;
-            o[6] = v[6];
-            o[7] = float(a.time);
             const PV3 n = pnormalize(PV3{((w * v[8]) + (aa * d[8])) / den, ((w * v[9]) + (aa * d[9])) / den, ((w * v[10]) + (aa * d[10])) / den});
-            o[8] = n.x; o[9] = n.y; o[10] = n.z;
-            o[11] = ((w * v[11]) + (aa * d[11])) / den;
-        } else {
-            v[3] = c_k1;
-            v[5] = hist + 1.0f;
-            v[7] = float(a.time);
-#pragma unroll
-            for (int k = 0; k < 12; k++) o[k] = v[k];
+            v[11] = ((w * v[11]) + (aa * d[11])) / den;
+            v[0] = ((w * v[0]) + (aa * d[0])) / den;
+            v[1] = ((w * v[1]) + (aa * d[1])) / den;
+            v[2] = ((w * v[2]) + (aa * d[2])) / den;
+            v[4] = encode_color3(((w * oldCol.x) + (aa * newCol.x)) / den, ((w * oldCol.y) + (aa * newCol.y)) / den,
+                                 ((w * oldCol.z) + (aa * newCol.z)) / den);
+            v[8] = n.x; v[9] = n.y; v[10] = n.z;
         }
-    } else {
+        v[3] = c_k1;
+        v[5] = hist + 1.0f;
+        v[7] = float(a.time);
+    }
+    if (live) {
+        const auto o = as_global(a.dst) + (size_t)s * 12;
 #pragma unroll
         for (int k = 0; k < 12; k++) o[k] = v[k];
     }
     const unsigned long long mg = __ballot(w_ != SF_FUSE_NONE);
     if ((threadIdx.x & 63) == 0 && mg) atomicAdd(a.result + 4, (int)__popcll(mg));
+    index_splat_lane(a, s, live, PV3{v[0], v[1], v[2]}, v[7]);
 }
 
 // ---- GlobalModel::clean (copy_unstable.vert): element e of [merged model (in dst) ..., candidates ...] ------------

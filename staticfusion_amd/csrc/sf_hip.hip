@@ -1148,11 +1148,10 @@ int sf_map_fuse_frames(sf_handle *h, int n, const int *streams, sf_map *const *m
         const unsigned begin_blocks = std::max(key_blocks, surfel_blocks);
         const unsigned clean_blocks = (unsigned)((max_elems + SF_CLEAN_BLOCK - 1) / SF_CLEAN_BLOCK);
         hipLaunchKernelGGL(sf_fuse_begin_kernel, dim3(begin_blocks, nm), dim3(256), 0, h->stream, tab);                        // :284
-        if (max_count) hipLaunchKernelGGL(sf_index_splat_kernel, dim3(surfel_blocks, nm), dim3(256), 0, h->stream, tab, 0);
+        if (max_count) hipLaunchKernelGGL(sf_index_splat_kernel, dim3(surfel_blocks, nm), dim3(256), 0, h->stream, tab);
         if (max_cand) hipLaunchKernelGGL(sf_fuse_data_kernel, dim3((max_cand + 63) / 64, nm), dim3(64), 0, h->stream, tab);   // :286-298
-        if (max_count) hipLaunchKernelGGL(sf_fuse_update_kernel, dim3(surfel_blocks, nm), dim3(256), 0, h->stream, tab);
         hipLaunchKernelGGL(sf_index_clear_kernel, dim3(key_blocks, nm), dim3(256), 0, h->stream, tab);                        // :300
-        if (max_count) hipLaunchKernelGGL(sf_index_splat_kernel, dim3(surfel_blocks, nm), dim3(256), 0, h->stream, tab, 1);
+        if (max_count) hipLaunchKernelGGL(sf_fuse_update_kernel, dim3(surfel_blocks, nm), dim3(256), 0, h->stream, tab);       // merge + index image of the result
         if (clean_blocks) {                                                                                                    // :302-311
             hipLaunchKernelGGL(sf_clean_flag_kernel, dim3(clean_blocks, nm), dim3(SF_CLEAN_BLOCK), 0, h->stream, tab);
             hipLaunchKernelGGL(sf_clean_scan_kernel, dim3(nm), dim3(1024), 0, h->stream, tab);

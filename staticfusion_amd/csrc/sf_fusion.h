@@ -5,8 +5,10 @@
 //   GlobalModel::clean        GlobalModel.cpp:494-601  Shaders/copy_unstable.vert / .geom
 //
 // What GL does with rasterisation, render targets and transform feedback becomes:
-//   * index image: one lane per surfel, ONE 64-bit atomicMin on key = bits(window depth) << 32 | surfel index into a
-//     4 rows x 4 cols key image (in-order GL_LESS: nearest wins, the earlier surfel wins a tie). The reference also
+//   * index image: one lane per surfel, ONE 64-bit atomicMin on key = epoch tag | window depth | surfel index into a
+//     4 rows x 4 cols key image (in-order GL_LESS: nearest wins, the earlier surfel wins a tie; a later image's tag is
+//     smaller, so it overwrites whatever an earlier image left: the 9.8 MB image is never cleared, only its 153 KB of
+//     occupancy bits, and readers look at occupied texels only). The reference also
 //     renders the surfel's camera-frame position / colour-time / normal-radius into three RGBA32F images (184 MB of
 //     render targets at QVGA x 4); here the consumers recompute them from the winning surfel: same operations, same bits.
 //   * data association: only pixels with (x, y) % 2 == tick % 2 can emit (data.vert:114), so one lane per CANDIDATE
@@ -44,6 +46,7 @@ struct FuseArgs {
     unsigned long long *keys;  // 4 rows x 4 cols, column-major
     unsigned long long *occ;   // occupancy bits of the key image: column tu owns occ_words words, bit tv of them = a surfel was drawn there
     int occ_words;             // ceil(4 rows / 64)
+    unsigned tag_first, tag_merged;  // epoch tags (top byte of the keys) of the two index images of this fuse
     unsigned *winner;          // [count]
     // candidates: pixels (2 i' + par, 2 j' + par), order index q = j' + i' * cand_rows
     int par, cand_rows, cand_cols, n_cand;
@@ -85,14 +88,12 @@ __device__ __forceinline__ PV3 decode_color3(float c) {
 __global__ __launch_bounds__(256) void sf_index_clear_kernel(const FuseArgs *tab) {
     const FuseArgs &a = tab[blockIdx.y];
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (o < (size_t)a.rows * a.cols * 16) a.keys[o] = SF_PRED_EMPTY;
-    if (o < (size_t)a.cols * 4 * a.occ_words) a.occ[o] = 0ull;
+    if (o < (size_t)a.cols * 4 * a.occ_words) a.occ[o] = 0ull;  // the keys themselves stay: the next image's tag beats them
 }
 // start of a fuse: clear the index image, the update-map winners and the counters in one launch
 __global__ __launch_bounds__(256) void sf_fuse_begin_kernel(const FuseArgs *tab) {
     const FuseArgs &a = tab[blockIdx.y];
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (o < (size_t)a.rows * a.cols * 16) a.keys[o] = SF_PRED_EMPTY;
     if (o < (size_t)a.cols * 4 * a.occ_words) a.occ[o] = 0ull;
     if (o < (size_t)a.count) a.winner[o] = SF_FUSE_NONE;
     if (o < 8) a.result[o] = 0;
@@ -107,7 +108,7 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) 
 }
 // index_map.vert + the depth test for surfel s at world position p with last-seen time t_last; every lane of the wave calls it
 // (live = false: nothing to draw)
-__device__ __forceinline__ void index_splat_lane(const FuseArgs &a, int s, bool live, PV3 p, float t_last) {
+__device__ __forceinline__ void index_splat_lane(const FuseArgs &a, unsigned tag, int s, bool live, PV3 p, float t_last) {
     const int W4 = a.cols * 4, H4 = a.rows * 4;
     bool draw = live;
     int px = 0, py = 0;
@@ -126,8 +127,8 @@ __device__ __forceinline__ void index_splat_lane(const FuseArgs &a, int s, bool 
         if (draw) {
             px = int(fx_);
             py = int(fy_);
-            const float depth = ndc_z * 0.5f + 0.5f;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned)s;
+            const float depth = ndc_z * 0.5f + 0.5f;  // in [0.5, 1]: bit patterns 0x3f000000 .. 0x3f800000, 24 bits after the offset
+            const unsigned long long key = ((unsigned long long)tag << 56) | ((unsigned long long)(__float_as_uint(depth) - 0x3f000000u) << 32) | (unsigned)s;
             __hip_atomic_fetch_min(as_global(a.keys) + (size_t)px * H4 + py, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // column-major key image
         }
     }
@@ -153,14 +154,15 @@ __global__ __launch_bounds__(256) void sf_index_splat_kernel(const FuseArgs *tab
     const int s = blockIdx.x * 256 + threadIdx.x;
     const bool live = s < a.count;
     const auto q = as_global(a.src) + (size_t)(live ? s : 0) * 12;  // typed global pointers: global_load, not flat_load
-    index_splat_lane(a, s, live, PV3{q[0], q[1], q[2]}, q[7]);
+    index_splat_lane(a, a.tag_first, s, live, PV3{q[0], q[1], q[2]}, q[7]);
 }
-__global__ __launch_bounds__(256) void sf_index_export_kernel(const unsigned long long *keys, unsigned *out, int W4, int H4) {  // -> row-major
+__global__ __launch_bounds__(256) void sf_index_export_kernel(const unsigned long long *keys, const unsigned long long *occ, int occ_words, unsigned *out,
+                                                              int W4, int H4) {  // -> row-major
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= (size_t)W4 * H4) return;
     const int tv = (int)(o / W4), tu = (int)(o - (size_t)tv * W4);
-    const unsigned long long key = keys[(size_t)tu * H4 + tv];
-    out[o] = key == SF_PRED_EMPTY ? 0u : (unsigned)(key & 0xffffffffull);
+    const bool occupied = (occ[(size_t)tu * occ_words + (tv >> 6)] >> (tv & 63)) & 1ull;
+    out[o] = occupied ? (unsigned)(keys[(size_t)tu * H4 + tv] & 0xffffffffull) : 0u;
 }
 
 // what the index image's other three textures hold for surfel idx (index_map.vert:56-59)
@@ -282,8 +284,7 @@ __global__ __launch_bounds__(64) void sf_fuse_data_kernel(const FuseArgs *tab) {
             while (bits) {
                 const int k = __ffs((int)bits) - 1;
                 bits &= bits - 1u;
-                const unsigned long long key = g_keys[(size_t)tu * H4 + vr.lo + k];
-                const unsigned current = key == SF_PRED_EMPTY ? 0u : (unsigned)(key & 0xffffffffull);
+                const unsigned current = (unsigned)(g_keys[(size_t)tu * H4 + vr.lo + k] & 0xffffffffull);  // occupied: a key of this image
                 if (current > 0U) {
                     const IndexTexelD t = index_texel_pos(a, g_src, current);
                     if (fabsf((t.pos.z * lambda) - (vPosLocal.z * lambda)) < 0.05f) {
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(256) void sf_fuse_update_kernel(const FuseArgs *tab
     }
     const unsigned long long mg = __ballot(w_ != SF_FUSE_NONE);
     if ((threadIdx.x & 63) == 0 && mg) atomicAdd(a.result + 4, (int)__popcll(mg));
-    index_splat_lane(a, s, live, PV3{v[0], v[1], v[2]}, v[7]);
+    index_splat_lane(a, a.tag_merged, s, live, PV3{v[0], v[1], v[2]}, v[7]);
 }
 
 // ---- GlobalModel::clean (copy_unstable.vert): element e of [merged model (in dst) ..., candidates ...] ------------
@@ -436,8 +437,7 @@ __global__ __launch_bounds__(SF_CLEAN_BLOCK) void sf_clean_flag_kernel(const Fus
                         const int k = __ffs((int)bits) - 1;
                         bits &= bits - 1u;
                         const int mult = mu * (int)((vr.mult >> (5 * k)) & 31ull);
-                        const unsigned long long key = g_keys[(size_t)tu * H4 + vr.lo + k];
-                        const unsigned current = key == SF_PRED_EMPTY ? 0u : (unsigned)(key & 0xffffffffull);
+                        const unsigned current = (unsigned)(g_keys[(size_t)tu * H4 + vr.lo + k] & 0xffffffffull);  // occupied: a key of this image
                         if (current > 0U) {
                             const IndexTexelD t = index_texel_pos(a, g_dst, current);
                             const float dx = t.pos.x - localPos.x, dy = t.pos.y - localPos.y;

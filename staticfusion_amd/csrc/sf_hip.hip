@@ -1008,6 +1008,7 @@ struct sf_map {
     unsigned char *flags = nullptr;
     int *block_counts = nullptr;
     bool have_index = false;
+    int epoch = 0;  // index images rendered since the key image was last filled with ones; tag = 255 - epoch
     std::vector<void *> allocs;
 };
 static int map_alloc_bytes(sf_map *m, void **p, size_t bytes) {
@@ -1033,6 +1034,7 @@ int sf_map_create(sf_handle *h, int capacity, sf_map **out) {
     if (!e) e = map_alloc(m, &m->buf[0], cap * 12);
     if (!e) e = map_alloc(m, &m->buf[1], cap * 12);
     if (!e) e = map_alloc(m, &m->keys, n0 * 16);
+    if (!e && hipMemset(m->keys, 0xff, n0 * 16 * sizeof(unsigned long long)) != hipSuccess) e = fail(SF_ERR_DEVICE, "hipMemset");
     if (!e) e = map_alloc(m, &m->occ, (size_t)h->k.cols * 4 * ((h->k.rows * 4 + 63) / 64));
     if (!e) e = map_alloc(m, &m->index_export, n0 * 16);
     if (!e) e = map_alloc(m, &m->winner, cap);
@@ -1120,6 +1122,12 @@ int sf_map_fuse_frames(sf_handle *h, int n, const int *streams, sf_map *const *m
         a.count = m->count; a.capacity = m->capacity;
         a.keys = m->keys; a.winner = m->winner;
         a.occ = m->occ; a.occ_words = (a.rows * 4 + 63) / 64;
+        if (m->epoch + 2 > 255) {  // the 8-bit tag is used up: one real clear, then count again
+            HIP_TRY(hipMemsetAsync(m->keys, 0xff, npx * 16 * sizeof(unsigned long long), h->stream));
+            m->epoch = 0;
+        }
+        a.tag_first = 255u - (unsigned)(m->epoch + 1); a.tag_merged = 255u - (unsigned)(m->epoch + 2);
+        m->epoch += 2;
         a.par = m->tick % 2;
         a.cand_rows = (a.rows - a.par + 1) / 2; a.cand_cols = (a.cols - a.par + 1) / 2;
         a.n_cand = a.cand_rows * a.cand_cols;
@@ -1142,15 +1150,14 @@ int sf_map_fuse_frames(sf_handle *h, int n, const int *streams, sf_map *const *m
     if (!fuse.empty()) {
         const FuseArgs *tab = (const FuseArgs *)((const unsigned char *)dev + init_bytes);
         const unsigned nm = (unsigned)fuse.size();
-        const size_t n_keys = npx * 16;
-        const unsigned key_blocks = (unsigned)((n_keys + 255) / 256);
         const unsigned surfel_blocks = (unsigned)((max_count + 255) / 256);
-        const unsigned begin_blocks = std::max(key_blocks, surfel_blocks);
+        const unsigned occ_blocks = (unsigned)(((size_t)h->k.cols * 4 * ((h->k.rows * 4 + 63) / 64) + 255) / 256);
+        const unsigned begin_blocks = std::max(occ_blocks, surfel_blocks);
         const unsigned clean_blocks = (unsigned)((max_elems + SF_CLEAN_BLOCK - 1) / SF_CLEAN_BLOCK);
         hipLaunchKernelGGL(sf_fuse_begin_kernel, dim3(begin_blocks, nm), dim3(256), 0, h->stream, tab);                        // :284
         if (max_count) hipLaunchKernelGGL(sf_index_splat_kernel, dim3(surfel_blocks, nm), dim3(256), 0, h->stream, tab);
         if (max_cand) hipLaunchKernelGGL(sf_fuse_data_kernel, dim3((max_cand + 63) / 64, nm), dim3(64), 0, h->stream, tab);   // :286-298
-        hipLaunchKernelGGL(sf_index_clear_kernel, dim3(key_blocks, nm), dim3(256), 0, h->stream, tab);                        // :300
+        hipLaunchKernelGGL(sf_index_clear_kernel, dim3(occ_blocks, nm), dim3(256), 0, h->stream, tab);                        // :300
         if (max_count) hipLaunchKernelGGL(sf_fuse_update_kernel, dim3(surfel_blocks, nm), dim3(256), 0, h->stream, tab);       // merge + index image of the result
         if (clean_blocks) {                                                                                                    // :302-311
             hipLaunchKernelGGL(sf_clean_flag_kernel, dim3(clean_blocks, nm), dim3(SF_CLEAN_BLOCK), 0, h->stream, tab);
@@ -1234,8 +1241,8 @@ int sf_map_get_index_map(sf_map *m, uint32_t *out) {
     if (!m->have_index) return fail(SF_ERR_STATE, "no index map yet (sf_map_fuse_frame with tick > 1 renders it)");
     HIP_TRY(hipSetDevice(m->h->device));
     const size_t n = m->h->k.n0 * 16;
-    hipLaunchKernelGGL(sf_index_export_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->h->stream, m->keys, m->index_export, m->h->k.cols * 4,
-                       m->h->k.rows * 4);
+    hipLaunchKernelGGL(sf_index_export_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->h->stream, m->keys, m->occ,
+                       (m->h->k.rows * 4 + 63) / 64, m->index_export, m->h->k.cols * 4, m->h->k.rows * 4);
     HIP_TRY(hipGetLastError());
     return d2h(m->h, out, m->index_export, n * sizeof(uint32_t));
 }

@@ -407,6 +407,40 @@ def test_hip_fusion_other_frame_sizes(hip, ora, rows, cols):
 
 
 @pytest.mark.gpu
+def test_hip_index_image_epoch_tags_wrap(hip, ora):
+    """the key image is never cleared: each index image carries a smaller 8-bit tag than the one before, and after 255 images
+    (127 fuses) the map does one real clear and starts over -- 140 fuses of a small frame, HIP == oracle before, at and after it"""
+    rows, cols = 120, 160
+    res = []
+    for api in (hip, ora):
+        p = driver_params(api)
+        p.ctf_levels = 2
+        s = make_solver(api, rows, cols, p)
+        m = SurfelMap(s)
+        depth, rgb = synthetic_view(np.eye(4), sphere=True)
+        depth, rgb = depth[::2, ::2][:rows, :cols], rgb[::2, ::2][:rows, :cols]
+        full_d = np.ascontiguousarray(np.repeat(np.repeat(np.clip(np.rint(depth[::-1] * 1000), 0, 65535).astype(np.uint16), 2, 0), 2, 1))
+        full_c = np.ascontiguousarray(np.repeat(np.repeat(rgb[::-1], 2, 0), 2, 1))
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        labels = (((xx // 20) + 8 * (yy // 20)) % 24).astype(np.int32)
+        s.load_frame(0, full_c, full_d, 2)
+        s.filter_depth()
+        s.set_segm_state(0, labels, np.linspace(0.3, 1.0, 24).astype(np.float32), np.ones(24, np.float32))
+        s.build_segm_image()
+        wiggle = [se3_exp(np.array([0.002, 0, 0, 0, 0.001, 0])), se3_exp(-np.array([0.002, 0, 0, 0, 0.001, 0]))]
+        snaps = []
+        for k in range(140):
+            m.fuse_frame(0, None if k == 0 else wiggle[k % 2])
+            if k in (1, 125, 126, 127, 128, 129, 139):
+                snaps.append((m.info(), m.download(), m.index_map()))
+        res.append(snaps)
+    for (ih, sh, xh), (io_, so, xo) in zip(*res):
+        assert ih["count"] == io_["count"] and ih["stats"] == io_["stats"], (ih, io_)
+        assert same_bits(sh, so) and np.array_equal(xh, xo), ih["tick"]
+    assert res[1][-1][0]["tick"] == 141 and res[1][-1][0]["stats"][1] > 3000
+
+
+@pytest.mark.gpu
 def test_hip_fusion_on_a_permuted_map(hip, ora):
     """the kernels lean on the map's point order for locality only: a map whose surfels were shuffled (uploaded that way on both
     sides) fuses to the same bits as the oracle's"""

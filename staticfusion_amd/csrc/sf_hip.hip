@@ -68,6 +68,8 @@ struct sf_handle {
     int *pr_dense = nullptr;                // per batched map: 2 ints (density sum; init-model counts)
     size_t pr_maps = 0;                     // how many maps the two blocks above are sized for
     bool pr_rendered = false;
+    vfloat4 *pr_rays = nullptr;             // view ray per pixel for the intrinsics below (sf_predict_rays_kernel)
+    float pr_rays_for[4] = {0.f, 0.f, 0.f, 0.f};
     float *pr_surfels = nullptr;
     size_t pr_capacity = 0;
     // argument tables of the batched map kernels (sf_predict.h, sf_fusion.h): device block + the host copy it is filled from
@@ -872,6 +874,13 @@ static int predict_batch(sf_handle *h, const std::vector<PredictJob> &jobs, cons
     if (!(p->conf_low <= p->conf_high)) return fail(SF_ERR_ARG, "conf_low must not exceed conf_high");
     if (jobs.empty()) return SF_OK;
     if (int e = predict_scratch(h, jobs.size())) return e;
+    if (!h->pr_rays)
+        if (int e = dev_alloc(h, &h->pr_rays, n)) return e;
+    if (h->pr_rays_for[0] != p->cx || h->pr_rays_for[1] != p->cy || h->pr_rays_for[2] != p->fx || h->pr_rays_for[3] != p->fy) {
+        hipLaunchKernelGGL(sf_predict_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->pr_rays, h->k.rows, h->k.cols, p->cx, p->cy,
+                           p->fx, p->fy);
+        h->pr_rays_for[0] = p->cx; h->pr_rays_for[1] = p->cy; h->pr_rays_for[2] = p->fx; h->pr_rays_for[3] = p->fy;
+    }
     std::vector<PredictArgs> tab(jobs.size());
     int max_count = 0;
     for (size_t q = 0; q < jobs.size(); q++) {
@@ -891,6 +900,7 @@ static int predict_batch(sf_handle *h, const std::vector<PredictJob> &jobs, cons
         a.b_img = h->k.b_img + (size_t)j.stream * n;
         a.depth_pred = h->k.pyr_pred[0] + (size_t)j.stream * h->k.n_tot;
         a.inten_pred = h->k.pyr_pred[1] + (size_t)j.stream * h->k.n_tot;
+        a.rays = h->pr_rays;
     }
     void *dev = nullptr;
     if (int e = upload_table(h, tab.data(), tab.size() * sizeof(PredictArgs), &dev)) return e;

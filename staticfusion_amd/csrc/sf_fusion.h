@@ -124,10 +124,11 @@ __device__ __forceinline__ void index_splat_lane(const FuseArgs &a, unsigned tag
         const float xw = (ndc_x + 1.f) * (fcols * 0.5f), yw = (ndc_y + 1.f) * (frows * 0.5f);
         const float fx_ = floorf(xw), fy_ = floorf(yw);
         draw = draw && (fx_ >= 0.f && fx_ < float(W4) && fy_ >= 0.f && fy_ < float(H4));
+        const float depth = ndc_z * 0.5f + 0.5f;  // in [0.5, 1]: bit patterns 0x3f000000 .. 0x3f800000, 24 bits after the offset
+        draw = draw && depth < 1.0f;              // GL_LESS against the cleared depth buffer (1.0): a surfel AT maxDepth is not drawn
         if (draw) {
             px = int(fx_);
             py = int(fy_);
-            const float depth = ndc_z * 0.5f + 0.5f;  // in [0.5, 1]: bit patterns 0x3f000000 .. 0x3f800000, 24 bits after the offset
             const unsigned long long key = ((unsigned long long)tag << 56) | ((unsigned long long)(__float_as_uint(depth) - 0x3f000000u) << 32) | (unsigned)s;
             __hip_atomic_fetch_min(as_global(a.keys) + (size_t)px * H4 + py, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // column-major key image
         }

@@ -71,7 +71,7 @@ __device__ __forceinline__ bool surfel_fragment(const PredictArgs &a, PV3 h, PV3
     if (pdot(diff, diff) > rad * rad) return false;
     z = corrected.z;
     depth = (corrected.z / (2.f * a.max_depth)) + 0.5f;
-    return depth >= 0.f && depth <= 1.f;
+    return depth >= 0.f && depth < 1.f;  // depth range clip, and GL_LESS against the cleared depth 1.0: a fragment AT 1.0 fails
 }
 
 __global__ __launch_bounds__(256) void sf_predict_rays_kernel(vfloat4 *rays, int rows, int cols, float cx, float cy, float fx, float fy) {

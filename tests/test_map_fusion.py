@@ -407,6 +407,45 @@ def test_hip_fusion_other_frame_sizes(hip, ora, rows, cols):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [int(x) for x in __import__("os").environ.get("SF_FUSION_HUNT", "0,13,26,38,5,8").split(",")])
+def test_hip_fusion_randomised_settings(hip, ora, case):
+    """random b per cluster, motion, weight multiplier, confidence threshold; a SHORT time window (surfels age out of the index
+    image and of the cleaning) and maxDepth = 3 m, where the room's far wall sits: a surfel whose window depth rounds to
+    exactly 1.0 fails GL_LESS against the cleared depth buffer and is not drawn (cases 0, 13, 26, 38 caught the HIP path
+    drawing it). SF_FUSION_HUNT=0,1,2,... runs other cases of the generator; 0..139 were run once: all bit-identical."""
+    rng = np.random.default_rng(7000 + case)
+    b = rng.uniform(0, 1, 24).astype(np.float32)
+    xi = XI * rng.uniform(0.2, 4.0) * rng.choice([-1, 1], 6)
+    sphere = bool(case % 2)
+    conf, wm = float(rng.uniform(0.1, 0.6)), float(rng.uniform(0.3, 1.0))
+    res = []
+    for api in (hip, ora):
+        s = make_solver(api, ROWS, COLS, driver_params(api))
+        m = SurfelMap(s)
+        mp = s.default_model_params()
+        mp.time_delta = [2, 5, 2147483647][case % 3]
+        mp.conf_high = conf
+        mp.max_depth = [3.0, 20.0][(case // 3) % 2]
+        mp.conf_low = min(mp.conf_low, mp.conf_high)
+        T = np.eye(4)
+        frames = []
+        for k in range(5):
+            depth, rgb = synthetic_view(T, sphere=sphere)
+            load_view(s, depth, rgb, b)
+            m.fuse_frame(0, None if k == 0 else se3_exp(xi), wm, mp)
+            m.predict(0, mp)
+            frames.append((m.info(), m.download(), m.index_map() if k else None, s.prediction()))
+            T = T @ se3_exp(xi)
+        res.append(frames)
+    for k, ((ih, sh, xh, ph), (io_, so, xo, po)) in enumerate(zip(*res)):
+        assert ih["count"] == io_["count"] and ih["stats"] == io_["stats"], (k, ih, io_)
+        assert same_bits(sh, so), k
+        if k:
+            assert np.array_equal(xh, xo), k
+        assert same_bits(ph[0], po[0]) and same_bits(ph[1], po[1]), k
+
+
+@pytest.mark.gpu
 def test_hip_index_image_epoch_tags_wrap(hip, ora):
     """the key image is never cleared: each index image carries a smaller 8-bit tag than the one before, and after 255 images
     (127 fuses) the map does one real clear and starts over -- 140 fuses of a small frame, HIP == oracle before, at and after it"""

@@ -111,6 +111,17 @@ def test_oracle_single_surfel_and_fill_in(ora):
     surf[0, 3] = 0.1
     s.predict_from_model(0, surf, np.eye(4))
     assert (s.prediction()[0] > 0).sum() == 0
+    # (3b) GL_LESS against the cleared depth buffer: gl_FragDepth = z / (2 maxDepth) + 0.5 reaches 1.0 AT maxDepth -> not drawn
+    near = mp.max_depth
+    mp.max_depth = 2.0
+    surf[0, 3] = 0.5
+    s.predict_from_model(0, surf, np.eye(4), mp)  # z = 2.0 = maxDepth: passes the cull (z > maxDepth is false), fails the depth test
+    assert (s.prediction()[0] > 0).sum() == 0
+    surf[0, 2] = np.float32(1.9999)
+    s.predict_from_model(0, surf, np.eye(4), mp)
+    assert (s.prediction()[0] > 0).sum() > 0
+    surf[0, 2] = 2.0
+    mp.max_depth = near
     # (4) a nearer surfel hides a farther one; beyond extract_max_depth nothing is reported
     two = np.repeat(surf, 2, 0)
     two[:, 3] = 0.5

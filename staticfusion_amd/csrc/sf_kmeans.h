@@ -294,62 +294,58 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
                 old[k] = valid[k] ? old[k] : 0;  // a safe table row for pixels that are not searched
             }
             km_search_n<SF_LOAD_BATCH>(s, old, pz, px, py, valid, best);
-            // members of this wave's part of the chunk per label (lane l < 24 holds the count of label l)
+            // members of this wave's part of the chunk per label (lane l < 24 holds the count of label l), and for every
+            // pixel its rank among the wave's members of the same label in pixel order (k-major, then lane): one pass of
+            // ballots gives both
             int cnt = 0;
+            int rank[SF_LOAD_BATCH];
 #pragma unroll
             for (int k = 0; k < SF_LOAD_BATCH; k++) {
                 const int idx = base + k * 64 + lane;
+                rank[k] = 0;
                 if (valid[k]) labels[o1 + idx] = (uint8_t)best[k];
                 unsigned long long rem = __ballot(valid[k]);
                 while (rem) {
                     const int src = __ffsll((long long)rem) - 1;
                     const int l = __builtin_amdgcn_readlane(best[k], src);
                     const unsigned long long m = __ballot(valid[k] && best[k] == l);
+                    const int start = __builtin_amdgcn_readlane(cnt, l);  // members of label l among the wave's earlier pixels
+                    if (valid[k] && best[k] == l) rank[k] = start + __popcll(m & ((1ull << lane) - 1ull));
                     if (lane == l) cnt += __popcll(m);
                     rem &= ~m;
                 }
             }
             if (lane < SF_NC) s.wcnt[wave][lane] = cnt;
             __syncthreads();  // also: the previous chunk's sums have consumed s.chunk
-            if (tid < SF_NC) {  // exclusive offsets over the waves, chunk totals
+            if (tid < 64) {  // wave 0: exclusive offsets over the waves per label, then over the labels (a 24-lane scan)
                 int run = 0;
-                for (int w = 0; w < SF_NW; w++) {
-                    const int c = s.wcnt[w][tid];
-                    s.wcnt[w][tid] = run;
-                    run += c;
+                if (tid < SF_NC)
+                    for (int w = 0; w < SF_NW; w++) {
+                        const int c = s.wcnt[w][tid];
+                        s.wcnt[w][tid] = run;
+                        run += c;
+                    }
+                int incl = run;
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) {
+                    const int up = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += up;
                 }
-                s.ccount[tid] = run;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int run = 0;
-                for (int l = 0; l < SF_NC; l++) {
-                    s.off[l] = run;
-                    run += s.ccount[l];
+                if (tid < SF_NC) {
+                    s.ccount[tid] = run;
+                    s.off[tid] = incl - run;
                 }
             }
             __syncthreads();
             // stable positions: cluster run start + members in earlier waves + members earlier in this wave
-            int running = (lane < SF_NC) ? (s.off[lane] + s.wcnt[wave][lane]) : 0;
 #pragma unroll
-            for (int k = 0; k < SF_LOAD_BATCH; k++) {  // ascending pixel order: ranks stay stable
-                const int lab = valid[k] ? best[k] : 0;
-                unsigned long long rem = __ballot(valid[k]);
-                while (rem) {
-                    const int src = __ffsll((long long)rem) - 1;
-                    const int l = __builtin_amdgcn_readlane(lab, src);
-                    const unsigned long long m = __ballot(valid[k] && lab == l);
-                    const int start = __builtin_amdgcn_readlane(running, l);
-                    if (valid[k] && lab == l) {
-                        const int pos = start + __popcll(m & ((1ull << lane) - 1ull));
-                        s.chunk[0][pos] = pz[k];
-                        s.chunk[1][pos] = px[k];
-                        s.chunk[2][pos] = py[k];
-                    }
-                    if (lane == l) running += __popcll(m);
-                    rem &= ~m;
+            for (int k = 0; k < SF_LOAD_BATCH; k++)
+                if (valid[k]) {
+                    const int pos = s.off[best[k]] + s.wcnt[wave][best[k]] + rank[k];
+                    s.chunk[0][pos] = pz[k];
+                    s.chunk[1][pos] = px[k];
+                    s.chunk[2][pos] = py[k];
                 }
-            }
             __syncthreads();
             if (tid < 3 * SF_NC) {  // the ordered sums, continued over this chunk's members
                 const int c = tid / 3, r = tid - 3 * c;

@@ -3,6 +3,6 @@
 A=$1; B=$2; WL=${3:-static}; R=${4:-3}
 for i in $(seq $R); do
   for lib in $A $B; do
-    echo -n "$lib: "; SF_HIP_LIB=$lib timeout 100 python tools/stage_profile.py --batch 4096 --workload $WL | grep workload
+    echo -n "$lib: "; SF_HIP_LIB=$lib timeout 100 python tools/stage_profile.py --batch ${BATCH:-4096} --workload $WL | grep workload
   done
 done

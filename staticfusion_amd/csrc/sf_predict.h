@@ -139,6 +139,13 @@ __global__ __launch_bounds__(SF_SPLAT_NT) void sf_predict_splat_kernel(const Pre
                 const float half = size * 0.5f;
                 i0 = max(0, (int)ceilf(xw - half - 0.5f)); i1 = min(a.cols - 1, (int)floorf(xw + half - 0.5f));
                 j0 = max(0, (int)ceilf(yw - half - 0.5f)); j1 = min(a.rows - 1, (int)floorf(yw + half - 0.5f));
+                // The sprite is a SQUARE of the longer extent (splat.vert:85), but a fragment survives only inside the disc
+                // (combo_splat.frag:47), and the disc lies inside the diamond whose corners were just projected: pixels outside
+                // their bounding rectangle (+ 1 pixel against rounding at the rim) would be discarded anyway -- skip them.
+                const float xlo = fminf(p1x, fminf(p2x, fminf(p3x, p4x))), xhi = fmaxf(p1x, fmaxf(p2x, fmaxf(p3x, p4x)));
+                const float ylo = fminf(p1y, fminf(p2y, fminf(p3y, p4y))), yhi = fmaxf(p1y, fmaxf(p2y, fmaxf(p3y, p4y)));
+                i0 = max(i0, (int)floorf(xlo - 1.5f)); i1 = min(i1, (int)ceilf(xhi + 0.5f));
+                j0 = max(j0, (int)floorf(ylo - 1.5f)); j1 = min(j1, (int)ceilf(yhi + 0.5f));
                 valid = i0 <= i1 && j0 <= j1;
             }
         }

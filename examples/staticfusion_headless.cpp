@@ -6,6 +6,10 @@
 //   g++ -std=c++17 -O2 -Iinclude examples/staticfusion_headless.cpp -o staticfusion_headless
 //       -Lstaticfusion_amd/csrc -lsf_hip -lsf_io -Wl,-rpath,$PWD/staticfusion_amd/csrc -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib   (one line)
 //   ./staticfusion_headless <dataset dir>/ [output prefix]      -> <prefix>.freiburg (trajectory), <prefix>.ply (map)
+//
+// Two deliberate differences from the reference's main(): it starts at the association file's FIRST entry (the reference sets
+// im_count = 1, :83, and never reads entry 0), and it writes a trajectory line for the bootstrap frame too (identity), so
+// that the file has one line per frame read.
 #include <cstdio>
 #include <cstdlib>
 #include <limits>

@@ -93,6 +93,54 @@ def test_deterministic_exp_log_and_velocity_weighting(ora):
         assert abs(call(A, B, 0.5) - 0.5 * want) < 1e-5
 
 
+def _fusion_fixture(api):
+    """run the frames of tests/golden/fusion_40x30.npz through an implementation of the ABI"""
+    import os
+    from conftest import GOLDEN
+
+    g = np.load(os.path.join(GOLDEN, "fusion_40x30.npz"))
+    rows, cols, res = int(g["rows"]), int(g["cols"]), int(g["res_factor"])
+    p = driver_params(api)
+    p.ctf_levels = 2
+    s = make_solver(api, rows, cols, p)
+    m = SurfelMap(s)
+    frames = []
+    for k in range(5):
+        s.load_frame(0, g["color_full_%d" % k], g["depth_full_%d" % k], res)
+        s.filter_depth()
+        s.set_segm_state(0, g["labels"], g["b_segm"], np.ones(24, np.float32))
+        s.build_segm_image()
+        m.fuse_frame(0, None if k == 0 else g["increments"][k])
+        frames.append((m.info(), m.download(), m.index_map() if k else None))
+    return g, frames
+
+
+def _check_against_fusion_fixture(g, frames):
+    assert same_bits(frames[0][1], g["map_0"])  # GlobalModel::initialise: an input of the fixture
+    for k in (1, 2, 3, 4):
+        info, surf, index = frames[k]
+        uid, want = g["update_id_%d" % k], g["map_%d" % k]
+        # everything discrete exactly: how many pixels emitted / associated, how many surfels merged, which survive, the index image
+        assert info["stats"] == [uid.size, int((uid == 1).sum()), g["merged_ids_%d" % k].size, want.shape[0]], (k, info["stats"])
+        assert np.array_equal(index, g["index_merged_%d" % k]), k
+        assert surf.shape == want.shape
+        # integers stored in floats: colour, history, times
+        assert np.array_equal(surf[:, 5:8], want[:, 5:8]), k
+        assert (surf[:, 4] != want[:, 4]).mean() < 0.01  # an averaged colour channel may round the other way
+        assert np.allclose(surf[:, 0:4], want[:, 0:4], rtol=0, atol=2e-6), (k, np.abs(surf[:, 0:4] - want[:, 0:4]).max())
+        assert np.allclose(surf[:, 8:12], want[:, 8:12], rtol=0, atol=2e-6), k
+
+
+def test_oracle_matches_the_independent_python_derivation(ora):
+    """tests/golden/fusion_40x30.npz: tools/golden/make_golden_fusion.py restates the four fusion shaders statement by statement
+    in Python float32 scalars (texture fetches through float coordinates, update maps as a dictionary, transform feedback
+    as lists), sharing no code with the oracle"""
+    g, frames = _fusion_fixture(ora)
+    _check_against_fusion_fixture(g, frames)
+    st = [f[0]["stats"] for f in frames]
+    assert st[2][1] < 0.85 * st[2][0] and st[4][3] < st[3][3] + (st[4][0] - st[4][1])  # pixels without a surfel; surfels removed by the cleaning
+
+
 def test_first_fuse_is_global_model_initialise(ora):
     s, m, out = walk(ora, 1)
     info = out[0]["info"]
@@ -326,6 +374,12 @@ def test_batched_calls_equal_single_calls_on_the_oracle(ora):
 # ------------------------------------------------------------------------------------------------
 #  GPU: HIP vs oracle
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_hip_matches_the_independent_python_derivation(hip):
+    g, frames = _fusion_fixture(hip)
+    _check_against_fusion_fixture(g, frames)
+
+
 @pytest.mark.gpu
 def test_hip_batched_fusion_equals_single_calls_and_the_oracle(hip, ora):
     """sf_map_fuse_frames / sf_map_predict_frames: one launch per kernel for three sequences, one of them initialising while the

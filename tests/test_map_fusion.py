@@ -112,7 +112,24 @@ def _fusion_fixture(api):
         s.build_segm_image()
         m.fuse_frame(0, None if k == 0 else g["increments"][k])
         frames.append((m.info(), m.download(), m.index_map() if k else None))
-    return g, frames
+    preds = []
+    for lo, hi in ((None, None), (0.6, 0.95)):  # Reconstruction::getPredictedImages from the final map; the strict one leaves holes to fill in
+        mp = s.default_model_params()
+        if lo is not None:
+            mp.conf_low, mp.conf_high = lo, hi
+        m.predict(0, mp)
+        preds.append(s.prediction() + (s.prediction_dense(),))
+    return g, frames, preds
+
+
+def _check_prediction_against_fixture(g, preds):
+    for (d, i, dense), name in zip(preds, ("", "_strict")):
+        wd, wi = g["pred_depth" + name], g["pred_intensity" + name]
+        assert dense == bool(g["pred_dense" + name])
+        assert np.array_equal(d > 0, wd > 0), name                       # the same pixels drawn / filled / cut at 4.5 m
+        close = np.abs(d - wd) <= 2e-6
+        assert close.mean() > 0.995 and np.abs(d - wd).max() < 0.05, (name, close.mean(), np.abs(d - wd).max())  # a depth tie may fall the other way
+        assert (np.abs(i - wi) <= 2e-6).mean() > 0.99, name
 
 
 def _check_against_fusion_fixture(g, frames):
@@ -135,8 +152,10 @@ def test_oracle_matches_the_independent_python_derivation(ora):
     """tests/golden/fusion_40x30.npz: tools/golden/make_golden_fusion.py restates the four fusion shaders statement by statement
     in Python float32 scalars (texture fetches through float coordinates, update maps as a dictionary, transform feedback
     as lists), sharing no code with the oracle"""
-    g, frames = _fusion_fixture(ora)
+    g, frames, preds = _fusion_fixture(ora)
     _check_against_fusion_fixture(g, frames)
+    _check_prediction_against_fixture(g, preds)
+    assert (preds[1][0] > 0).sum() < (preds[0][0] > 0).sum()
     st = [f[0]["stats"] for f in frames]
     assert st[2][1] < 0.85 * st[2][0] and st[4][3] < st[3][3] + (st[4][0] - st[4][1])  # pixels without a surfel; surfels removed by the cleaning
 
@@ -376,8 +395,9 @@ def test_batched_calls_equal_single_calls_on_the_oracle(ora):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_hip_matches_the_independent_python_derivation(hip):
-    g, frames = _fusion_fixture(hip)
+    g, frames, preds = _fusion_fixture(hip)
     _check_against_fusion_fixture(g, frames)
+    _check_prediction_against_fixture(g, preds)
 
 
 @pytest.mark.gpu

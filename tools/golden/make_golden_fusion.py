@@ -10,6 +10,9 @@ the update maps as a dictionary keyed by texel, transform feedback as Python lis
   update_pass       GlobalModel::fuse, second half GlobalModel.cpp:427-492, Shaders/update.vert
   clean_pass        GlobalModel::clean             GlobalModel.cpp:494-601, Shaders/copy_unstable.vert, copy_unstable.geom
   weighting         Reconstruction::fuseFrame      Reconstruction.cpp:264-282 (rotation vector by scipy instead of rodrigues2)
+  predict_images    Reconstruction::getPredictedImages  Reconstruction.cpp:628-720, IndexMap.cpp:221-300, Shaders/splat.vert,
+                                                   combo_splat.frag, fill_vertex.frag, fill_vertex_from_texture.frag, fill_rgb.frag,
+                                                   extract_depth.frag, Shaders/Resize.cpp + denseEnough (:218-233)
 
 exp / log are NumPy's (the oracle uses include/sf_detmath.h's fmaf sequences), the pose inverse is numpy.linalg.inv: the
 fixture is compared with a small tolerance on the floats and EXACTLY on everything discrete (counts, which pixel merged into
@@ -292,6 +295,96 @@ def clean_pass(vertices, t_inv, cam, time, time_delta, conf_threshold, surf, ind
     return kept, flags
 
 
+def splat_pass(surf, t_inv, cam, time, max_time, time_delta, max_depth, conf_threshold):
+    """IndexMap::combinedPredict for one confidence level: vertex.z and the RGBA8 image of the nearest surfel per pixel.
+    A point sprite covers the pixels whose centres lie within gl_PointSize / 2 of its centre."""
+    cx, cy, fx, fy = cam
+    fc, fr_ = F(COLS), F(ROWS)
+    zimg = np.zeros((ROWS, COLS), F)
+    rgb = np.zeros((ROWS, COLS, 3), np.uint8)
+    zbuf = np.ones((ROWS, COLS), F)
+    for s in range(surf.shape[0]):
+        q = surf[s]
+        h = mat4_point(t_inv, q[0:3])                                      # splat.vert:55
+        if h[2] > max_depth or h[2] < F(0.4) or q[3] < F(conf_threshold) or F(F(time) - q[7]) > F(time_delta) or q[7] > F(max_time):  # :57
+            continue
+        with np.errstate(all="ignore"):
+            ndc_x = F(F(F(F(F(fx * h[0]) / h[2]) + cx) - F(fc * F(0.5))) / F(fc * F(0.5)))   # projectPoint :39-44
+            ndc_y = F(F(F(F(F(fy * h[1]) / h[2]) + cy) - F(fr_ * F(0.5))) / F(fr_ * F(0.5)))
+        if not (-1 <= ndc_x <= 1 and -1 <= ndc_y <= 1):
+            continue
+        xw, yw = F(F(ndc_x + F(1)) * F(fc * F(0.5))), F(F(ndc_y + F(1)) * F(fr_ * F(0.5)))
+        n = normalize(mat3_vec(t_inv, q[8:11]))                            # :68
+        rad = q[11]
+        t = normalize(v3(F(n[1] - n[2]), F(-n[0]), n[0]))
+        x1 = np.array([F(F(t[k] * rad) * F(1.41421356)) for k in range(3)], F)   # :70
+        y1 = cross(n, x1)                                                  # :72
+        def proj(p):                                                       # projectPointImage :46-51
+            with np.errstate(all="ignore"):
+                return F(F(F(fx * p[0]) / p[2]) + cx), F(F(F(fy * p[1]) / p[2]) + cy)
+        pts = [proj((h + x1).astype(F)), proj((h + y1).astype(F)), proj((h - y1).astype(F)), proj((h - x1).astype(F))]
+        x_diff = abs(F(max(p_[0] for p_ in pts) - min(p_[0] for p_ in pts)))
+        y_diff = abs(F(max(p_[1] for p_ in pts) - min(p_[1] for p_ in pts)))
+        size = max(F(0), max(x_diff, y_diff))                              # :85
+        if not size > 0:
+            continue
+        half = F(size * F(0.5))
+        i0, i1 = max(0, int(math.ceil(F(F(xw - half) - F(0.5))))), min(COLS - 1, int(math.floor(F(F(xw + half) - F(0.5)))))
+        j0, j1 = max(0, int(math.ceil(F(F(yw - half) - F(0.5))))), min(ROWS - 1, int(math.floor(F(F(yw + half) - F(0.5)))))
+        pn = dot(h, n)
+        for j in range(j0, j1 + 1):
+            for i in range(i0, i1 + 1):
+                fcx, fcy = F(F(i) + F(0.5)), F(F(j) + F(0.5))              # gl_FragCoord
+                l = normalize(v3(F(F(fcx - cx) / fx), F(F(fcy - cy) / fy), F(1)))   # combo_splat.frag:37
+                with np.errstate(all="ignore"):
+                    k_ = F(pn / dot(l, n))
+                corrected = np.array([F(k_ * l[0]), F(k_ * l[1]), F(k_ * l[2])], F)   # :39
+                diff = (corrected - h).astype(F)
+                if dot(diff, diff) > F(rad * rad):                         # :42-49
+                    continue
+                depth = F(F(corrected[2] / F(F(2) * max_depth)) + F(0.5))   # :63
+                if not (0 <= depth <= 1) or not depth < zbuf[j, i]:
+                    continue
+                zbuf[j, i] = depth
+                zimg[j, i] = corrected[2]
+                col = int(q[4])
+                rgb[j, i] = ((col >> 16) & 0xFF, (col >> 8) & 0xFF, col & 0xFF)
+    return zimg, rgb
+
+
+def predict_images(surf, pose, cam, time, time_delta, max_depth, conf_low, conf_high, extract_max, fr_prev):
+    """Reconstruction::getPredictedImages: depthPrediction, intensityPrediction as (rows, cols) arrays"""
+    t_inv = np.linalg.inv(pose.astype(np.float64)).astype(F)
+    z_lo, rgb_lo = splat_pass(surf, t_inv, cam, time, time, time_delta, max_depth, conf_low)
+    z_hi, rgb_hi = splat_pass(surf, t_inv, cam, time, time, time_delta, max_depth, conf_high)
+    rw, rh = COLS // 40, ROWS // 40                                        # Resize to 1/40 + denseEnough
+    dense = False
+    if rw * rh > 0:
+        hits = 0
+        for j in range(rh):
+            for i in range(rw):
+                sx = min(COLS - 1, int(F(F(F(F(i) + F(0.5)) / F(rw)) * F(COLS))))
+                sy = min(ROWS - 1, int(F(F(F(F(j) + F(0.5)) / F(rh)) * F(ROWS))))
+                hits += int(all(rgb_lo[sy, sx] > 0))
+        dense = F(hits) / F(rh * rw) > F(0.25)
+    lo_empty = rgb_lo.astype(int).sum(2) == 0
+    hi_empty = rgb_hi.astype(int).sum(2) == 0
+    if not dense:                                                          # Reconstruction.cpp:663-669
+        zr = (fr_prev["fil_mm"].astype(F) / F(1000.0)).astype(F)
+        z1 = np.where(z_lo == 0, np.where(fr_prev["b"] > F(0.6), zr, F(0)), z_lo)      # fill_vertex.frag
+        z = np.where(z_hi == 0, z1, z_hi)                                  # fill_vertex_from_texture.frag
+        c1 = np.where(lo_empty[..., None], fr_prev["rgb"], rgb_lo)         # fill_rgb.frag
+        c = np.where(hi_empty[..., None], c1, rgb_hi)
+    else:                                                                  # :696-700
+        z = np.where(z_hi == 0, z_lo, z_hi)
+        c = np.where(hi_empty[..., None], rgb_lo, rgb_hi)
+    depth = np.where((z > F(extract_max)) | (z <= 0), F(0), z).astype(F)   # extract_depth.frag
+    nf = F(F(1.0) / F(255.0))
+    r, g, b = [(c[..., k].astype(F) * nf).astype(F) for k in range(3)]
+    inten = ((F(0.299) * r + F(0.587) * g).astype(F) + F(0.114) * b).astype(F)   # :692
+    return depth, inten, bool(dense)
+
+
 def weighting(last_pose, curr_pose, multiplier):
     from scipy.spatial.transform import Rotation
 
@@ -346,7 +439,7 @@ def main():
         # the independent input stage: decimate / flip, bilateral filter, metricise; buildSegmImage
         inten, depth_loaded, mm, color = load_frame(color_full, depth_full, RES)
         fil_mm = bilateral_mm(mm)
-        fr = dict(raw=metricise(mm), fil=metricise(fil_mm), rgb=color, b=segm_image(labels, b_segm, np.ones(24, F)))
+        fr = dict(raw=metricise(mm), fil=metricise(fil_mm), rgb=color, b=segm_image(labels, b_segm, np.ones(24, F)), fil_mm=fil_mm)
         if k == 0:
             # GlobalModel::initialise comes from the oracle (it has its own tests); it is an INPUT of this fixture
             s.load_frame(0, color_full, depth_full, RES)
@@ -379,6 +472,11 @@ def main():
         out["map_%d" % k] = surf.copy()
         print("frame %d: %d emitted, %d associated, %d surfels merged, %d -> %d surfels" %
               (k, len(emitted), int((out["update_id_%d" % k] == 1).sum()), len(merged_ids), merged_model.shape[0], surf.shape[0]))
+    # Reconstruction::getPredictedImages from the final map at the final pose (tick = 6), fill-in from the last frame
+    for name, lo, hi in (("", mp.conf_low, mp.conf_high), ("_strict", 0.6, 0.95)):  # the second one leaves holes for the fill-in
+        d, i_, dense = predict_images(surf, pose, cam, 6, mp.time_delta, F(mp.max_depth), lo, hi, mp.extract_max_depth, fr)
+        out["pred_depth" + name], out["pred_intensity" + name], out["pred_dense" + name] = d, i_, np.bool_(dense)
+        print("prediction%s: %d pixels drawn, dense %s" % (name, int((d > 0).sum()), dense))
     path = os.path.join(ROOT, "tests", "golden", "fusion_40x30.npz")
     np.savez_compressed(path, **out)
     print("wrote", path)

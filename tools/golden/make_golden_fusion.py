@@ -10,6 +10,8 @@ the update maps as a dictionary keyed by texel, transform feedback as Python lis
   update_pass       GlobalModel::fuse, second half GlobalModel.cpp:427-492, Shaders/update.vert
   clean_pass        GlobalModel::clean             GlobalModel.cpp:494-601, Shaders/copy_unstable.vert, copy_unstable.geom
   weighting         Reconstruction::fuseFrame      Reconstruction.cpp:264-282 (rotation vector by scipy instead of rodrigues2)
+  init_model        GlobalModel::initialise        GlobalModel.cpp:200-258, Reconstruction::computeFeedbackBuffers (:205-216),
+                                                   Shaders/FeedbackBuffer.cpp, vertex_feedback.vert/.geom, init_unstable.vert
   predict_images    Reconstruction::getPredictedImages  Reconstruction.cpp:628-720, IndexMap.cpp:221-300, Shaders/splat.vert,
                                                    combo_splat.frag, fill_vertex.frag, fill_vertex_from_texture.frag, fill_rgb.frag,
                                                    extract_depth.frag, Shaders/Resize.cpp + denseEnough (:218-233)
@@ -18,8 +20,7 @@ exp / log are NumPy's (the oracle uses include/sf_detmath.h's fmaf sequences), t
 fixture is compared with a small tolerance on the floats and EXACTLY on everything discrete (counts, which pixel merged into
 which surfel, the index image, which surfels survive the cleaning).
 
-The frames go through the independent input-stage derivation (make_golden_input.py) and buildSegmImage (make_golden.py); the
-map of the first frame (GlobalModel::initialise, tested on its own) is taken from the oracle and stored as an input.
+The frames go through the independent input-stage derivation (make_golden_input.py) and buildSegmImage (make_golden.py).
 
 Run (in the build container):  python tools/golden/make_golden_fusion.py  -> tests/golden/fusion_40x30.npz
 """
@@ -295,6 +296,55 @@ def clean_pass(vertices, t_inv, cam, time, time_delta, conf_threshold, surf, ind
     return kept, flags
 
 
+def feedback_pass(depth_img, colour_of, cam, time, max_depth):
+    """FeedbackBuffer::compute: vertex_feedback.vert + .geom over the uv buffer (x outer, y inner) -> emitted (pos, colour, normRad)"""
+    cx, cy, fx, fy = cam
+    camz, camw = F(F(1.0) / fx), F(F(1.0) / fy)                            # FeedbackBuffer.cpp:89-92 (float division)
+    fc, fr_ = F(COLS), F(ROWS)
+    out = []
+    for i in range(COLS):
+        for j in range(ROWS):
+            tx = F(float(F(i) / fc) + 1.0 / (2 * float(fc)))              # FeedbackBuffer.cpp:46-47
+            ty = F(float(F(j) / fr_) + 1.0 / (2 * float(fr_)))
+            x, y = F(tx * fc), F(ty * fr_)
+
+            def vertex(u, v, xx, yy):
+                z = F(fetch(depth_img, u, v))
+                return v3(F(F(F(xx - cx) * z) * camz), F(F(F(yy - cy) * z) * camw), z)
+
+            one_c, one_r = F(F(1.0) / fc), F(F(1.0) / fr_)
+            pos = vertex(tx, ty, x, y)
+            xf, xb = vertex(F(tx + one_c), ty, F(x + F(1)), y), vertex(F(tx - one_c), ty, F(x - F(1)), y)
+            yf, yb = vertex(tx, F(ty + one_r), x, F(y + F(1))), vertex(tx, F(ty - one_r), x, F(y - F(1)))
+            half = lambda a, b: np.array([F(F(a[k] + b[k]) / F(2)) for k in range(3)], F)
+            n = normalize(cross((half(xb, pos) - half(xf, pos)).astype(F), (half(yb, pos) - half(yf, pos)).astype(F)))
+            mean_focal = F(F(F(F(1.0) / abs(camz)) + F(F(1.0) / abs(camw))) / F(2.0))
+            radius = F(F(pos[2] / mean_focal) * F(1.41421356237))
+            with np.errstate(all="ignore"):
+                radius_n = min(F(F(2.0) * radius), F(radius / abs(n[2])))
+            if pos[2] <= 0 or pos[2] > max_depth:                          # zVal = 0: vertex_feedback.geom emits nothing
+                continue
+            colour = np.array([encode_color(colour_of(tx, ty)), F(0), F(0), F(time)], F)   # vColor.x, .y = 0, .w = time (.z: the texture's blue)
+            out.append((pos, colour, np.array([n[0], n[1], n[2], radius_n], F)))
+    return out
+
+
+def init_model(fr, pose, cam, time, max_depth):
+    """GlobalModel::initialise: RAW feedback (position, colour) paired by index with FILTERED feedback (normal / radius, b as colour)"""
+    raw = feedback_pass(fr["raw"], lambda u, v: fetch(fr["rgb"], u, v).astype(F) / F(255), cam, time, max_depth)
+    fil = feedback_pass(fr["fil"], lambda u, v: np.full(3, fetch(fr["b"], u, v), F), cam, time, max_depth)   # a LUMINANCE texture reads (L, L, L)
+    surf = np.zeros((len(raw), 12), F)
+    for k, (pos, colour, _) in enumerate(raw):
+        nr = fil[k][2] if k < len(fil) else np.zeros(4, F)                # the buffers start zero-filled
+        prob = fil[k][1][0] if k < len(fil) else F(0)
+        surf[k, 0:3] = mat4_point(pose, pos)                               # init_unstable.vert:36
+        surf[k, 3] = decode_color(prob)[0]                                 # :38-40
+        surf[k, 4], surf[k, 5], surf[k, 6], surf[k, 7] = colour[0], F(1), F(1), colour[3]   # :42-45
+        surf[k, 8:11] = mat3_vec(pose, nr[0:3])                            # :47
+        surf[k, 11] = nr[3]
+    return surf
+
+
 def splat_pass(surf, t_inv, cam, time, max_time, time_delta, max_depth, conf_threshold):
     """IndexMap::combinedPredict for one confidence level: vertex.z and the RGBA8 image of the nearest surfel per pixel.
     A point sprite covers the pixels whose centres lie within gl_PointSize / 2 of its centre."""
@@ -441,14 +491,14 @@ def main():
         fil_mm = bilateral_mm(mm)
         fr = dict(raw=metricise(mm), fil=metricise(fil_mm), rgb=color, b=segm_image(labels, b_segm, np.ones(24, F)), fil_mm=fil_mm)
         if k == 0:
-            # GlobalModel::initialise comes from the oracle (it has its own tests); it is an INPUT of this fixture
+            # the oracle is used here only to cross-check the inputs the two sides must agree on before the fusion starts
             s.load_frame(0, color_full, depth_full, RES)
             s.filter_depth()
             s.set_segm_state(0, labels, b_segm, np.ones(24, np.float32))
             s.build_segm_image()
             assert np.array_equal(s.b_image(), fr["b"]) and np.array_equal(s.input_image(sf.capi.IN_DEPTH_METRIC), fr["raw"])
             assert np.array_equal(s.current()[0], fr["fil"]) and np.array_equal(s.input_image(sf.capi.IN_COLOR), fr["rgb"])
-            surf = s.init_model_from_frame(0, pose, mp, time=1)
+            surf = init_model(fr, pose, cam, 1, F(mp.max_depth))
             out["map_0"] = surf.copy()
             continue
         time = k + 1

@@ -64,6 +64,27 @@ def check_lin_planes_single_level(api):
     return s
 
 
+def check_kmeans(api):
+    """tests/golden/kmeans_160x120.npz: the independent Python derivation of KMeans.cpp (tools/golden/make_golden_kmeans.py).
+    Labels of every level, centres, connectivity and the iteration count: exactly."""
+    g = np.load(os.path.join(GOLDEN, "kmeans_160x120.npz"))
+    s = make_solver(api, 120, 160, driver_params(api, ctf_levels=4))
+    s.set_current(0, g["depth0"], g["intensity0"])
+    s.build_pyramid(False)
+    s.kmeans()
+    for L in range(4):
+        assert np.array_equal(s.labels(L), g["labels%d" % L]), L
+    assert np.array_equal(s.kmeans_centres(), g["centres"])  # bit for bit: the sums run in the reference's pixel order
+    assert np.array_equal(s.connectivity(), g["connectivity"])
+    assert s.stats().kmeans_iters == int(g["iterations"])
+    assert (g["labels1"] != g["init_labels1"]).mean() > 0.05 and (g["labels0"] == 24).sum() > 0  # the iterations moved pixels; invalid pixels exist
+    return s
+
+
+def test_oracle_kmeans_golden(ora):
+    check_kmeans(ora)
+
+
 def test_oracle_pyramid_golden(ora):
     check_pyramid(ora)
 

@@ -81,6 +81,71 @@ def check_kmeans(api):
     return s
 
 
+def check_full_solve(api, tol=2e-6, tol_b=1e-4):
+    """tests/golden/solver_160x120.npz: StaticFusion::runSolver derived independently in NumPy (tools/golden/make_golden_solver.py:
+    warp, linearisation, segmentation prior, joint IRLS with the b-solve, motion filter, SE(3) update; float64 for every
+    cross-pixel sum and every small linear-algebra step) -- discrete outcomes exactly, the floats to rounding. Two frame
+    pairs: the pyramid fixture's, and one with four times the motion (two outer iterations at the coarsest level)."""
+    from conftest import trace_array
+
+    g = np.load(os.path.join(GOLDEN, "pyramid_160x120.npz"))
+    w = np.load(os.path.join(GOLDEN, "solver_160x120.npz"))
+    out = []
+    for prefix, new, old in (("", (g["d_new0"], g["i_new0"]), (g["d_old0"], g["i_old0"])),
+                             ("big_", (w["big_d_new0"], w["big_i_new0"]), (w["big_d_old0"], w["big_i_old0"]))):
+        s = make_solver(api, 120, 160, driver_params(api, kb=1.05, ctf_levels=3))
+        s.set_current(0, *new)
+        s.set_prediction(0, *old)
+        s.build_pyramid(True)
+        s.run_solver(True)
+        st = s.stats()
+        n = int(w[prefix + "n_outer"])
+        assert st.n_outer == n and st.status == 0, prefix
+        for key in ("level", "k", "n_valid", "irls_iters"):
+            assert np.array_equal(trace_array(st, key)[:n], w[prefix + key]), (prefix, key)
+        assert np.allclose(trace_array(st, "aver_res")[:n], w[prefix + "trace_aver_res"], rtol=2e-4, atol=0), prefix
+        assert np.abs(trace_array(st, "var")[:n] - w[prefix + "trace_var"]).max() < tol, prefix
+        assert np.abs(trace_array(st, "twist_level")[:n] - w[prefix + "trace_twist_level"]).max() < tol, prefix
+        assert np.abs(trace_array(st, "b_segm")[:n] - w[prefix + "trace_b_segm"]).max() < tol_b, prefix
+        T_trace = trace_array(st, "T")[:n].reshape(n, 4, 4).transpose(0, 2, 1)  # column-major in the ABI
+        assert np.abs(T_trace - w[prefix + "trace_T"]).max() < tol, prefix
+        assert np.abs(s.T() - w[prefix + "T"]).max() < tol and np.abs(s.twist() - w[prefix + "twist"]).max() < tol, prefix
+        out.append(s)
+    assert np.linalg.norm(w["twist"]) > 0.015 and (w["trace_b_segm"][-1] < 0.5).sum() >= 1  # a real motion; the sphere's clusters are dynamic
+    assert list(w["big_k"][:2]) == [0, 1] and np.linalg.norm(w["big_trace_twist_level"][0]) > 0.04   # a second outer iteration at the coarsest level
+    return out
+
+
+def check_history_residuals(api, tol=5e-6):
+    """computeResidualsAgainstPreviousImage (FrontEnd.cpp:896-1069) derived independently for the last of six frames driven
+    through sf_process_frame (carried solver state, the 5-frame ring, the product of the buffered odometries)"""
+    w = np.load(os.path.join(GOLDEN, "solver_160x120.npz"))
+    s = make_solver(api, 120, 160, driver_params(api, kb=1.5, ctf_levels=3))
+    s.set_current(0, w["hist_depth"][0], w["hist_intensity"][0])
+    s.current_to_prediction()
+    s.push_history(0)
+    for k in range(1, 6):
+        s.set_current(0, w["hist_depth"][k], w["hist_intensity"][k])
+        s.process_frame(k)
+        assert np.abs(s.T() - w["hist_T"][k - 1]).max() < 1e-5, k   # the fixture's poses are the oracle's (inputs of the derivation)
+        if k < 5:
+            s.current_to_prediction()
+    assert np.array_equal(s.labels(0), w["hist_labels0"])
+    got, want = s.cluster_residuals(), w["hist_cluster_res"]
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanmax(np.abs(got - want)) < tol, np.nanmax(np.abs(got - want))
+    assert np.nanmax(want) > 0.2 and np.nanmin(want) < 0.005   # the sphere's clusters stand out
+    return s
+
+
+def test_oracle_full_solve_golden(ora):
+    check_full_solve(ora)
+
+
+def test_oracle_history_residuals_golden(ora):
+    check_history_residuals(ora)
+
+
 def test_oracle_kmeans_golden(ora):
     check_kmeans(ora)
 

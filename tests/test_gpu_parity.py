@@ -136,6 +136,8 @@ def test_golden_fixtures_on_the_hip_path(hip):
     test_golden.check_linearise_and_first_irls(hip)
     test_golden.check_lin_planes_single_level(hip)
     test_golden.check_kmeans(hip)
+    test_golden.check_full_solve(hip, tol=5e-6, tol_b=5e-4)  # the HIP path's IRLS weights use the hardware rsq / rcp
+    test_golden.check_history_residuals(hip, tol=2e-5)
     g = np.load(os.path.join(GOLDEN, "segm_image_160x120.npz"))
     s = make_solver(hip, 120, 160, driver_params(hip))
     s.set_segm_state(0, g["labels0"], g["b_segm"], g["cluster_res"])

@@ -555,6 +555,43 @@ def test_hip_index_image_epoch_tags_wrap(hip, ora):
 
 
 @pytest.mark.gpu
+def test_hip_fusion_at_vga(hip, ora):
+    """res_factor 1: 480 x 640 frames, a 2560 x 1920 index image (39 MB of keys), 300 k surfels -- three fuses and a prediction"""
+    from staticfusion_amd.synth import Scene
+
+    rows, cols = 480, 640
+    scene = Scene(seed=99, sphere=True)
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    labels = (((xx // 80) + 8 * (yy // 80)) % 24).astype(np.int32)
+    res = []
+    for api in (hip, ora):
+        p = driver_params(api)
+        p.ctf_levels = 6
+        s = make_solver(api, rows, cols, p)
+        m = SurfelMap(s)
+        T = np.eye(4)
+        frames = []
+        for k in range(3):
+            depth, inten = scene.render(T, 640, 480)
+            g = np.clip(np.rint(inten * 255), 1, 255).astype(np.uint8)
+            s.load_frame(0, np.ascontiguousarray(np.repeat(g[::-1, :, None], 3, axis=2)), np.clip(np.rint(depth[::-1] * 1000), 0, 65535).astype(np.uint16), 1)
+            s.filter_depth()
+            s.set_segm_state(0, labels, np.linspace(0.05, 1.0, 24).astype(np.float32), np.ones(24, np.float32))
+            s.build_segm_image()
+            m.fuse_frame(0, None if k == 0 else se3_exp(XI))
+            frames.append((m.info(), m.download()))
+            T = T @ se3_exp(XI)
+        m.predict(0)
+        res.append((frames, m.index_map(), s.prediction()))
+    (fh, xh, ph), (fo, xo, po) = res
+    for k, ((ih, sh), (io_, so)) in enumerate(zip(fh, fo)):
+        assert ih["count"] == io_["count"] and ih["stats"] == io_["stats"], (k, ih, io_)
+        assert same_bits(sh, so), k
+    assert fo[-1][0]["count"] > 250000 and fo[-1][0]["stats"][1] > 60000
+    assert np.array_equal(xh, xo) and same_bits(ph[0], po[0]) and same_bits(ph[1], po[1])
+
+
+@pytest.mark.gpu
 def test_hip_fusion_on_a_permuted_map(hip, ora):
     """the kernels lean on the map's point order for locality only: a map whose surfels were shuffled (uploaded that way on both
     sides) fuses to the same bits as the oracle's"""

@@ -323,7 +323,7 @@ __device__ __forceinline__ void normalise_acc(long long sd, long long packed, fl
 //  Integer sums => the result is independent of both orders.
 // ---------------------------------------------------------------------------------------------
 #define SPLAT_TV 64
-#define SPLAT_TU (2 * SF_NT / 64)
+#define SPLAT_TU ((SF_NT == 256 ? 4 : 2) * SF_NT / 64)
 #define SPLAT_PX ((SPLAT_TV * SPLAT_TU) / SF_NT)  // source pixels per lane and tile
 #define WIN_V (SPLAT_TV + 6)
 #define WIN_U (SPLAT_TU + 6)

@@ -66,7 +66,8 @@ enum {
 /* The reference's parameter set: public members written by the drivers
  * (reference FrontEnd.cpp:57-76 ctor defaults, StaticFusion-datasets.cpp:79-94 driver values). */
 typedef struct sf_params {
-    int32_t ctf_levels;          /* 0 = log2(cols/40)+2 as in FrontEnd.cpp:61 */
+    int32_t ctf_levels;          /* 0 = log2(cols/40)+2 as in FrontEnd.cpp:61; 2..8, or 1 with segmentation_enabled = 0
+                                    (K-means clusters image level 1, KMeans.cpp:145) */
     int32_t max_iter_per_level;  /* FrontEnd.cpp:69 / datasets.cpp:83 */
     int32_t max_iter_irls;       /* FrontEnd.cpp:68 / datasets.cpp:89 */
     int32_t use_motion_filter;   /* FrontEnd.cpp:76 / datasets.cpp:79 */
@@ -97,6 +98,10 @@ typedef struct sf_outer_trace {
     float twist_level[6]; /* twist_level_odometry */
     float b_segm[SF_NUM_CLUSTERS];
     float T[16];        /* T_odometry after this iteration, column-major */
+    float b_prior[SF_NUM_CLUSTERS];    /* computeSegPrior of this iteration (SegmentationBackground.cpp:53-103) */
+    float lambda_t_w[SF_NUM_CLUSTERS];
+    float AtA[36];      /* normal equations of the LAST IRLS iteration (FrontEnd.cpp:640-641), row-major 6x6 */
+    float AtB[6];
 } sf_outer_trace;
 
 typedef struct sf_frame_stats {
@@ -131,6 +136,18 @@ void SF_FN(ctor_params)(sf_params *p);
 /* Replaces StaticFusion::StaticFusion(res_factor) (FrontEnd.cpp:52-181) minus the GUI / map objects.
  * rows x cols is the solver resolution (240 x 320 for res_factor 2). device = HIP ordinal. */
 int SF_FN(create)(const sf_params *p, int rows, int cols, int batch, int device, sf_handle **out);
+/* The same with an explicit choice of the frame-kernel build. The reference has one code path;
+ * the MI355X library carries several builds of the same algorithm that differ in how many lanes / CUs serve one
+ * stream, and sf_create picks by batch size (SF_VARIANT_AUTO). Tests and benchmarks name the build they measure:
+ *   SF_VARIANT_THROUGHPUT  one 256-thread workgroup per stream, four per CU            (thousands of streams)
+ *   SF_VARIANT_LATENCY     one 1024-thread workgroup per stream, one per CU             (up to ~2 streams per CU)
+ *   SF_VARIANT_CLUSTER     several 1024-thread workgroups (CUs) per stream              (one live camera, a few streams)
+ * The CPU oracle accepts and ignores the argument. */
+enum { SF_VARIANT_AUTO = 0, SF_VARIANT_THROUGHPUT = 1, SF_VARIANT_LATENCY = 2, SF_VARIANT_CLUSTER = 3 };
+int SF_FN(create_ex)(const sf_params *p, int rows, int cols, int batch, int device, int variant, sf_handle **out);
+/* Which build the handle runs: *variant = SF_VARIANT_*, *threads = workgroup size, *workgroups_per_stream (1 except
+ * for SF_VARIANT_CLUSTER). Any pointer may be NULL. */
+int SF_FN(get_variant)(const sf_handle *h, int *variant, int *threads, int *workgroups_per_stream);
 void SF_FN(destroy)(sf_handle *h);
 int SF_FN(set_params)(sf_handle *h, const sf_params *p);
 int SF_FN(get_params)(const sf_handle *h, sf_params *p);
@@ -354,6 +371,13 @@ int SF_FN(get_batch_results)(sf_handle *h, float *T, int32_t *n_irls, int32_t *n
 int SF_FN(get_plane)(sf_handle *h, int stream, int set, int channel, int level, float *out);
 /* dcu..ddt, weights, Null of the last executed outer iteration (size of that iteration's level). */
 int SF_FN(get_lin_plane)(sf_handle *h, int stream, int which, float *out, int *rows, int *cols);
+
+/* The Jacobian of the last executed outer iteration (FrontEnd.cpp:539-586): A is 2N x 6 row-major, B has 2N entries,
+ * N = validPixels.size(); rows 2i / 2i+1 are the intensity / depth row of the i-th valid pixel in the reference's
+ * validPixels order (u outer, v inner). *n_rows = 2N; A and B may be NULL to query the size. Needs
+ * params.debug_planes = 1. The MI355X kernels never store A: a debug kernel expands the rows from the factored
+ * per-pixel form the IRLS passes evaluate, so this is the device arithmetic of those passes. */
+int SF_FN(get_jacobian_rows)(sf_handle *h, int stream, float *A, float *B, int *n_rows);
 
 int SF_FN(level_rows)(const sf_handle *h, int level);
 int SF_FN(level_cols)(const sf_handle *h, int level);

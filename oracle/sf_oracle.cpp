@@ -385,6 +385,7 @@ void StaticFusion::setParams(const Params &p) {
     max_iter_irls = p.max_iter_irls;
     use_motion_filter = p.use_motion_filter;
     segmentation_enabled = p.segmentation_enabled;
+    keep_rows = p.keep_rows;
     fovh = p.fovh;
     k_photometric_res = p.k_photometric_res;
     irls_delta_threshold = p.irls_delta_threshold;
@@ -829,6 +830,12 @@ void StaticFusion::solveOdometryAndSegmJoint() {
             for (int c = 0; c < 6; c++) t0.var[c] = t0.twist_level[c] = 0.f;
             for (int l = 0; l < NUM_CLUSTERS; l++) t0.b_segm[l] = b_segm[l];
             std::memcpy(t0.T, T_odometry.m, sizeof(t0.T));
+            for (int l = 0; l < NUM_CLUSTERS; l++) {
+                t0.b_prior[l] = b_prior[l];
+                t0.lambda_t_w[l] = lambda_t_w[l];
+            }
+            std::memset(t0.AtA, 0, sizeof(t0.AtA));
+            std::memset(t0.AtB, 0, sizeof(t0.AtB));
         }
         return;
     }
@@ -933,6 +940,16 @@ void StaticFusion::solveOdometryAndSegmJoint() {
         tr->irls_iters = int(iters_done);
         tr->aver_res = aver_res;
         for (int c = 0; c < 6; c++) tr->var[c] = Var[c];
+        for (int l = 0; l < NUM_CLUSTERS; l++) {
+            tr->b_prior[l] = b_prior[l];
+            tr->lambda_t_w[l] = lambda_t_w[l];
+        }
+        std::memcpy(tr->AtA, AtA, sizeof(tr->AtA));
+        std::memcpy(tr->AtB, AtB, sizeof(tr->AtB));
+    }
+    if (keep_rows) {
+        dbg_A = A;
+        dbg_B = B;
     }
 
     filterEstimateAndComputeT(Var);  // :690

@@ -86,6 +86,7 @@ struct Params {
     float kz = 1.5f;
     float lambda_reg = 0.35f;
     float lambda_prior = 0.5f;
+    bool keep_rows = false;  // test hook (sf_params.debug_planes): keep A and B of the last outer iteration
 };
 
 struct OuterTrace {
@@ -95,6 +96,8 @@ struct OuterTrace {
     float twist_level[6];
     float b_segm[NUM_CLUSTERS];
     float T[16];
+    float b_prior[NUM_CLUSTERS], lambda_t_w[NUM_CLUSTERS];  // computeSegPrior of this iteration
+    float AtA[36], AtB[6];                                  // normal equations of the last IRLS iteration
 };
 
 struct FrameStats {
@@ -192,6 +195,8 @@ class StaticFusion {
     // ---- not in the reference ----
     bool segmentation_enabled = true;  // false: "b_segm.fill(1.f)" alternative, FrontEnd.cpp:606-607
     FrameStats stats;
+    bool keep_rows = false;                 // test hook: keep the Jacobian of the last outer iteration
+    std::vector<float> dbg_A, dbg_B;        // column-major 2N x 6 / 2N (FrontEnd.cpp:539-586), only with keep_rows
 
     StaticFusion(unsigned int rows_, unsigned int cols_, const Params &p);
     void setParams(const Params &p);

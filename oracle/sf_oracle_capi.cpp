@@ -56,6 +56,7 @@ static sfo::Params to_oracle(const sf_params &p) {
     o.kz = p.kz;
     o.lambda_reg = p.lambda_reg;
     o.lambda_prior = p.lambda_prior;
+    o.keep_rows = p.debug_planes != 0;
     return o;
 }
 
@@ -111,13 +112,26 @@ int sfo_create(const sf_params *p, int rows, int cols, int batch, int device, sf
     sfo::Params op = to_oracle(*p);
     for (int i = 0; i < batch; i++) h->s.emplace_back(new sfo::StaticFusion(rows, cols, op));
     h->params.ctf_levels = int(h->s[0]->ctf_levels);
-    if (h->params.ctf_levels < 2 || h->params.ctf_levels > SF_MAX_LEVELS ||
+    if (h->params.ctf_levels < (p->segmentation_enabled ? 2 : 1) || h->params.ctf_levels > SF_MAX_LEVELS ||
         h->params.ctf_levels * h->params.max_iter_per_level > SF_MAX_OUTER ||
         (rows >> (h->params.ctf_levels - 1)) < 3 || (cols >> (h->params.ctf_levels - 1)) < 3) {
         delete h;
         return fail(SF_ERR_ARG, "unsupported ctf_levels for this resolution");
     }
     *out = h;
+    return SF_OK;
+}
+
+// the oracle has one code path: the build selector of the MI355X library is accepted and ignored
+int sfo_create_ex(const sf_params *p, int rows, int cols, int batch, int device, int variant, sf_handle **out) {
+    if (variant < SF_VARIANT_AUTO || variant > SF_VARIANT_CLUSTER) return fail(SF_ERR_ARG, "unknown variant");
+    return sfo_create(p, rows, cols, batch, device, out);
+}
+int sfo_get_variant(const sf_handle *h, int *variant, int *threads, int *workgroups_per_stream) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    if (variant) *variant = SF_VARIANT_AUTO;
+    if (threads) *threads = 1;
+    if (workgroups_per_stream) *workgroups_per_stream = 1;
     return SF_OK;
 }
 
@@ -353,6 +367,10 @@ int sfo_get_stats(sf_handle *h, int stream, sf_frame_stats *out) {
         std::memcpy(b.twist_level, a.twist_level, sizeof(b.twist_level));
         std::memcpy(b.b_segm, a.b_segm, sizeof(b.b_segm));
         std::memcpy(b.T, a.T, sizeof(b.T));
+        std::memcpy(b.b_prior, a.b_prior, sizeof(b.b_prior));
+        std::memcpy(b.lambda_t_w, a.lambda_t_w, sizeof(b.lambda_t_w));
+        std::memcpy(b.AtA, a.AtA, sizeof(b.AtA));
+        std::memcpy(b.AtB, a.AtB, sizeof(b.AtB));
     }
     return SF_OK;
 }
@@ -408,6 +426,20 @@ int sfo_get_lin_plane(sf_handle *h, int stream, int which, float *out, int *rows
             }
             out[v + size_t(u) * r] = val;
         }
+    return SF_OK;
+}
+
+int sfo_get_jacobian_rows(sf_handle *h, int stream, float *A, float *B, int *n_rows) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!n_rows) return fail(SF_ERR_ARG, "null");
+    if (!h->params.debug_planes) return fail(SF_ERR_STATE, "the Jacobian rows need params.debug_planes = 1");
+    auto &s = *h->s[stream];
+    const size_t M = s.dbg_B.size();
+    *n_rows = int(M);
+    if (A)
+        for (size_t r = 0; r < M; r++)
+            for (int c = 0; c < 6; c++) A[r * 6 + c] = s.dbg_A[r + size_t(c) * M];  // the oracle keeps A column-major
+    if (B) std::memcpy(B, s.dbg_B.data(), M * sizeof(float));
     return SF_OK;
 }
 

@@ -19,6 +19,9 @@ CH_DEPTH, CH_INTENSITY, CH_XX, CH_YY = 0, 1, 2, 3
 
 IN_DEPTH_MM, IN_DEPTH_FILTERED_MM, IN_DEPTH_METRIC, IN_COLOR = range(4)
 
+VARIANT_AUTO, VARIANT_THROUGHPUT, VARIANT_LATENCY, VARIANT_CLUSTER = range(4)
+VARIANT_NAMES = {"auto": 0, "throughput": 1, "latency": 2, "cluster": 3}
+
 STATUS_EIG_SKIPPED = 1
 STATUS_EMPTY_LEVEL = 2
 
@@ -64,6 +67,10 @@ class SfOuterTrace(C.Structure):
         ("twist_level", C.c_float * 6),
         ("b_segm", C.c_float * NUM_CLUSTERS),
         ("T", C.c_float * 16),
+        ("b_prior", C.c_float * NUM_CLUSTERS),
+        ("lambda_t_w", C.c_float * NUM_CLUSTERS),
+        ("AtA", C.c_float * 36),
+        ("AtB", C.c_float * 6),
     ]
 
 
@@ -87,6 +94,8 @@ SIGNATURES = {
     "default_params": (None, [C.POINTER(SfParams)]),
     "ctor_params": (None, [C.POINTER(SfParams)]),
     "create": (C.c_int, [C.POINTER(SfParams), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
+    "create_ex": (C.c_int, [C.POINTER(SfParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
+    "get_variant": (C.c_int, [_H, _ip, _ip, _ip]),
     "destroy": (None, [_H]),
     "set_params": (C.c_int, [_H, C.POINTER(SfParams)]),
     "get_params": (C.c_int, [_H, C.POINTER(SfParams)]),
@@ -149,6 +158,7 @@ SIGNATURES = {
     "get_batch_results": (C.c_int, [_H, _fp, _ip, _ip, C.POINTER(C.c_int64)]),
     "get_plane": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "get_lin_plane": (C.c_int, [_H, C.c_int, C.c_int, _fp, _ip, _ip]),
+    "get_jacobian_rows": (C.c_int, [_H, C.c_int, _fp, _fp, _ip]),
     "level_rows": (C.c_int, [_H, C.c_int]),
     "level_cols": (C.c_int, [_H, C.c_int]),
     "batch": (C.c_int, [_H]),
@@ -195,6 +205,14 @@ class Api:
     def backend_name(self):
         return self.backend().decode()
 
+    def with_variant(self, variant):
+        """A view of this binding whose Solver()s default to the named frame-kernel build (tests run every case on each)."""
+        import copy
+
+        v = copy.copy(self)
+        v.default_variant = variant
+        return v
+
 
 def _f32(a):
     """column-major float32 contiguous buffer of a (rows, cols) array"""
@@ -204,12 +222,16 @@ def _f32(a):
 class Solver:
     """numpy convenience wrapper over one sf_handle (a batch of independent streams)."""
 
-    def __init__(self, api, rows, cols, batch=1, params=None, device=0):
+    def __init__(self, api, rows, cols, batch=1, params=None, device=0, variant=None):
+        """variant: None = the api's default_variant (normally "auto": sf_create's own choice by batch size), or one of
+        "auto" / "throughput" / "latency" / "cluster" (sf_create_ex)."""
         self.api = api
         self.rows, self.cols, self.batch_size = rows, cols, batch
         p = params if params is not None else api.default_params_struct()
         self.h = _H()
-        api.check(api.create(C.byref(p), rows, cols, batch, device, C.byref(self.h)))
+        v = variant if variant is not None else getattr(api, "default_variant", "auto")
+        v = VARIANT_NAMES[v] if isinstance(v, str) else int(v)
+        api.check(api.create_ex(C.byref(p), rows, cols, batch, device, v, C.byref(self.h)))
         self.params = SfParams()
         api.check(api.get_params(self.h, C.byref(self.params)))
         self.levels = self.params.ctf_levels
@@ -218,6 +240,12 @@ class Solver:
         if self.h:
             self.api.destroy(self.h)
             self.h = _H()
+
+    def variant(self):
+        """(name, threads per workgroup, workgroups per stream) of the frame-kernel build this handle runs"""
+        v, t, g = C.c_int32(), C.c_int32(), C.c_int32()
+        self.api.check(self.api.get_variant(self.h, C.byref(v), C.byref(t), C.byref(g)))
+        return {n: k for k, n in VARIANT_NAMES.items()}[v.value], t.value, g.value
 
     def __del__(self):
         try:
@@ -405,6 +433,15 @@ class Solver:
         out = np.zeros((c.value, r.value), dtype=np.float32)
         self.api.check(self.api.get_lin_plane(self.h, stream, which, out.ctypes.data_as(_fp), C.byref(r), C.byref(c)))
         return out.T.copy()
+
+    def jacobian_rows(self, stream=0):
+        """(A (2N, 6), B (2N,)) of the last executed outer iteration, validPixels order (needs debug_planes)"""
+        n = C.c_int32()
+        self.api.check(self.api.get_jacobian_rows(self.h, stream, None, None, C.byref(n)))
+        A = np.zeros((max(n.value, 1), 6), np.float32)
+        B = np.zeros(max(n.value, 1), np.float32)
+        self.api.check(self.api.get_jacobian_rows(self.h, stream, A.ctypes.data_as(_fp), B.ctypes.data_as(_fp), C.byref(n)))
+        return A[: n.value].copy(), B[: n.value].copy()
 
     def stats(self, stream=0):
         st = SfFrameStats()

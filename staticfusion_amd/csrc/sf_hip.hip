@@ -23,6 +23,7 @@
 
 // the two builds of the frame kernels (sf_frame_kernels.hip, -DSF_NT=256 / -DSF_NT=1024)
 struct FrameVariant {
+    int id;  // SF_VARIANT_*
     const char *name;
     void (*geometry)(int *threads, int *blocks_per_cu);
     void (*launch_frame)(int grid, hipStream_t st, const KArgs *ka, int stage_mask, int im_count);
@@ -35,8 +36,8 @@ extern "C" __attribute__((visibility("hidden"))) void sf_launch_irls_pass_nt1024
 extern "C" __attribute__((visibility("hidden"))) void sf_variant_geometry_nt256(int *, int *);
 extern "C" __attribute__((visibility("hidden"))) void sf_variant_geometry_nt1024(int *, int *);
 static const FrameVariant VARIANTS[2] = {
-    {"throughput", sf_variant_geometry_nt256, sf_launch_frame_nt256, sf_launch_irls_pass_nt256},
-    {"latency", sf_variant_geometry_nt1024, sf_launch_frame_nt1024, sf_launch_irls_pass_nt1024},
+    {SF_VARIANT_THROUGHPUT, "throughput", sf_variant_geometry_nt256, sf_launch_frame_nt256, sf_launch_irls_pass_nt256},
+    {SF_VARIANT_LATENCY, "latency", sf_variant_geometry_nt1024, sf_launch_frame_nt1024, sf_launch_irls_pass_nt1024},
 };
 
 // =============================================================================================
@@ -202,11 +203,28 @@ void sf_destroy(sf_handle *h) {
 }
 
 int sf_create(const sf_params *p, int rows, int cols, int batch, int device, sf_handle **out) {
+    return sf_create_ex(p, rows, cols, batch, device, SF_VARIANT_AUTO, out);
+}
+
+int sf_get_variant(const sf_handle *h, int *variant, int *threads, int *workgroups_per_stream) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    int t = 0, per_cu = 0;
+    h->fv->geometry(&t, &per_cu);
+    if (variant) *variant = h->fv->id;
+    if (threads) *threads = t;
+    if (workgroups_per_stream) *workgroups_per_stream = 1;
+    return SF_OK;
+}
+
+int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, int variant, sf_handle **out) {
     if (!p || !out || rows < 8 || cols < 8 || batch < 1) return fail(SF_ERR_ARG, "bad argument");
+    if (variant < SF_VARIANT_AUTO || variant > SF_VARIANT_CLUSTER) return fail(SF_ERR_ARG, "unknown variant");
+    if (variant == SF_VARIANT_CLUSTER) return fail(SF_ERR_ARG, "SF_VARIANT_CLUSTER is not built into this library");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(SF_ERR_DEVICE, "no HIP device visible: libsf_hip.so has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(SF_ERR_ARG, "device ordinal out of range");
+    if (p->ctf_levels <= 0 && cols < 40) return fail(SF_ERR_ARG, "ctf_levels = 0 (log2(cols/40)+2, FrontEnd.cpp:61) needs cols >= 40");
     int levels = p->ctf_levels > 0 ? p->ctf_levels : int(std::log2(double(cols / 40)) + 2);  // FrontEnd.cpp:61
     if (int e = validate_params(p, levels)) return e;
     if ((rows >> (levels - 1)) < 3 || (cols >> (levels - 1)) < 3)
@@ -259,11 +277,16 @@ int sf_create(const sf_params *p, int rows, int cols, int batch, int device, sf_
     HIP_OR_FREE(hipGetDeviceProperties(&prop, device));
     // Few streams: one 1024-thread workgroup per stream and CU gives each stream four times the lanes (1.6-1.8x
     // lower latency, and higher throughput up to ~2 streams per CU); many streams: four 256-thread workgroups per CU.
-    // SF_VARIANT=throughput|latency overrides the choice.
+    // sf_create_ex names the build explicitly; for SF_VARIANT_AUTO the environment variable SF_VARIANT=throughput|latency
+    // may still override the choice by batch size (A/B tooling).
     h->fv = &VARIANTS[(batch <= 2 * prop.multiProcessorCount) ? 1 : 0];
-    if (const char *v = std::getenv("SF_VARIANT")) {
-        if (!std::strcmp(v, "throughput")) h->fv = &VARIANTS[0];
-        if (!std::strcmp(v, "latency")) h->fv = &VARIANTS[1];
+    if (variant == SF_VARIANT_AUTO) {
+        if (const char *v = std::getenv("SF_VARIANT")) {
+            if (!std::strcmp(v, "throughput")) h->fv = &VARIANTS[0];
+            if (!std::strcmp(v, "latency")) h->fv = &VARIANTS[1];
+        }
+    } else {
+        h->fv = &VARIANTS[variant == SF_VARIANT_THROUGHPUT ? 0 : 1];
     }
     int wg_threads = 0, wg_per_cu = 0;
     h->fv->geometry(&wg_threads, &wg_per_cu);

@@ -1020,11 +1020,18 @@ __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level,
 
     if (N == 0) {  // defined behaviour for an empty level: nothing moves
         if (tid < 6) s.twist_level[tid] = 0.f;
-        if (tid == 0 && tr) {
-            tr->level = level; tr->k = kouter; tr->n_valid = 0; tr->irls_iters = 0; tr->aver_res = 0.f;
-            for (int c = 0; c < 6; c++) tr->var[c] = tr->twist_level[c] = 0.f;
-            for (int l = 0; l < SF_NC; l++) tr->b_segm[l] = s.b_segm[l];
-            for (int q = 0; q < 16; q++) tr->T[q] = s.T[q];
+        if (tr) {
+            if (tid == 0) {
+                tr->level = level; tr->k = kouter; tr->n_valid = 0; tr->irls_iters = 0; tr->aver_res = 0.f;
+            }
+            if (tid < 6) tr->var[tid] = tr->twist_level[tid] = tr->AtB[tid] = 0.f;
+            if (tid < 16) tr->T[tid] = s.T[tid];
+            if (tid < 36) tr->AtA[tid] = 0.f;
+            if (tid < SF_NC) {
+                tr->b_segm[tid] = s.b_segm[tid];
+                tr->b_prior[tid] = s.b_prior[tid];
+                tr->lambda_t_w[tid] = s.lambda_t_w[tid];
+            }
         }
         __syncthreads();
         return;
@@ -1058,18 +1065,27 @@ __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level,
         if (__builtin_amdgcn_readfirstlane(s.ctrl)) break;
     }
 
-    if (tid == 0 && tr) {
-        tr->level = level; tr->k = kouter; tr->n_valid = N; tr->irls_iters = iters_done;
-        tr->aver_res = s.aver_res;
-        for (int c = 0; c < 6; c++) tr->var[c] = s.Var[c];
+    if (tr && wave == SF_NW - 1) {  // the trace: a wave that is not busy with the filter (one wave: after it, in order)
+        if (lane == 0) {
+            tr->level = level; tr->k = kouter; tr->n_valid = N; tr->irls_iters = iters_done;
+            tr->aver_res = s.aver_res;
+        }
+        if (lane < 6) {
+            tr->var[lane] = s.Var[lane];
+            tr->AtB[lane] = s.AtB[lane];
+        }
+        if (lane < 36) tr->AtA[lane] = s.AtA[lane];
+        if (lane < SF_NC) {
+            tr->b_prior[lane] = s.b_prior[lane];
+            tr->lambda_t_w[lane] = s.lambda_t_w[lane];
+        }
     }
     if (wave == 0) solve_filter_and_update(a, s, level, lane);
-    if (tid == 0) {
-        if (tr) {
-            for (int c = 0; c < 6; c++) tr->twist_level[c] = s.twist_level[c];
-            for (int l = 0; l < SF_NC; l++) tr->b_segm[l] = s.b_segm[l];
-            for (int q = 0; q < 16; q++) tr->T[q] = s.T[q];
-        }
+    __syncthreads();
+    if (tr) {
+        if (tid < 6) tr->twist_level[tid] = s.twist_level[tid];
+        if (tid < SF_NC) tr->b_segm[tid] = s.b_segm[tid];
+        if (tid < 16) tr->T[tid] = s.T[tid];
     }
     __syncthreads();
     PROF_MARK(s, tid, PF_FILTER);

@@ -37,9 +37,24 @@ def ora():
     return binding.load()
 
 
+# Every GPU test that takes the `hip` fixture runs once per build of the frame kernel: the
+# driver's green therefore covers `sf_frame_kernel_nt256` (the build bench.py times) as well as `_nt1024`.
+# SF_TEST_VARIANTS=throughput (comma separated) narrows the set for a quick run.
+HIP_VARIANTS = [v for v in os.environ.get("SF_TEST_VARIANTS", "throughput,latency").split(",") if v]
+
+
+@pytest.fixture(scope="session", params=HIP_VARIANTS)
+def hip(request):
+    """The product library, bound to one named build of the frame kernel (Solver(...) defaults to it through
+    sf_create_ex). No fallback: a missing extension or GPU is a test ERROR, not a skip."""
+    import staticfusion_amd as sf
+
+    return sf.load().with_variant(request.param)
+
+
 @pytest.fixture(scope="session")
-def hip():
-    """The product library. No fallback: a missing extension or GPU is a test ERROR, not a skip."""
+def hip_auto():
+    """The product library with sf_create's own choice of the build (by batch size)."""
     import staticfusion_amd as sf
 
     return sf.load()
@@ -65,10 +80,10 @@ def pair():
     return _pairs()
 
 
-def make_solver(api, rows, cols, params, pair=None, batch=1):
+def make_solver(api, rows, cols, params, pair=None, batch=1, variant=None):
     import staticfusion_amd as sf
 
-    s = sf.Solver(api, rows, cols, batch, params)
+    s = sf.Solver(api, rows, cols, batch, params, variant=variant)
     if pair is not None:
         for b in range(batch):
             s.set_current(b, *pair["new"])

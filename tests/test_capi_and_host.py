@@ -65,6 +65,19 @@ def test_hip_library_fails_loudly_without_gpu():
     assert rc == -2 and b"no CPU fallback" in api.last_error()
 
 
+def test_create_ex_rejects_unknown_variants(ora):
+    """sf_create_ex: the build selector is validated before any device work (both libraries)."""
+    import staticfusion_amd as sf
+
+    for api in (sf.load(), ora):
+        p = api.default_params_struct()
+        h = ctypes.c_void_p()
+        assert api.create_ex(ctypes.byref(p), 240, 320, 1, 0, 7, ctypes.byref(h)) == -1
+        assert api.create_ex(ctypes.byref(p), 240, 320, 1, 0, -1, ctypes.byref(h)) == -1
+    s = sf.Solver(ora, 60, 80, 1, ora.default_params_struct(), variant="throughput")  # accepted and ignored by the oracle
+    assert s.variant() == ("auto", 1, 1)
+
+
 def test_default_params_are_the_driver_values(ora):
     """StaticFusion-datasets.cpp:79-94 and FrontEnd.cpp:57-76; both libraries must agree byte for byte."""
     import staticfusion_amd as sf

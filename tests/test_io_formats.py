@@ -247,7 +247,8 @@ def test_cpp_example_driver_matches_the_python_runner(hip, lib, tmp_path):
     write_dataset(root, 7)
     exe = build_example(tmp_path)
     out = str(tmp_path / "cpp.freiburg")
-    subprocess.check_call([exe, root, out])
+    # the example calls sf_create (SF_VARIANT_AUTO), which honours SF_VARIANT: same build of the frame kernel on both sides
+    subprocess.check_call([exe, root, out], env=dict(os.environ, SF_VARIANT=hip.default_variant))
     _, lines, _ = run(hip, lib, root)
     assert open(out).read() == "".join(lines)
 
@@ -389,7 +390,7 @@ def test_headless_example_is_the_python_fusion_loop(hip, lib, tmp_path):
     write_dataset(root, 8)
     exe = build_headless(tmp_path)
     prefix = str(tmp_path / "out")
-    msg = subprocess.check_output([exe, root, prefix]).decode()
+    msg = subprocess.check_output([exe, root, prefix], env=dict(os.environ, SF_VARIANT=hip.default_variant)).decode()
     _, lines, s = run(hip, lib, root, mode="fusion")
     assert open(prefix + ".freiburg").read() == "".join(lines), msg
     assert open(prefix + ".ply", "rb").read() == io_oracle.save_ply_bytes(s.map.download(), 0.25), msg

@@ -648,8 +648,10 @@ void StaticFusion::computeSegPrior() {
     int cluster_size[NUM_CLUSTERS], cluster_nonnull[NUM_CLUSTERS];
     const MatI &labels_ref = clusterAllocation[image_level];
 
+    double exact[NUM_CLUSTERS];  // exact_sums (test hook): the same terms accumulated in fp64
     for (int l = 0; l < NUM_CLUSTERS; l++) {
         b_prior[l] = 0.f;
+        exact[l] = 0.0;
         cluster_size[l] = 0;
         cluster_nonnull[l] = 0;
         lambda_t_w[l] = 0.f;
@@ -662,10 +664,13 @@ void StaticFusion::computeSegPrior() {
                 if (Null(v, u) == 0) {
                     cluster_nonnull[l]++;
                     b_prior[l] += 1.f - kz * std::abs(ddt(v, u));
+                    exact[l] += double(1.f - kz * std::abs(ddt(v, u)));
                 }
                 cluster_size[labels_ref(v, u)]++;
             }
         }
+    if (exact_sums)
+        for (int l = 0; l < NUM_CLUSTERS; l++) b_prior[l] = float(exact[l]);
 
     for (unsigned int l = 0; l < NUM_CLUSTERS; l++) {
         if (cluster_size[l] != 0) {
@@ -897,13 +902,18 @@ void StaticFusion::solveOdometryAndSegmJoint() {
         }
         const float aver_res_old = aver_res;
 
+        double exact_label[NUM_CLUSTERS];  // exact_sums (test hook): the same terms accumulated in fp64
+        for (int l = 0; l < NUM_CLUSTERS; l++) exact_label[l] = 0.0;
         for (size_t i = 0; i < N; ++i) {
             const std::pair<int, int> &vu = validPixels[i];
             const float ress_here = std::abs(res[2 * i]) + std::abs(res[2 * i + 1]);
             const int lab = segmentation_enabled ? labels_ref(vu.first, vu.second) : 0;
             aver_res_label[lab] += ress_here;
+            exact_label[lab] += double(ress_here);
             num_pix_label[lab]++;
         }
+        if (exact_sums)
+            for (int l = 0; l < NUM_CLUSTERS; l++) aver_res_label[l] = float(exact_label[l]);
         // aver_res_label.matrix().sumAll()  [C1]
         double ssum = 0.0;
         for (int l = 0; l < NUM_CLUSTERS; l++) ssum += double(aver_res_label[l]);
@@ -1239,7 +1249,11 @@ void StaticFusion::computeResidualsAgainstPreviousImage(int index) {
     // residuals, overall and cluster-wise (:1036-1068)
     for (int l = 0; l < NUM_CLUSTERS; l++) perClusterAverageResidual[l] = std::numeric_limits<float>::quiet_NaN();
     int num_pix_label[NUM_CLUSTERS];
-    for (int l = 0; l < NUM_CLUSTERS; l++) num_pix_label[l] = 1;
+    double exact[NUM_CLUSTERS];  // exact_sums (test hook)
+    for (int l = 0; l < NUM_CLUSTERS; l++) {
+        num_pix_label[l] = 1;
+        exact[l] = 0.0;
+    }
 
     for (unsigned int j = 0; j < cols; j++)
         for (unsigned int i = 0; i < rows; i++) {
@@ -1252,9 +1266,13 @@ void StaticFusion::computeResidualsAgainstPreviousImage(int index) {
                     perClusterAverageResidual[lab] = cumulative;
                 else
                     perClusterAverageResidual[lab] += cumulative;
+                exact[lab] += double(cumulative);
                 num_pix_label[lab]++;
             }
         }
+    if (exact_sums)
+        for (int l = 0; l < NUM_CLUSTERS; l++)
+            if (!std::isnan(perClusterAverageResidual[l])) perClusterAverageResidual[l] = float(exact[l]);
     for (int l = 0; l < NUM_CLUSTERS; l++) perClusterAverageResidual[l] /= float(2 * num_pix_label[l]);
 }
 

@@ -195,6 +195,10 @@ class StaticFusion {
     // ---- not in the reference ----
     bool segmentation_enabled = true;  // false: "b_segm.fill(1.f)" alternative, FrontEnd.cpp:606-607
     FrameStats stats;
+    bool exact_sums = false;                // test hook (sfo_test_set_exact_sums): the per-cluster float sums the reference
+                                            // accumulates sequentially in fp32 (computeSegPrior, the IRLS residual sums,
+                                            // the 5-frame residuals) are accumulated in fp64 instead -- what the formula
+                                            // means without the reference's own summation error
     bool keep_rows = false;                 // test hook: keep the Jacobian of the last outer iteration
     std::vector<float> dbg_A, dbg_B;        // column-major 2N x 6 / 2N (FrontEnd.cpp:539-586), only with keep_rows
 

@@ -447,6 +447,12 @@ int sfo_level_rows(const sf_handle *h, int level) { return h ? (h->rows >> level
 int sfo_level_cols(const sf_handle *h, int level) { return h ? (h->cols >> level) : 0; }
 int sfo_batch(const sf_handle *h) { return h ? h->batch : 0; }
 
+// test hook (not part of include/sf.h): accumulate the reference's sequential fp32 per-cluster sums in fp64 instead
+int sfo_test_set_exact_sums(sf_handle *h, int on) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    for (auto &s : h->s) s->exact_sums = on != 0;
+    return SF_OK;
+}
 // test hook (not part of include/sf.h): the weight function of include/sf_detmath.h, evaluated by this library
 void sfo_test_exp_neg(const float *a, int n, float *out) {
     for (int i = 0; i < n; i++) out[i] = sf_exp_neg(a[i]);

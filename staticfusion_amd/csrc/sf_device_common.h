@@ -76,6 +76,7 @@ struct StreamState {
     float hist_T[SF_HISTORY][16];   // odomBuffer
     float kb;
     int32_t last_level;             // image level of the last executed outer iteration
+    int32_t last_first;             // 1 if that iteration ran on Warped := Pred (the first of a solve)
     float inv_max_c, inv_max_d;     // 1/max of the raw pre-weights of that iteration
     long long cum_frames, cum_irls, cum_outer, cum_pixel_iters;  // totals since sf_create
     long long prof[SF_PROF_SLOTS];  // cumulative 100 MHz ticks per stage (lane 0 of the workgroup)

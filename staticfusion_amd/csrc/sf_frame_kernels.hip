@@ -22,6 +22,7 @@
 #define SF_VARIANT_FN(name) SF_PASTE(SF_PASTE(name, _nt), SF_VARIANT_TAG)
 #define sf_frame_kernel SF_VARIANT_FN(sf_frame_kernel)
 #define sf_irls_pass_kernel SF_VARIANT_FN(sf_irls_pass_kernel)
+#define sf_debug_rows_kernel SF_VARIANT_FN(sf_debug_rows_kernel)
 
 union FrameShared {
     KmShared km;
@@ -113,6 +114,14 @@ __global__ __launch_bounds__(SF_NT, 4) void sf_irls_pass_kernel(const KArgs *__r
     }
 }
 
+
+// test support: the Jacobian rows of one stream's last outer iteration (sf_get_jacobian_rows); never part of a solve
+__global__ __launch_bounds__(SF_NT) void sf_debug_rows_kernel(const KArgs *__restrict__ ka, int b, float *out) {
+    debug_rows(*ka, b, out, blockIdx.x * SF_NT + threadIdx.x, gridDim.x * SF_NT);
+}
+extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_launch_debug_rows)(int grid, hipStream_t st, const KArgs *ka, int b, float *out) {
+    hipLaunchKernelGGL(sf_debug_rows_kernel, dim3(grid), dim3(SF_NT), 0, st, ka, b, out);
+}
 
 extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_launch_frame)(int grid, hipStream_t st, const KArgs *ka, int stage_mask, int im_count) {
     hipLaunchKernelGGL(sf_frame_kernel, dim3(grid), dim3(SF_NT), 0, st, ka, stage_mask, im_count);

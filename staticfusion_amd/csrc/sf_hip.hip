@@ -28,16 +28,19 @@ struct FrameVariant {
     void (*geometry)(int *threads, int *blocks_per_cu);
     void (*launch_frame)(int grid, hipStream_t st, const KArgs *ka, int stage_mask, int im_count);
     void (*launch_irls_pass)(int grid, hipStream_t st, const KArgs *ka, int which, int variant, int reps, int slices);
+    void (*launch_debug_rows)(int grid, hipStream_t st, const KArgs *ka, int b, float *out);
 };
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_nt256(int, hipStream_t, const KArgs *, int, int);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_irls_pass_nt256(int, hipStream_t, const KArgs *, int, int, int, int);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_nt1024(int, hipStream_t, const KArgs *, int, int);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_irls_pass_nt1024(int, hipStream_t, const KArgs *, int, int, int, int);
+extern "C" __attribute__((visibility("hidden"))) void sf_launch_debug_rows_nt256(int, hipStream_t, const KArgs *, int, float *);
+extern "C" __attribute__((visibility("hidden"))) void sf_launch_debug_rows_nt1024(int, hipStream_t, const KArgs *, int, float *);
 extern "C" __attribute__((visibility("hidden"))) void sf_variant_geometry_nt256(int *, int *);
 extern "C" __attribute__((visibility("hidden"))) void sf_variant_geometry_nt1024(int *, int *);
 static const FrameVariant VARIANTS[2] = {
-    {SF_VARIANT_THROUGHPUT, "throughput", sf_variant_geometry_nt256, sf_launch_frame_nt256, sf_launch_irls_pass_nt256},
-    {SF_VARIANT_LATENCY, "latency", sf_variant_geometry_nt1024, sf_launch_frame_nt1024, sf_launch_irls_pass_nt1024},
+    {SF_VARIANT_THROUGHPUT, "throughput", sf_variant_geometry_nt256, sf_launch_frame_nt256, sf_launch_irls_pass_nt256, sf_launch_debug_rows_nt256},
+    {SF_VARIANT_LATENCY, "latency", sf_variant_geometry_nt1024, sf_launch_frame_nt1024, sf_launch_irls_pass_nt1024, sf_launch_debug_rows_nt1024},
 };
 
 // =============================================================================================
@@ -180,7 +183,9 @@ const char *sf_last_error(void) { return g_err.c_str(); }
 const char *sf_backend(void) { return "hip:gfx950"; }
 
 static int validate_params(const sf_params *p, int levels) {
-    if (levels < 2 || levels > SF_MAX_LEVELS) return fail(SF_ERR_ARG, "ctf_levels must be in [2, 8]");
+    // K-means clusters image level 1 (KMeans.cpp:145): a one-level pyramid is only meaningful without segmentation
+    if (levels < (p->segmentation_enabled ? 2 : 1) || levels > SF_MAX_LEVELS)
+        return fail(SF_ERR_ARG, "ctf_levels must be in [2, 8] (1 is accepted with segmentation_enabled = 0)");
     if (p->max_iter_per_level < 1 || p->max_iter_irls < 1 || levels * p->max_iter_per_level > SF_MAX_OUTER)
         return fail(SF_ERR_ARG, "iteration counts out of range");
     return SF_OK;
@@ -633,6 +638,43 @@ int sf_get_plane(sf_handle *h, int stream, int set, int channel, int level, floa
     const float *base = tab[set][channel];
     if (!base) return fail(SF_ERR_STATE, "WARPED / INTER planes need params.debug_planes = 1 at sf_create");
     return d2h(h, out, base + off, sizeof(float) * n);
+}
+
+int sf_get_jacobian_rows(sf_handle *h, int stream, float *A, float *B, int *n_rows) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!n_rows) return fail(SF_ERR_ARG, "null");
+    if (!h->k.p.debug_planes) return fail(SF_ERR_STATE, "the Jacobian rows need params.debug_planes = 1");
+    HIP_TRY(hipSetDevice(h->device));
+    StreamState st;
+    if (int e = d2h(h, &st, &h->k.state[stream], sizeof(st))) return e;
+    const int L = st.last_level;
+    if (L < 0 || L >= h->k.levels || st.cum_frames == 0) return fail(SF_ERR_STATE, "no outer iteration executed yet");
+    const size_t n = h->k.ln[L];
+    float *dev = nullptr;
+    HIP_TRY(hipMalloc((void **)&dev, 14 * n * sizeof(float)));
+    std::vector<float> planes(14 * n);
+    if (h->args_dirty) {
+        HIP_TRY(hipMemcpyAsync(h->d_args, &h->k, sizeof(KArgs), hipMemcpyHostToDevice, h->stream));
+        h->args_dirty = false;
+    }
+    h->fv->launch_debug_rows(int((n + 1023) / 1024), h->stream, (const KArgs *)h->d_args, stream, dev);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(planes.data(), dev, planes.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(SF_ERR_DEVICE, std::string("sf_get_jacobian_rows: ") + hipGetErrorString(e));
+    int rows = 0;  // validPixels order of the reference = ascending column-major index (u outer, v inner)
+    for (size_t q = 0; q < n; q++) {
+        if (std::isnan(planes[q])) continue;
+        for (int half = 0; half < 2; half++) {
+            if (A)
+                for (int c = 0; c < 6; c++) A[(size_t)rows * 6 + c] = planes[(size_t)(7 * half + c) * n + q];
+            if (B) B[rows] = planes[(size_t)(7 * half + 6) * n + q];
+            rows++;
+        }
+    }
+    *n_rows = rows;
+    return SF_OK;
 }
 
 int sf_get_lin_plane(sf_handle *h, int stream, int which, float *out, int *rows, int *cols) {

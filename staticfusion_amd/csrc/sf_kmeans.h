@@ -33,8 +33,6 @@ struct KmShared {
     vfloat4 cent4[SF_NC];          // (z, x, y, 0) of centre l: one 16-byte LDS read
     int wcnt[SF_NW][SF_NC];        // members per (wave range, label); then exclusive offsets
     int count[SF_NC];
-    int off[SF_NC];
-    int ccount[SF_NC];             // members of the current chunk per label
     unsigned conn[SF_NC];
     unsigned useed[SF_NC], vseed[SF_NC];
     unsigned prefix[SF_NC], krank[SF_NC];
@@ -97,7 +95,7 @@ __device__ __forceinline__ int km_search(const LDS KmShared &s, int last, float 
 // search has ended ride along without effect. act[k] = false: pixel k is not searched (best[k] = last[k]).
 template <int N>
 __device__ __forceinline__ void km_search_n(const LDS KmShared &s, const int (&last)[N], const float (&pz)[N], const float (&px)[N],
-                                            const float (&py)[N], const bool (&act)[N], int (&best)[N]) {
+                                            const float (&py)[N], const bool (&act)[N], int (&best)[N], int *trips = nullptr) {
     float best_d[N], lim[N];
     vfloat2 cd[N];
     bool run[N];
@@ -118,16 +116,27 @@ __device__ __forceinline__ void km_search_n(const LDS KmShared &s, const int (&l
             any = any || run[k];
         }
         if (!__any(any)) break;
+#ifdef SF_KM_FINE_PROFILE
+        if (trips) (*trips)++;
+#endif
         const int nxt = min(li + 1, SF_NC - 1);
+        // all 2 N LDS reads of the trip are issued before any of them is consumed (the compiler otherwise sinks every read
+        // next to its use and waits for each in turn: N dependent LDS round trips per trip instead of one)
+        vfloat4 cc[N];
+        vfloat2 cdn[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) cc[k] = s.cent4[__float_as_int(cd[k].y)];
+#pragma unroll
+        for (int k = 0; k < N; k++) cdn[k] = s.cand[last[k] * SF_NC + nxt];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < N; k++) {
             const int c = __float_as_int(cd[k].y);
-            const vfloat4 cc = s.cent4[c];
-            cd[k] = s.cand[last[k] * SF_NC + nxt];
-            const float dl = sqdist3(cc.x, cc.y, cc.z, pz[k], px[k], py[k]);
+            const float dl = sqdist3(cc[k].x, cc[k].y, cc[k].z, pz[k], px[k], py[k]);
             const bool upd = run[k] && (dl < best_d[k]);
             best_d[k] = upd ? dl : best_d[k];
             best[k] = upd ? c : best[k];
+            cd[k] = cdn[k];
         }
     }
 }
@@ -148,6 +157,19 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
             kt = now_;                             \
         }                                          \
     } while (0)
+#ifdef SF_KM_FINE_PROFILE  // profiling build (make kmprof): phases of the Lloyd chunk loop (register accumulators, flushed once)
+    long long fine[SF_PROF_SLOTS] = {};
+#define KM_FINE(slot)                              \
+    do {                                           \
+        if (tid == 0) {                            \
+            const long long now_ = wall_clock64(); \
+            fine[slot] += now_ - kt;               \
+            kt = now_;                             \
+        }                                          \
+    } while (0)
+#else
+#define KM_FINE(slot) do {} while (0)
+#endif
 
     // ------------------------------------------------------------------ initializeKMeans (K1)
     const int rows_km = a.lrows[1], cols_km = a.lcols[1], n1 = a.ln[1], o1 = a.loff[1];
@@ -206,23 +228,31 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
                     lds_add(&s.hist[lb[k] * 256 + ((bits[k] >> shift) & 255u)], 1u);
         }
         __syncthreads();
-        if (tid < SF_NC) {
-            if (pass == 0) {
-                unsigned size = 0;
-                for (int q = 0; q < 256; q++) size += s.hist[tid * 256 + q];
-                s.count[tid] = (int)size;
-                s.krank[tid] = size / 2;
-            }
-            if (s.count[tid] > 0) {
-                unsigned k = s.krank[tid], cum = 0;
-                int bin = 0;
-                for (; bin < 256; bin++) {
-                    const unsigned h = s.hist[tid * 256 + bin];
-                    if (cum + h > k) break;
-                    cum += h;
+        // per label: the bin that holds rank k. One wave per label (four bins per lane, an inclusive DPP scan over the lane
+        // totals, a ballot for the first lane whose running count exceeds k) instead of 24 lanes walking 256 bins each.
+        for (int l = wave; l < SF_NC; l += SF_NW) {
+            typedef unsigned __attribute__((ext_vector_type(4))) vuint4;
+            const vuint4 h4 = *(const LDS vuint4 *)&s.hist[l * 256 + 4 * lane];
+            const int p0 = (int)h4.x, p1 = p0 + (int)h4.y, p2 = p1 + (int)h4.z, p3 = p2 + (int)h4.w;
+            int incl = p3;
+            SF_DPP_REDUCE(incl, dpp_i32, sf_op_add)  // inclusive scan: lane 63 holds the label's size (pass 0) / the bucket's size
+            const int size = __builtin_amdgcn_readlane(incl, 63);
+            const unsigned k = (pass == 0) ? (unsigned)size / 2u : s.krank[l];
+            if (pass == 0 && lane == 0) s.count[l] = size;
+            if ((pass == 0 ? size : s.count[l]) > 0) {
+                const unsigned long long over = __ballot((unsigned)incl > k);
+                const int src = __ffsll((long long)over) - 1;  // first lane whose bins reach rank k
+                if (lane == src) {
+                    const unsigned cum0 = (unsigned)(incl - p3);
+                    int bin;
+                    unsigned cum;
+                    if (cum0 + (unsigned)p0 > k) { bin = 0; cum = cum0; }
+                    else if (cum0 + (unsigned)p1 > k) { bin = 1; cum = cum0 + (unsigned)p0; }
+                    else if (cum0 + (unsigned)p2 > k) { bin = 2; cum = cum0 + (unsigned)p1; }
+                    else { bin = 3; cum = cum0 + (unsigned)p2; }
+                    s.prefix[l] = (s.prefix[l] << 8) | (unsigned)(4 * lane + bin);
+                    s.krank[l] = k - cum;
                 }
-                s.prefix[tid] = (s.prefix[tid] << 8) | (unsigned)bin;
-                s.krank[tid] = k - cum;
             }
         }
         __syncthreads();
@@ -293,7 +323,17 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
                 valid[k] = (idx < n1) && pz[k] != 0.f;
                 old[k] = valid[k] ? old[k] : 0;  // a safe table row for pixels that are not searched
             }
+#ifdef SF_KM_FINE_PROFILE
+            int trips = 0;
+            km_search_n<SF_LOAD_BATCH>(s, old, pz, px, py, valid, best, &trips);
+            if (tid == 0) {
+                fine[21] += trips;
+                fine[22] += 1;
+            }
+#else
             km_search_n<SF_LOAD_BATCH>(s, old, pz, px, py, valid, best);
+#endif
+            KM_FINE(PF_KM_ASSIGN);
             // members of this wave's part of the chunk per label (lane l < 24 holds the count of label l), and for every
             // pixel its rank among the wave's members of the same label in pixel order (k-major, then lane): one pass of
             // ballots gives both
@@ -317,50 +357,72 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
             }
             if (lane < SF_NC) s.wcnt[wave][lane] = cnt;
             __syncthreads();  // also: the previous chunk's sums have consumed s.chunk
-            if (tid < 64) {  // wave 0: exclusive offsets over the waves per label, then over the labels (a 24-lane scan)
-                int run = 0;
-                if (tid < SF_NC)
-                    for (int w = 0; w < SF_NW; w++) {
-                        const int c = s.wcnt[w][tid];
-                        s.wcnt[w][tid] = run;
-                        run += c;
-                    }
-                int incl = run;
+            // every wave derives the offsets itself: lane l < 24 sums the waves' counts of label l (members in earlier waves,
+            // members in the chunk), an inclusive DPP scan over the labels gives the cluster's run start
+            int before = 0, members = 0;
+            if (lane < SF_NC) {
+                int c[SF_NW];
 #pragma unroll
-                for (int o = 1; o < 32; o <<= 1) {
-                    const int up = __shfl_up(incl, o, 64);
-                    if (lane >= o) incl += up;
-                }
-                if (tid < SF_NC) {
-                    s.ccount[tid] = run;
-                    s.off[tid] = incl - run;
+                for (int w = 0; w < SF_NW; w++) c[w] = s.wcnt[w][lane];
+#pragma unroll
+                for (int w = 0; w < SF_NW; w++) {
+                    before += (w < wave) ? c[w] : 0;
+                    members += c[w];
                 }
             }
-            __syncthreads();
+            int incl = members;  // lanes >= 24 hold 0: the scan over the first two rows is the scan over the labels
+            incl += dpp_i32<0x111, 0xf>(incl);
+            incl += dpp_i32<0x112, 0xf>(incl);
+            incl += dpp_i32<0x114, 0xf>(incl);
+            incl += dpp_i32<0x118, 0xf>(incl);
+            incl += dpp_i32<0x142, 0xa>(incl);
+            const int run_start = incl - members;         // lane l: where cluster l's run begins in s.chunk
+            const int my_base = run_start + before;       // ... and where this wave's members of it begin
             // stable positions: cluster run start + members in earlier waves + members earlier in this wave
 #pragma unroll
-            for (int k = 0; k < SF_LOAD_BATCH; k++)
+            for (int k = 0; k < SF_LOAD_BATCH; k++) {
+                const int base_k = __builtin_amdgcn_ds_bpermute(best[k] << 2, my_base);
                 if (valid[k]) {
-                    const int pos = s.off[best[k]] + s.wcnt[wave][best[k]] + rank[k];
+                    const int pos = base_k + rank[k];
                     s.chunk[0][pos] = pz[k];
                     s.chunk[1][pos] = px[k];
                     s.chunk[2][pos] = py[k];
                 }
+            }
+            const int sum_c = (tid < 3 * SF_NC) ? tid / 3 : 0;  // lane (c, r) of the ordered sums: its cluster's run
+            const int sum_n = __builtin_amdgcn_ds_bpermute(sum_c << 2, members);
+            const int sum_o = __builtin_amdgcn_ds_bpermute(sum_c << 2, run_start);
             __syncthreads();
-            if (tid < 3 * SF_NC) {  // the ordered sums, continued over this chunk's members
-                const int c = tid / 3, r = tid - 3 * c;
-                const int n = s.ccount[c], o = s.off[c];
+            KM_FINE(PF_KM_PARTITION);
+            if (tid < 3 * SF_NC) {  // the ordered sums, continued over this chunk's members: strictly front to back per sum;
+                                    // the next eight values are in flight while the current eight are added
+                const int r = tid - 3 * sum_c;
+                const LDS float *src = &s.chunk[r][sum_o];
+                const int n = sum_n;
+                float v[8], w[8];
                 int j = 0;
-                for (; j + 8 <= n; j += 8) {
-                    float v[8];
+                if (n >= 8) {
 #pragma unroll
-                    for (int q = 0; q < 8; q++) v[q] = s.chunk[r][o + j + q];
+                    for (int q = 0; q < 8; q++) v[q] = src[q];
+                }
+                for (; j + 16 <= n; j += 8) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) w[q] = src[j + 8 + q];
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int q = 0; q < 8; q++) acc += v[q];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) v[q] = w[q];
                 }
-                for (; j < n; j++) acc += s.chunk[r][o + j];
+                if (j + 8 <= n) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) acc += v[q];
+                    j += 8;
+                }
+                for (; j < n; j++) acc += src[j];
             }
-            if (tid < SF_NC) total += s.ccount[tid];
+            if (tid < SF_NC) total += members;
+            KM_FINE(PF_KM_SUM);
         }
         __syncthreads();
         if (tid < SF_NC) s.count[tid] = total;
@@ -387,6 +449,15 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
     }
     if (tid < 3 * SF_NC) st.kmeans[tid] = s.cent_a[tid];
     if (tid == 0) a.stats[b].kmeans_iters = iters;
+#ifdef SF_KM_FINE_PROFILE
+    if (tid == 0) {
+        st.prof[PF_KM_ASSIGN] += fine[PF_KM_ASSIGN];
+        st.prof[PF_KM_PARTITION] += fine[PF_KM_PARTITION];
+        st.prof[PF_KM_SUM] += fine[PF_KM_SUM];
+        st.prof[21] += fine[21];
+        st.prof[22] += fine[22];
+    }
+#endif
 
     // ------------------------------------------------------------------ labels at full resolution
     km_sort_centres(s, tid);
@@ -500,4 +571,5 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
     __syncthreads();
     KM_MARK(PF_KM_CONN_PYR);
 #undef KM_MARK
+#undef KM_FINE
 }

@@ -378,7 +378,11 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                 const float dct_ = s.lt.t_in[e] - s.lt.t_iw[e];
                 ddt_ = dn - dw;
                 lab = seg ? (k ? c_lab1 : c_lab0) : ((dn != 0.f) ? 0 : SF_NC);
-                valid = !nul && (u != 0) && (v != 0) && (u != cols_i - 1) && (v != rows_i - 1);
+                // validPixels (reference :415-427). Departure: a point warped BEHIND the camera that still projects into the
+                // image gives a negative warped depth, which the reference keeps in validPixels (:816-823 has no depth test);
+                // here such a pixel is left out everywhere (counts, sums, passes), because the sign of the stored warped
+                // depth is what marks membership for the passes. It needs a diverged pose to happen at all.
+                valid = !nul && (dw > 0.f) && (u != 0) && (v != 0) && (u != cols_i - 1) && (v != rows_i - 1);
                 float dcu_ = 0.f, dcv_ = 0.f, ddu_ = 0.f, ddv_ = 0.f;
                 if (valid) {
                     const int eL = e - TILE_LV, eR = e + TILE_LV, eU = e - 1, eD = e + 1;  // (v,u-1) (v,u+1) (v-1,u) (v+1,u)
@@ -1165,6 +1169,7 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, LDS SolveShared 
         fs.pixel_iters = s.pixel_iters;
         fs.status = s.status;
         st.last_level = last_L;
+        st.last_first = s.first;
         st.cum_frames += 1;
         st.cum_irls += s.n_irls;
         st.cum_outer += s.n_outer;
@@ -1190,6 +1195,54 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, LDS SolveShared 
     __syncthreads();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+//  test support (sf_get_jacobian_rows): the rows of A and B of the LAST outer iteration of stream b, expanded
+//  from the factored per-pixel form the passes evaluate: a_c = pc g1 + qc g2, a_d = twd g3 + pd g1 + qd g2,
+//  b_c = -bct, b_d = -bdt (see above). out = 14 planes of n pixels: a_c[0..5], b_c, a_d[0..5], b_d; pixels outside
+//  validPixels get NaN in plane 0. Never part of a solve.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void debug_rows(const KArgs &a, int b, float *out, int gtid, int gstride) {
+    const StreamState &st = a.state[b];
+    const int L = st.last_level;
+    const int n = a.ln[L], rows_i = a.lrows[L], cols_i = a.lcols[L];
+    const size_t rb = (size_t)b * a.n0;
+    const float f = float(cols_i) / (2.f * a.tan_half_fovh);
+    LevelGeom g;
+    g.rows_i = rows_i;
+    g.inv_rows = 1.f / float(rows_i);
+    g.disp_u_i = 0.5f * float(cols_i - 1);
+    g.disp_v_i = 0.5f * float(rows_i - 1);
+    g.inv_f_pyr = 2.f * a.tan_half_fovh / float(cols_i);
+    g.inv_f_w = 1.f / f;
+    g.f_inv = f;
+    g.kph = a.p.k_photometric_res;
+    g.inv_max_c = st.inv_max_c;
+    g.inv_max_d = st.inv_max_d;
+    g.first = st.last_first;
+    const float *dnew = a.pyr_new[0] + (size_t)b * a.n_tot + a.loff[L];
+    for (int idx = gtid; idx < n; idx += gstride) {
+        const float dw = a.rec[R_DW][rb + idx];
+        if (!(dw > 0.f)) {
+            out[idx] = __int_as_float(0x7fc00000);
+            continue;
+        }
+        float fu, fv;
+        split_index(g, idx, fu, fv);
+        PixFact<float> p;
+        fact_from_record<float>(g, fu, fv, dnew[idx], dw, a.rec[R_DCU][rb + idx], a.rec[R_DCV][rb + idx], a.rec[R_DCT][rb + idx],
+                                a.rec[R_DDU][rb + idx], a.rec[R_DDV][rb + idx], p);
+        const float g1[6] = {-1.f, 0.f, p.xd, p.xyd, -p.xxd, p.y};
+        const float g2[6] = {0.f, -1.f, p.yd, p.yyd, -p.xyd, -p.x};
+        const float g3[6] = {0.f, 0.f, 1.f, p.y, -p.x, 0.f};
+        for (int c = 0; c < 6; c++) {
+            out[(size_t)c * n + idx] = fmaf(p.pc, g1[c], p.qc * g2[c]);
+            out[(size_t)(7 + c) * n + idx] = fmaf(p.twd, g3[c], fmaf(p.pd, g1[c], p.qd * g2[c]));
+        }
+        out[(size_t)6 * n + idx] = -p.bct;
+        out[(size_t)13 * n + idx] = -p.bdt;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 //  measurement support: the two IRLS streaming passes in isolation, over the level-0 records the

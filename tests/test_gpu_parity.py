@@ -134,9 +134,10 @@ def test_golden_fixtures_on_the_hip_path(hip):
 
     test_golden.check_pyramid(hip)
     test_golden.check_linearise_and_first_irls(hip)
-    test_golden.check_lin_planes_single_level(hip)
+    # the HIP path expands A from its factored rows (another association, FMA) and its IRLS weights use the hardware rsq
+    test_golden.check_lin_planes_single_level(hip, tol_rows=5e-6, tol_ata=5e-6)
     test_golden.check_kmeans(hip)
-    test_golden.check_full_solve(hip, tol=5e-6, tol_b=5e-4)  # the HIP path's IRLS weights use the hardware rsq / rcp
+    test_golden.check_full_solve(hip, tol=5e-6, tol_b=2e-4, tol_prior=2e-5)  # the HIP path's IRLS weights use the hardware rsq / rcp
     test_golden.check_history_residuals(hip, tol=2e-5)
     g = np.load(os.path.join(GOLDEN, "segm_image_160x120.npz"))
     s = make_solver(hip, 120, 160, driver_params(hip))
@@ -200,7 +201,7 @@ def test_edge_cases(hip, ora, pair):
     d = big["new"][0].copy()
     d[:, :70] = 0
     sg, so = solve_both(hip, ora, 120, 160, lambda a: driver_params(a), {"new": (d, big["new"][1]), "old": big["old"]})
-    assert_traces_match(sg, so, tol_twist=1e-5, tol_b=1e-3)  # stress case: large motion, half the image invalid
+    assert_traces_match(sg, so, tol_twist=1e-5, tol_b=3e-4)  # stress case: large motion, half the image invalid
     rot, trans = pose_delta(so.T(), sg.T())
     assert rot <= POSE_TOL and trans <= POSE_TOL
 
@@ -325,7 +326,7 @@ def test_vga_resolution_six_levels(hip, ora):
         assert np.array_equal(sg.plane(capi.SET_NEW, capi.CH_DEPTH, L), so.plane(capi.SET_NEW, capi.CH_DEPTH, L))
     assert np.array_equal(sg.kmeans_centres(), so.kmeans_centres())
     # the oracle sums 600k residuals sequentially in float32 (reference FrontEnd.cpp:655-664): ~1e-3 relative
-    assert_traces_match(sg, so, tol_twist=5e-6, rtol_aver=2e-3, tol_b=3e-3)
+    assert_traces_match(sg, so, tol_twist=5e-6, rtol_aver=2e-3, tol_b=1e-3)
     rot, trans = pose_delta(so.T(), sg.T())
     assert rot <= POSE_TOL and trans <= POSE_TOL
     assert np.array_equal(sg.b_image() > 0.5, so.b_image() > 0.5)
@@ -346,4 +347,4 @@ def test_many_seeds_small(hip, ora, pair, seed):
         assert np.array_equal(sg.labels(L), so.labels(L))
     rot, trans = pose_delta(so.T(), sg.T())
     assert rot <= POSE_TOL and trans <= POSE_TOL
-    assert np.abs(sg.b() - so.b()).max() < 1e-3
+    assert np.abs(sg.b() - so.b()).max() < 2e-4

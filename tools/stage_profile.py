@@ -11,9 +11,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--workload", default="static")
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--lib", default=None, help="another build of the library (e.g. staticfusion_amd/csrc/libsf_hip_kmprof.so)")
+ap.add_argument("--variant", default="auto")
 ap.add_argument("--res-factor", type=int, default=2, help="2: QVGA 320x240 (the drivers' setting), 1: VGA 640x480")
 a = ap.parse_args()
-api = sf.load()
+api = (sf.load() if a.lib is None else sf.Api(a.lib, "sf_")).with_variant(a.variant)
 rows, cols = 480 // a.res_factor, 640 // a.res_factor
 p = bench.make_params(api, a.workload)
 if a.res_factor == 1 and a.workload == "static":
@@ -36,3 +38,9 @@ tot = p1["total"] - p0["total"]
 for k in s.STAGES:
     d = p1[k] - p0[k]
     print("  %-11s %8.1f us/frame  %5.1f %%" % (k, 1e6 * d / frames, 100 * d / tot))
+
+if a.lib and "kmprof" in a.lib:
+    import ctypes
+    t = (ctypes.c_int64 * 24)()
+    api.check(api.get_stage_profile(s.h, t))
+    print("  Lloyd search trips (wave 0): %d over %d chunks = %.2f per chunk; k-means iterations of stream 0: %d" % (t[21], t[22], t[21] / max(1, t[22]), s.stats(0).kmeans_iters))

@@ -11,19 +11,28 @@ resident in HBM: the reference drivers' per-frame sequence
 (reference StaticFusion-datasets.cpp:171-184) for every stream of the batch = one launch of
 `sf_frame_kernel` through the C ABI (sf_process_frame).
 
-Workload (default): BASELINE.json configs[1] — synthetic static RGB-D pairs (VGA render decimated
-to QVGA 320x240), 3-level pyramid, segmentation disabled (pure 6-DoF Cauchy IRLS), constructor
-parameters (max_iter_irls 10, delta 1e-6, no motion filter).  `--workload sphere` runs configs[2]
-(moving sphere, full solver, K-means 24, b-field, driver parameters, 5 levels).
+Workloads
+  static     BASELINE.json configs[1] (the configuration `metric` is quoted on): synthetic static RGB-D pairs (VGA
+             render decimated to QVGA 320x240), 3-level pyramid, segmentation disabled (pure 6-DoF Cauchy IRLS),
+             constructor parameters (max_iter_irls 10, delta 1e-6, no motion filter).  THE DEFAULT: `value`.
+             The default run ALSO times configs[2] in the same process and reports it as the `full_solver` block.
+  sphere     BASELINE.json configs[2]: moving sphere, full solver, K-means(24), b-field, driver parameters, 5 levels.
+  sequences  SURVEY.md section 8(d) config 5 / BASELINE configs[4] shape: per rank, independent synthetic SEQUENCES (seeds
+             1000 + rank ..., smooth random-walk camera, a sphere swinging through the room), resident in HBM; every
+             step advances every stream by one frame with the previous frame as prediction (frame-to-frame, the
+             dataset drivers' loop without the map), so iteration counts are data dependent and streams diverge.
 
 metric  = solver iterations/s: executions of the IRLS loop body (reference FrontEnd.cpp:611-684)
           summed over all streams, steps and GPUs, divided by the wall time of the K timed steps
           (max over ranks).  frames/s is reported beside it.
-Multi-GPU: independent streams per GPU (no data-path collective), weak scaling.
+Multi-GPU: independent streams per GPU (no data-path collective), weak scaling; the line carries world_size and the
+per-rank rates so that the rank count RCCL saw can be checked from the output.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,6 +43,15 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+WORKLOAD_TEXT = {
+    "static": ("BASELINE.json configs[1]: synthetic static RGB-D pairs, VGA->QVGA 320x240, 3-level pyramid, "
+               "segmentation disabled (pure 6-DoF Cauchy IRLS)"),
+    "sphere": ("BASELINE.json configs[2]: synthetic QVGA pairs with a moving sphere, full solver, "
+               "K-means(24) + b-field, driver parameters, 5 levels"),
+    "sequences": ("SURVEY 8(d) config 5: independent synthetic QVGA sequences per rank (seeds 1000 + rank ..., smooth random-walk "
+                  "camera, swinging sphere), frame-to-frame prediction, full solver, K-means(24) + b-field, driver parameters"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -41,8 +59,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16384, help="independent streams per GPU (8.3 MB of HBM each: 136 GB); 16 rounds of the 1024 resident workgroups")
-    ap.add_argument("--workload", choices=["static", "sphere"], default="static")
+    ap.add_argument("--workload", choices=["static", "sphere", "sequences"], default="static")
+    ap.add_argument("--variant", choices=["auto", "throughput", "latency", "cluster"], default="auto", help="frame-kernel build (sf_create_ex)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pairs (tiled over the batch)")
+    ap.add_argument("--seq-distinct", type=int, default=4, help="sequences workload: distinct sequences per rank")
+    ap.add_argument("--seq-frames", type=int, default=200, help="sequences workload: frames per sequence")
+    ap.add_argument("--no-full-solver", action="store_true", help="static workload: skip the configs[2] block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
@@ -92,74 +114,144 @@ def reduce_over_ranks(dist, device, elapsed, iters, frames):
     return float(t.item()), float(c[0].item()), float(c[1].item())
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+def gather_per_rank(dist, device, elapsed, iters, frames):
+    """[(elapsed, iters, frames)] of every rank, in rank order: evidence of the ranks the collective saw."""
+    if dist is None:
+        return [(elapsed, float(iters), float(frames))]
+    import torch
 
-    import torch  # plumbing only: device sync + torch.distributed (RCCL) barrier / reductions
+    mine = torch.tensor([elapsed, float(iters), float(frames)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [tuple(float(x) for x in t.tolist()) for t in out]
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    # Test hooks (tests/test_gpu_parity_sweep.py runs the N > 1 flow on a one-GPU box): SF_BENCH_BACKEND=gloo does the
-    # barrier / reductions over gloo on CPU tensors, SF_BENCH_SINGLE_GPU=1 puts every rank on cuda:0. The driver's runs
-    # use neither: one rank per GPU, RCCL ("nccl").
-    backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
-    dev_index = 0 if os.environ.get("SF_BENCH_SINGLE_GPU") else local_rank
-    torch.cuda.set_device(dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    reduce_device = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
+def source_sha():
+    """Identity of the device code a measurement belongs to: sha256 over the kernel sources and headers."""
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "staticfusion_amd", "csrc")
+    files = sorted(f for f in os.listdir(base) if f.endswith((".h", ".hip", ".cpp")) or f == "Makefile")
+    for f in files + ["../../include/sf.h", "../../include/sf_detmath.h"]:
+        with open(os.path.join(base, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
+
+
+def measured_traffic(workload, batch, variant):
+    """HBM bytes per launch from the PMC counters (tools/measure_traffic.sh writes profiles/traffic_*.json together with the
+    identity of the sources it measured). A file that belongs to other sources, another batch or another build of the
+    kernel is NOT reported: null plus the reason."""
+    path = os.path.join(ROOT, "profiles", "traffic_%s_b%d.json" % (workload, batch))
+    if not os.path.exists(path):
+        return None, "no PMC measurement for this workload and batch (tools/measure_traffic.sh)"
+    with open(path) as f:
+        t = json.load(f)
+    now = source_sha()
+    if t.get("src_sha") != now or t.get("batch") != batch or t.get("variant", variant) != variant:
+        return None, "stale: measured on sources %s (batch %s, %s), running %s" % (t.get("src_sha"), t.get("batch"), t.get("variant"), now)
+    return {"hbm_bytes_per_launch": t["hbm_bytes_per_launch"], "src_sha": t["src_sha"], "head": t.get("head"), "batch": t["batch"],
+            "variant": t.get("variant"), "ratio_to_algorithmic": None}, None
+
+
+class Harness:
+    """Device selection, process group and the barrier of the contract."""
+
+    def __init__(self, args):
+        import torch  # plumbing only: device sync + torch.distributed (RCCL) barrier / reductions
+
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus and self.world > 1:
+            args.gpus = self.world
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+        # Test hooks (tests/test_gpu_parity_sweep.py runs the N > 1 flow on a one-GPU box): SF_BENCH_BACKEND=gloo does the
+        # barrier / reductions over gloo on CPU tensors, SF_BENCH_SINGLE_GPU=1 puts every rank on cuda:0. The driver's runs
+        # use neither: one rank per GPU, RCCL ("nccl").
+        self.backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
+        self.dev_index = 0 if os.environ.get("SF_BENCH_SINGLE_GPU") else self.local_rank
+        torch.cuda.set_device(self.dev_index)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.dev_index))
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+            self.dist = dist
+        self.reduce_device = torch.device("cuda", self.dev_index) if self.backend == "nccl" else torch.device("cpu")
+
+    def barrier(self, solver):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+        solver.synchronize()
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def oracle_check(pairs, workload, T_first, solver, n=4):
+    """Parity of the first frame against the CPU oracle on the first n distinct pairs (the checker: never timed)."""
     import staticfusion_amd as sf
-    from staticfusion_amd.synth import make_batch, pose_delta
+    from oracle import binding
+    from staticfusion_amd.synth import pose_delta
+
+    ora = binding.load()
+    n = min(n, len(pairs))
+    o = sf.Solver(ora, 240, 320, n, make_params(ora, workload))
+    for b in range(n):
+        o.set_current(b, *pairs[b]["new"])
+        o.set_prediction(b, *pairs[b]["old"])
+    o.process_frame(0)
+    rot_max = trans_max = 0.0
+    labels_equal = decisions_equal = True
+    for b in range(n):
+        r, t = pose_delta(o.T(b), T_first[b])
+        rot_max, trans_max = max(rot_max, r), max(trans_max, t)
+        if workload != "static":
+            labels_equal = labels_equal and all(np.array_equal(solver.labels(L, b), o.labels(L, b)) for L in range(solver.levels))
+            decisions_equal = decisions_equal and np.array_equal(solver.b_image(b) > 0.5, o.b_image(b) > 0.5)
+    out = {"rot_rad": rot_max, "trans_m": trans_max, "frames_checked": n}
+    if workload != "static":
+        out["cluster_labels_identical"] = bool(labels_equal)
+        out["static_dynamic_decision_identical"] = bool(decisions_equal)
+    return out
+
+
+def run_pairs_workload(hx, args, workload, batch, with_parity):
+    """configs[1] / configs[2]: one launch of the frame kernel per step over `batch` resident pairs. Returns the block."""
+    import staticfusion_amd as sf
+    from staticfusion_amd.synth import make_batch
 
     api = sf.load()
-    params = make_params(api, args.workload)
-    rows, cols, B = 240, 320, args.batch
-    sphere = args.workload == "sphere"
-    pairs = make_batch(args.distinct, base_seed=1234 + 100000 * rank, sphere=sphere, distinct=args.distinct)
-
-    solver = sf.Solver(api, rows, cols, B, params, device=dev_index)
+    params = make_params(api, workload)
+    rows, cols, B = 240, 320, batch
+    pairs = make_batch(args.distinct, base_seed=1234 + 100000 * hx.rank, sphere=(workload == "sphere"), distinct=args.distinct)
+    solver = sf.Solver(api, rows, cols, B, params, device=hx.dev_index, variant=args.variant)
     for b in range(B):
         pr = pairs[b % len(pairs)]
         solver.set_current(b, *pr["new"])
         solver.set_prediction(b, *pr["old"])
-
-    # ---- parity of the first frame against the CPU oracle (rank 0, the distinct pairs only)
-    parity = None
     solver.process_frame(0)
     solver.synchronize()
     T_first, _, _, _ = solver.batch_results()
-    if rank == 0 and not args.no_cpu_baseline:
-        from oracle import binding  # the checker: never on the measured path
+    parity = oracle_check(pairs, workload, T_first, solver) if (with_parity and hx.rank == 0) else None
 
-        ora = binding.load()
-        po = make_params(ora, args.workload)
-        rot_max = trans_max = 0.0
-        ncheck = min(4, len(pairs))
-        osolver = sf.Solver(ora, rows, cols, ncheck, po)
-        for b in range(ncheck):
-            osolver.set_current(b, *pairs[b]["new"])
-            osolver.set_prediction(b, *pairs[b]["old"])
-        osolver.process_frame(0)
-        for b in range(ncheck):
-            r, t = pose_delta(osolver.T(b), T_first[b])
-            rot_max, trans_max = max(rot_max, r), max(trans_max, t)
-        parity = {"rot_rad": rot_max, "trans_m": trans_max, "frames_checked": ncheck}
-
-    # ---- prime the 5-frame history so that the timed frames include computeResiduals
-    for im in range(1, 5):
+    for im in range(1, 5):  # prime the 5-frame history so that the timed frames include computeResiduals
         solver.process_frame(im)
     im = 5
     for _ in range(args.warmup):
@@ -167,133 +259,343 @@ def main():
         im += 1
     solver.synchronize()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        solver.synchronize()
-
-    # ---- the timed region: exactly K steps = K launches of sf_frame_kernel, back to back, bracketed by
-    #      barrier + device synchronisation.  HIP events recorded on the handle's stream around the
-    #      same K launches give the average kernel duration; the device-side counters give the
-    #      number of IRLS iterations those K steps executed (read outside the region).
+    # ---- the timed region: exactly K steps = K launches of sf_frame_kernel, back to back, bracketed by barrier + device
+    #      synchronisation. HIP events recorded on the handle's stream around the same K launches give the average kernel
+    #      duration; the device-side counters give the IRLS iterations those K steps executed (read outside the region).
     c0 = solver.counters()
-    barrier()
+    hx.barrier(solver)
     t0 = time.perf_counter()
     region_ms = solver.timed_process_frames(im, args.steps)
-    barrier()
+    hx.barrier(solver)
     elapsed = time.perf_counter() - t0
     im += args.steps
     c1 = solver.counters()
-    frames_timed = c1[0] - c0[0]
-    iters_total = c1[1] - c0[1]
-    pix_total = c1[3] - c0[3]
+    frames_timed, iters_total, pix_total = c1[0] - c0[0], c1[1] - c0[1], c1[3] - c0[3]
     assert frames_timed == B * args.steps, (frames_timed, B, args.steps)
-    kernel_ms = [region_ms / args.steps]
-    # per-stage unit counts of ONE launch (for the algorithmic byte count): one more, un-timed step
-    solver.process_frame(im)
-    im += 1
+    k_ms = region_ms / args.steps
+    solver.process_frame(im)  # per-stage unit counts of ONE launch (for the algorithmic byte count): one more, un-timed step
     stats_last = [solver.stats(b) for b in range(min(B, args.distinct))]
+    variant = solver.variant()
+    levels_n = [solver.level_shape(L)[0] * solver.level_shape(L)[1] for L in range(solver.levels)]
+    levels = int(solver.levels)
+    solver.close()
 
-    t_max, iters_all, frames_all = reduce_over_ranks(dist, reduce_device, elapsed, iters_total, B * args.steps)
+    t_max, iters_all, frames_all = reduce_over_ranks(hx.dist, hx.reduce_device, elapsed, iters_total, B * args.steps)
+    per_rank = gather_per_rank(hx.dist, hx.reduce_device, elapsed, iters_total, B * args.steps)
+    seg = bool(params.segmentation_enabled)
+    per_stream = algorithmic_bytes(stats_last, levels_n, levels_n[1], seg, True)
+    alg_bytes_launch = sum(per_stream.values()) * B / float(len(stats_last))
+    achieved = alg_bytes_launch / (k_ms * 1e-3) / 1e9
+    traffic, why = measured_traffic(workload, B, variant[0])
+    if traffic:
+        traffic["ratio_to_algorithmic"] = traffic["hbm_bytes_per_launch"] / alg_bytes_launch
+    return {
+        "workload": workload,
+        "value": iters_all / t_max,
+        "frames_per_s": frames_all / t_max,
+        "ms_per_step": 1e3 * t_max / args.steps,
+        "iterations_per_frame": iters_total / float(B * args.steps),
+        "pixel_iterations_per_s": pix_total / elapsed * hx.world,
+        "parity": parity,
+        "per_rank": [{"rank": r, "elapsed_s": e, "iterations_per_s": i / e, "frames_per_s": f / e} for r, (e, i, f) in enumerate(per_rank)],
+        "config": {
+            "workload": WORKLOAD_TEXT[workload],
+            "streams_per_gpu": B, "distinct_pairs": len(pairs), "rows": rows, "cols": cols, "ctf_levels": levels,
+            "max_iter_irls": int(params.max_iter_irls), "max_iter_per_level": int(params.max_iter_per_level),
+            "kernel_build": "%s (%d threads per workgroup, %d workgroup(s) per stream)" % variant,
+            "parallelism": "independent streams, %d GPU(s)" % hx.world,
+            "step": "sf_process_frame: pyramid(old)+runSolver(true)+residuals+segm image for every stream, one launch",
+        },
+        "roofline": {
+            "kernel": "sf_frame_kernel (%s build)" % variant[0],
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_note": why,
+            "algorithmic_bytes_per_launch": alg_bytes_launch,
+            "algorithmic_bytes_breakdown_per_stream": {k: v / float(len(stats_last)) for k, v in per_stream.items()},
+            "kernel_ms_avg": k_ms,
+        },
+        "pairs": pairs,
+    }
 
-    if rank == 0:
-        levels_n = [solver.level_shape(L)[0] * solver.level_shape(L)[1] for L in range(solver.levels)]
-        seg = bool(params.segmentation_enabled)
-        per_stream = algorithmic_bytes(stats_last, levels_n, levels_n[1], seg, True)
-        scale = B / float(len(stats_last))
-        alg_bytes_launch = sum(per_stream.values()) * scale
-        k_ms = float(np.mean(kernel_ms))
-        achieved = alg_bytes_launch / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_%s_b%d.json" % (args.workload, B))
-        if os.path.exists(tfile):
-            with open(tfile) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+
+def run_sequences_workload(hx, args):
+    """Independent sequences per rank, resident in HBM, frame-to-frame prediction (see the module docstring)."""
+    import multiprocessing as mp
+
+    import staticfusion_amd as sf
+    from staticfusion_amd.synth import make_sequence, pose_delta
+
+    torch = hx.torch
+    api = sf.load()
+    params = make_params(api, "sequences")
+    rows, cols, B = 240, 320, args.batch
+    D, F = args.seq_distinct, args.seq_frames
+    assert args.warmup + args.steps + 2 <= F, "sequence too short for the requested steps"
+    with mp.get_context("spawn").Pool(min(len(os.sched_getaffinity(0)), 16)) as pool:
+        seqs = [make_sequence(1000 + hx.rank * D + q, F, sphere=True, pool=pool) for q in range(D)]
+    n0 = rows * cols
+    col = lambda a: np.ascontiguousarray(np.asarray(a, np.float32).T).ravel()
+    pool_d = torch.from_numpy(np.stack([col(f[0]) for s in seqs for f in s["frames"]])).to("cuda:%d" % hx.dev_index)
+    pool_i = torch.from_numpy(np.stack([col(f[1]) for s in seqs for f in s["frames"]])).to("cuda:%d" % hx.dev_index)
+    assert pool_d.shape == (D * F, n0)
+    solver = sf.Solver(api, rows, cols, B, params, device=hx.dev_index, variant=args.variant)
+    # stream b plays sequence b % D starting at frame phase[b]; frames wrap to 1 (never to 0) so that a wrap is a large
+    # jump for one frame rather than a repeated bootstrap
+    phase = (np.arange(B) // D * 7) % (F - 1)
+    seq_of = np.arange(B) % D
+
+    def index_at(step):
+        return (seq_of * F + (phase + step) % F).astype(np.int32)
+
+    solver.advance_sequences_device(pool_d.data_ptr(), pool_i.data_ptr(), index_at(0))
+    solver.push_history(0)
+    step = 1
+    for _ in range(5 + args.warmup):  # bootstrap + the 5-frame ring + warm-up
+        solver.advance_sequences_device(pool_d.data_ptr(), pool_i.data_ptr(), index_at(step))
+        solver.process_frame(step)
+        step += 1
+    solver.synchronize()
+    c0 = solver.counters()
+    hx.barrier(solver)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.advance_sequences_device(pool_d.data_ptr(), pool_i.data_ptr(), index_at(step))
+        solver.process_frame(step)
+        step += 1
+    hx.barrier(solver)
+    elapsed = time.perf_counter() - t0
+    c1 = solver.counters()
+    frames_timed, iters_total = c1[0] - c0[0], c1[1] - c0[1]
+    assert frames_timed == B * args.steps
+    # kernel duration + unit counts from three more, un-timed launches
+    k_ms, stats_last = [], None
+    for _ in range(3):
+        solver.advance_sequences_device(pool_d.data_ptr(), pool_i.data_ptr(), index_at(step))
+        solver.process_frame(step)
+        solver.synchronize()
+        k_ms.append(solver.last_solver_kernel_ms())
+        step += 1
+    ncheck = min(B, 4 * D)
+    stats_last = [solver.stats(b) for b in range(ncheck)]
+    # tracking check against the ground truth of the generator for the last frame (streams 0 .. D-1 did not wrap)
+    T_all, n_irls, _, _ = solver.batch_results()
+    err = []
+    for b in range(min(B, D)):
+        k = int((phase[b] + step - 1) % F)
+        err.append(pose_delta(seqs[b % D]["T_gt"][k], T_all[b]))
+    variant = solver.variant()
+    levels_n = [solver.level_shape(L)[0] * solver.level_shape(L)[1] for L in range(solver.levels)]
+    levels = int(solver.levels)
+    solver.close()
+    del pool_d, pool_i
+
+    t_max, iters_all, frames_all = reduce_over_ranks(hx.dist, hx.reduce_device, elapsed, iters_total, B * args.steps)
+    per_rank = gather_per_rank(hx.dist, hx.reduce_device, elapsed, iters_total, B * args.steps)
+    per_stream = algorithmic_bytes(stats_last, levels_n, levels_n[1], True, True)
+    alg_bytes_launch = sum(per_stream.values()) * B / float(len(stats_last))
+    kms = float(np.mean(k_ms))
+    achieved = alg_bytes_launch / (kms * 1e-3) / 1e9
+    return {
+        "workload": "sequences",
+        "value": iters_all / t_max,
+        "frames_per_s": frames_all / t_max,
+        "ms_per_step": 1e3 * t_max / args.steps,
+        "iterations_per_frame": iters_total / float(B * args.steps),
+        "iterations_per_frame_spread": [int(n_irls.min()), int(n_irls.max())],
+        "parity": {"tracking_error_vs_ground_truth": {"rot_rad_max": max(e[0] for e in err), "trans_m_max": max(e[1] for e in err), "streams": len(err)}},
+        "per_rank": [{"rank": r, "elapsed_s": e, "iterations_per_s": i / e, "frames_per_s": f / e} for r, (e, i, f) in enumerate(per_rank)],
+        "config": {
+            "workload": WORKLOAD_TEXT["sequences"],
+            "streams_per_gpu": B, "distinct_sequences_per_rank": D, "frames_per_sequence": F, "sequence_seeds": [1000 + hx.rank * D, 1000 + hx.rank * D + D - 1],
+            "rows": rows, "cols": cols, "ctf_levels": levels,
+            "max_iter_irls": int(params.max_iter_irls), "max_iter_per_level": int(params.max_iter_per_level),
+            "kernel_build": "%s (%d threads per workgroup, %d workgroup(s) per stream)" % variant,
+            "parallelism": "independent sequences, %d GPU(s)" % hx.world,
+            "step": "sf_advance_sequences_device (prediction := current, current := next frame from the HBM pool) + sf_process_frame",
+        },
+        "roofline": {
+            "kernel": "sf_frame_kernel (%s build)" % variant[0],
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "traffic_note": "not measured for this workload",
+            "algorithmic_bytes_per_launch": alg_bytes_launch,
+            "algorithmic_bytes_breakdown_per_stream": {k: v / float(len(stats_last)) for k, v in per_stream.items()},
+            "kernel_ms_avg": kms,
+        },
+        "pairs": None,
+    }
+
+
+def main():
+    args = parse()
+    hx = Harness(args)
+    want_parity = not args.no_cpu_baseline
+    if args.workload == "sequences":
+        blk = run_sequences_workload(hx, args)
+    else:
+        blk = run_pairs_workload(hx, args, args.workload, args.batch, want_parity)
+    full = None
+    if args.workload == "static" and not args.no_full_solver:
+        full = run_pairs_workload(hx, args, "sphere", args.batch, want_parity)
+
+    if hx.rank == 0:
         out = {
             "metric": "solver iterations/s (IRLS loop bodies, reference FrontEnd.cpp:611-684) at QVGA",
-            "value": iters_all / t_max,
+            "value": blk["value"],
             "unit": "iterations/s",
-            "frames_per_s": frames_all / t_max,
+            "frames_per_s": blk["frames_per_s"],
             "n_gpus": args.gpus,
+            "world_size": hx.world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * t_max / args.steps,
+            "ms_per_step": blk["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {
-                "workload": ("BASELINE.json configs[1]: synthetic static RGB-D pairs, VGA->QVGA 320x240, 3-level pyramid, "
-                             "segmentation disabled (pure 6-DoF Cauchy IRLS)") if not sphere else
-                            ("BASELINE.json configs[2]: synthetic QVGA pairs with a moving sphere, full solver, "
-                             "K-means(24) + b-field, driver parameters, 5 levels"),
-                "streams_per_gpu": B,
-                "distinct_pairs": len(pairs),
-                "rows": rows, "cols": cols, "ctf_levels": int(solver.levels),
-                "max_iter_irls": int(params.max_iter_irls), "max_iter_per_level": int(params.max_iter_per_level),
-                "parallelism": "independent streams, %d GPU(s), one workgroup per stream" % args.gpus,
-                "step": "sf_process_frame: pyramid(old)+runSolver(true)+residuals+segm image for every stream, one launch",
-            },
-            "iterations_per_frame": iters_total / float(B * args.steps),
-            "pixel_iterations_per_s": pix_total / elapsed * args.gpus,
-            "pose_delta_vs_cpu": parity,
-            "roofline": {
-                "kernel": "sf_frame_kernel",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes_launch,
-                "algorithmic_bytes_breakdown_per_stream": {k: v / float(len(stats_last)) for k, v in per_stream.items()},
-                "kernel_ms_avg": k_ms,
-            },
+            "config": blk["config"],
+            "iterations_per_frame": blk["iterations_per_frame"],
+            "pixel_iterations_per_s": blk.get("pixel_iterations_per_s"),
+            "pose_delta_vs_cpu": blk["parity"],
+            "per_rank": blk["per_rank"],
+            "roofline": blk["roofline"],
+            "build": {"head": git_head(), "src_sha": source_sha()},
         }
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args, pairs)
+        if "iterations_per_frame_spread" in blk:
+            out["iterations_per_frame_spread"] = blk["iterations_per_frame_spread"]
+        if full is not None:
+            out["full_solver"] = {
+                "workload": full["config"]["workload"],
+                "value": full["value"], "unit": "iterations/s", "frames_per_s": full["frames_per_s"], "ms_per_step": full["ms_per_step"],
+                "steps": args.steps, "warmup": args.warmup,
+                "iterations_per_frame": full["iterations_per_frame"], "pose_delta_vs_cpu": full["parity"],
+                "config": full["config"], "roofline": full["roofline"], "per_rank": full["per_rank"],
+            }
+        if not args.no_cpu_baseline and hx.world == 1 and args.workload != "sequences":  # rank 0 at N = 1 only
+            lib = native_oracle()
+            out["cpu_baseline"] = cpu_baseline(args.workload, blk["pairs"], args.cpu_seconds, lib)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.workload, min(args.cpu_seconds, 8.0), lib)
+            if full is not None:
+                out["full_solver"]["cpu_baseline"] = cpu_baseline("sphere", full["pairs"], min(args.cpu_seconds, 8.0), lib)
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    hx.close()
 
 
-def cpu_baseline(args, pairs):
-    """The CPU restatement (oracle/, kind 'port': the reference itself cannot be built here) on one
-    host core, on a bounded sample of the same workload."""
-    import staticfusion_amd as sf
+# ---------------------------------------------------------------------------------------------------------------------
+#  CPU comparator: the oracle (kind "port": the reference itself cannot be built here), timed on the GPU box's host
+# ---------------------------------------------------------------------------------------------------------------------
+def native_oracle():
+    """The reference is built -O3 -msse2 -msse3 -mtune=native (reference CMakeLists.txt:100-105). The committed oracle
+    library is tuned for the build container; for the timing leg the same sources are compiled once more ON THIS HOST with
+    -mtune=native (a few seconds, /tmp). Falls back to the shipped library if no compiler is present."""
     from oracle import binding
 
-    ora = binding.load()
-    p = make_params(ora, args.workload)
-    n = min(4, len(pairs))
-    s = sf.Solver(ora, 240, 320, n, p)
-    for b in range(n):
-        s.set_current(b, *pairs[b]["new"])
-        s.set_prediction(b, *pairs[b]["old"])
+    out = "/tmp/sf_oracle_native_%d/liboracle.so" % os.getuid()
+    try:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        src = os.path.join(ROOT, "oracle")
+        files = [os.path.join(src, f) for f in sorted(os.listdir(src)) if f.endswith(".cpp")]
+        subprocess.check_call(["g++", "-O3", "-msse2", "-msse3", "-mtune=native", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
+                               "-o", out] + files, stderr=subprocess.DEVNULL, timeout=180)
+        return out
+    except Exception:
+        return binding.LIB
+
+
+def _cpu_leg(job):
+    """One pinned process: `seconds` of the workload on one stream. Returns (iterations, frames, elapsed)."""
+    workload, seconds, seed, lib, cpu = job
+    if cpu is not None:
+        os.sched_setaffinity(0, {cpu})
+    import staticfusion_amd as sf
+    from staticfusion_amd.synth import make_batch
+
+    ora = sf.Api(lib, "sfo_")
+    pairs = make_batch(1, base_seed=1234 + seed, sphere=(workload == "sphere"), distinct=1)
+    s = sf.Solver(ora, 240, 320, 1, make_params(ora, workload))
+    s.set_current(0, *pairs[0]["new"])
+    s.set_prediction(0, *pairs[0]["old"])
     for im in range(5):
         s.process_frame(im)
     im, iters, frames = 5, 0, 0
     t0 = time.perf_counter()
-    while True:
+    while time.perf_counter() - t0 < seconds:
         s.process_frame(im)
         im += 1
-        _, n_irls, _, _ = s.batch_results()
-        iters += int(n_irls.sum())
-        frames += n
-        dt = time.perf_counter() - t0
-        if dt > args.cpu_seconds:
-            break
+        frames += 1
+        iters += s.stats(0).n_irls
+    return iters, frames, time.perf_counter() - t0
+
+
+def cpu_baseline(workload, pairs, seconds, lib):
+    """One host core (pinned), a bounded sample of the same workload."""
+    import staticfusion_amd as sf
+
+    allowed = sorted(os.sched_getaffinity(0))
+    os.sched_setaffinity(0, {allowed[-1]})
+    try:
+        ora = sf.Api(lib, "sfo_")
+        n = min(4, len(pairs))
+        s = sf.Solver(ora, 240, 320, n, make_params(ora, workload))
+        for b in range(n):
+            s.set_current(b, *pairs[b]["new"])
+            s.set_prediction(b, *pairs[b]["old"])
+        for im in range(5):
+            s.process_frame(im)
+        im, iters, frames = 5, 0, 0
+        t0 = time.perf_counter()
+        while True:
+            s.process_frame(im)
+            im += 1
+            _, n_irls, _, _ = s.batch_results()
+            iters += int(n_irls.sum())
+            frames += n
+            dt = time.perf_counter() - t0
+            if dt > seconds:
+                break
+    finally:
+        os.sched_setaffinity(0, set(allowed))
     return {
-        "value": iters / dt,
-        "unit": "iterations/s",
-        "frames_per_s": frames / dt,
-        "cores": 1,
-        "kind": "port",
-        "sample": "%d frames of the same workload (%d distinct pairs, repeated), single thread, %.1f s" % (frames, n, dt),
-        "host_cpus": os.cpu_count(),
+        "value": iters / dt, "unit": "iterations/s", "frames_per_s": frames / dt, "cores": 1, "kind": "port",
+        "sample": "%d frames of the same workload (%d distinct pairs, repeated), single thread pinned to CPU %d, %.1f s" % (frames, n, allowed[-1], dt),
+        "build": "g++ -O3 -msse2 -msse3 -mtune=native -ffp-contract=off on this host" if lib.startswith("/tmp/") else "shipped liboracle.so (no compiler on this host)",
+        "host_cpus": os.cpu_count(), "usable_cpus": len(allowed),
+    }
+
+
+def cgroup_cpu_limit():
+    """CPUs the container may use at once (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        return None if quota == "max" else float(quota) / float(period)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else float(q) / p
+    except Exception:
+        return None
+
+
+def cpu_baseline_all_cores(workload, seconds, lib):
+    """Embarrassingly parallel: one independent stream per CPU this container may use, one process each.
+    The GPU boxes expose all host threads in the affinity mask but cap the container's CPU time (cpu.max): more
+    processes than the cap only contend, so the leg runs min(affinity, cap) processes, pinned when there is no cap."""
+    import multiprocessing as mp
+
+    allowed = sorted(os.sched_getaffinity(0))
+    cap = cgroup_cpu_limit()
+    n = len(allowed) if cap is None else max(1, min(len(allowed), int(cap)))
+    pin = cap is None  # under a quota the scheduler places the processes; pinning 16 of 256 threads would pick SMT siblings
+    with mp.get_context("spawn").Pool(n) as pool:
+        res = pool.map(_cpu_leg, [(workload, seconds, k % 8, lib, allowed[k] if pin else None) for k in range(n)])
+    return {
+        "value": sum(r[0] / r[2] for r in res), "unit": "iterations/s", "frames_per_s": sum(r[1] / r[2] for r in res),
+        "cores": n, "kind": "port",
+        "sample": "one independent stream per process, %d processes (%s), %.1f s each" % (n, "pinned" if pin else "container CPU quota %.1f" % cap, seconds),
+        "host_cpus": os.cpu_count(), "usable_cpus": len(allowed), "cgroup_cpu_limit": cap,
     }
 
 

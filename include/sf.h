@@ -170,6 +170,14 @@ int SF_FN(set_prediction)(sf_handle *h, int stream, const float *depth, const fl
  * (what an MI355X-resident producer such as a HIP renderer / loader hands over). */
 int SF_FN(set_current_device)(sf_handle *h, const void *d_depth, const void *d_intensity);
 int SF_FN(set_prediction_device)(sf_handle *h, const void *d_depth, const void *d_intensity);
+/* Frame-to-frame replay of many sequences that are resident in HBM (the dataset drivers' loop without the map:
+ * prediction := the previous frame, StaticFusion-imagesequenceassoc.cpp:105-108 applied every frame): for every stream b
+ *   depthPrediction / intensityPrediction := depthCurrent / intensityCurrent
+ *   depthCurrent / intensityCurrent       := frame frame_index[b] of the pools
+ * in ONE pass over the images. pool_depth / pool_intensity are DEVICE buffers of frames laid out [frame][cols][rows]
+ * (column-major float32, rows*cols each); frame_index is a HOST array of `batch` frame numbers, a negative entry leaves
+ * that stream untouched. Asynchronous on the handle's stream (the index array is copied before the call returns). */
+int SF_FN(advance_sequences_device)(sf_handle *h, const void *pool_depth, const void *pool_intensity, const int32_t *frame_index);
 /* Overlapped upload for PCIe-fed deployments: sf_upload_current_async starts copying depthCurrent / intensityCurrent
  * of the WHOLE batch (host buffers laid out [batch][cols][rows]; page-locked memory from sf_alloc_pinned makes the
  * copy truly asynchronous) into a staging block on a second HIP stream and returns at once -- the solver launches

@@ -197,6 +197,19 @@ int sfo_set_prediction_device(sf_handle *h, const void *d, const void *i) {
     for (int b = 0; b < h->batch; b++) sfo_set_prediction(h, b, (const float *)d + b * n, (const float *)i + b * n);
     return SF_OK;
 }
+int sfo_advance_sequences_device(sf_handle *h, const void *pool_depth, const void *pool_intensity, const int32_t *frame_index) {
+    // "device" pools of the CPU oracle are host buffers [frame][cols][rows]
+    if (!h || !pool_depth || !pool_intensity || !frame_index) return fail(SF_ERR_ARG, "null");
+    const size_t n = size_t(h->rows) * h->cols;
+    for (int b = 0; b < h->batch; b++) {
+        if (frame_index[b] < 0) continue;
+        auto &s = *h->s[b];
+        s.depthPrediction = s.depthCurrent;
+        s.intensityPrediction = s.intensityCurrent;
+        if (int e = sfo_set_current(h, b, (const float *)pool_depth + size_t(frame_index[b]) * n, (const float *)pool_intensity + size_t(frame_index[b]) * n)) return e;
+    }
+    return SF_OK;
+}
 // the CPU oracle has no second stream: the "asynchronous" upload copies at commit time from the caller's buffers
 static const float *g_up_d = nullptr, *g_up_i = nullptr;
 int sfo_upload_current_async(sf_handle *h, const float *d, const float *i) {

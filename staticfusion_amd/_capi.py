@@ -108,6 +108,7 @@ SIGNATURES = {
     "set_prediction": (C.c_int, [_H, C.c_int, _fp, _fp]),
     "set_current_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "set_prediction_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    "advance_sequences_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, _ip]),
     "upload_current_async": (C.c_int, [_H, _fp, _fp]),
     "commit_upload": (C.c_int, [_H]),
     "alloc_pinned": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -335,6 +336,12 @@ class Solver:
         i = np.zeros((self.cols, self.rows), dtype=np.float32)
         self.api.check(self.api.get_prediction(self.h, stream, d.ctypes.data_as(_fp), i.ctypes.data_as(_fp)))
         return d.T.copy(), i.T.copy()
+
+    def advance_sequences_device(self, pool_depth_ptr, pool_intensity_ptr, frame_index):
+        """prediction := current; current := pool frame frame_index[b] (device pools [frame][cols][rows]; host index array)"""
+        idx = np.ascontiguousarray(frame_index, dtype=np.int32)
+        assert idx.shape == (self.batch_size,)
+        self.api.check(self.api.advance_sequences_device(self.h, C.c_void_p(pool_depth_ptr), C.c_void_p(pool_intensity_ptr), idx.ctypes.data_as(_ip)))
 
     def current_to_prediction(self):
         self.api.check(self.api.current_to_prediction(self.h))

@@ -43,6 +43,25 @@ static const FrameVariant VARIANTS[2] = {
     {SF_VARIANT_LATENCY, "latency", sf_variant_geometry_nt1024, sf_launch_frame_nt1024, sf_launch_irls_pass_nt1024, sf_launch_debug_rows_nt1024},
 };
 
+// prediction := current; current := pool[frame_index[stream]] for every stream, 16 bytes per lane and plane
+// (sf_advance_sequences_device). grid = (slices, batch).
+__global__ __launch_bounds__(256) void sf_advance_kernel(float *cur_d, float *cur_i, float *pred_d, float *pred_i, const float *pool_d,
+                                                         const float *pool_i, const int *frame_index, int n0, int n_tot) {
+    const int b = blockIdx.y;
+    const int f = frame_index[b];
+    if (f < 0) return;
+    typedef float __attribute__((ext_vector_type(4))) f4;
+    const size_t so = (size_t)b * n_tot, po = (size_t)f * n0;
+    for (int q = (blockIdx.x * 256 + threadIdx.x) * 4; q < n0; q += gridDim.x * 256 * 4) {
+        const f4 cd = *(const f4 *)(cur_d + so + q), ci = *(const f4 *)(cur_i + so + q);
+        const f4 nd = *(const f4 *)(pool_d + po + q), ni = *(const f4 *)(pool_i + po + q);
+        *(f4 *)(pred_d + so + q) = cd;
+        *(f4 *)(pred_i + so + q) = ci;
+        *(f4 *)(cur_d + so + q) = nd;
+        *(f4 *)(cur_i + so + q) = ni;
+    }
+}
+
 // =============================================================================================
 //  host side
 // =============================================================================================
@@ -87,6 +106,13 @@ struct sf_handle {
     hipEvent_t copy_done = nullptr, compute_done = nullptr;
     float *up_depth = nullptr, *up_inten = nullptr;
     bool upload_pending = false;
+    // sf_advance_sequences_device: per-stream frame numbers, a ring of device + pinned host slots so that calls queue up
+    // behind running frame kernels without a host synchronisation (a slot is reused only after its copy has executed)
+    static const int SEQ_SLOTS = 8;
+    int *seq_index = nullptr;
+    int *seq_index_host = nullptr;
+    hipEvent_t seq_done[SEQ_SLOTS] = {};
+    unsigned seq_calls = 0;
 };
 
 static thread_local std::string g_err;
@@ -200,6 +226,9 @@ void sf_destroy(sf_handle *h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->evk0) (void)hipEventDestroy(h->evk0);
     if (h->evk1) (void)hipEventDestroy(h->evk1);
+    if (h->seq_index_host) (void)hipHostFree(h->seq_index_host);
+    for (auto &e : h->seq_done)
+        if (e) (void)hipEventDestroy(e);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->copy_done) (void)hipEventDestroy(h->copy_done);
     if (h->compute_done) (void)hipEventDestroy(h->compute_done);
@@ -431,6 +460,30 @@ int sf_set_current_device(sf_handle *h, const void *d, const void *i) {
 int sf_set_prediction_device(sf_handle *h, const void *d, const void *i) {
     return h ? copy_batch_device(h, h->k.pyr_pred, d, i) : fail(SF_ERR_ARG, "null");
 }
+int sf_advance_sequences_device(sf_handle *h, const void *pool_depth, const void *pool_intensity, const int32_t *frame_index) {
+    if (!h || !pool_depth || !pool_intensity || !frame_index) return fail(SF_ERR_ARG, "null");
+    if (h->k.n0 % 4 || h->k.n_tot % 4) return fail(SF_ERR_ARG, "level sizes must be multiples of 4 pixels");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t B = (size_t)h->k.batch;
+    if (!h->seq_index) {
+        if (int e = dev_alloc(h, &h->seq_index, B * sf_handle::SEQ_SLOTS)) return e;
+        HIP_TRY(hipHostMalloc((void **)&h->seq_index_host, sizeof(int) * B * sf_handle::SEQ_SLOTS, hipHostMallocDefault));
+        for (auto &e : h->seq_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const unsigned slot = h->seq_calls % sf_handle::SEQ_SLOTS;
+    if (h->seq_calls >= (unsigned)sf_handle::SEQ_SLOTS) HIP_TRY(hipEventSynchronize(h->seq_done[slot]));  // eight calls ago
+    h->seq_calls++;
+    int *host = h->seq_index_host + slot * B, *dev = h->seq_index + slot * B;
+    std::memcpy(host, frame_index, sizeof(int) * B);
+    HIP_TRY(hipMemcpyAsync(dev, host, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+    const dim3 grid((unsigned)std::min(16, (h->k.n0 / 4 + 255) / 256), (unsigned)h->k.batch);
+    hipLaunchKernelGGL(sf_advance_kernel, grid, dim3(256), 0, h->stream, h->k.pyr_new[0], h->k.pyr_new[1], h->k.pyr_pred[0], h->k.pyr_pred[1],
+                       (const float *)pool_depth, (const float *)pool_intensity, (const int *)dev, h->k.n0, h->k.n_tot);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->seq_done[slot], h->stream));
+    return SF_OK;
+}
+
 // ---- overlapped upload: the next batch of frames crosses PCIe on a second HIP stream while the solver runs ----
 int sf_upload_current_async(sf_handle *h, const float *depth_batch, const float *intensity_batch) {
     if (!h || !depth_batch || !intensity_batch) return fail(SF_ERR_ARG, "null");

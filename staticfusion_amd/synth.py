@@ -185,3 +185,42 @@ def make_batch(n, base_seed=1234, sphere=False, distinct=None, out_rows=240, out
         xi = np.array(DEFAULT_XI) * scale * np.array([g.uniform(0.6, 1.4) * (1 if g.uniform() < 0.5 else -1) for _ in range(6)])
         pairs.append(make_pair(seed=base_seed + j, xi=xi, sphere=sphere, out_rows=out_rows, out_cols=out_cols))
     return [pairs[i % distinct] for i in range(n)]
+
+
+def sequence_trajectory(seed, frames, scale=1.0):
+    """Camera poses (camera -> world, 4x4 float64) of a smooth random walk: the per-frame twist is a first-order
+    autoregressive process around DEFAULT_XI-sized steps (about 1 cm and 0.3 degrees per frame), so consecutive frames
+    overlap like a hand-held camera's, and no two sequences (seeds) move alike. Returns (poses, sphere offsets)."""
+    g = LCG64(0x5EED0000 + seed)
+    sigma = np.array(DEFAULT_XI) * scale * 1.2
+    xi = np.array([g.uniform(-1, 1) for _ in range(6)]) * sigma
+    T = np.eye(4)
+    poses, offsets = [], []
+    ph = [g.uniform(0, 2 * np.pi) for _ in range(3)]
+    for k in range(frames):
+        poses.append(T.copy())
+        # the sphere swings through the scene (a few cm per frame at most)
+        offsets.append((0.30 * np.sin(0.07 * k + ph[0]), 0.10 * np.sin(0.05 * k + ph[1]), 0.15 * np.sin(0.04 * k + ph[2])))
+        noise = np.array([g.uniform(-1, 1) for _ in range(6)]) * sigma
+        xi = 0.9 * xi + 0.45 * noise
+        # keep the camera in the room: a weak pull of the position back to the origin
+        pull = -0.02 * np.concatenate([T[:3, :3].T @ T[:3, 3], np.zeros(3)])
+        T = T @ se3_exp(xi + pull)
+    return poses, offsets
+
+
+def _render_sequence_frame(args):
+    seed, pose, offset, sphere, W, H = args
+    scene = Scene(seed=seed, sphere=sphere, sphere_seed=seed + 4444)
+    return quantise_and_decimate(*scene.render(pose, W, H, sphere_offset=offset if sphere else (0, 0, 0)))
+
+
+def make_sequence(seed, frames, sphere=True, out_rows=240, out_cols=320, scale=1.0, pool=None):
+    """One synthetic RGB-D sequence: `frames` (depth, intensity) QVGA images rendered at 2x the output size along
+    sequence_trajectory(seed). T_gt[k] = pose_{k-1}^-1 pose_k is what the solver should report for frame k against frame
+    k - 1 as prediction. `pool`: an optional multiprocessing pool for the ray casting (0.17 s per VGA frame and core)."""
+    poses, offsets = sequence_trajectory(seed, frames, scale)
+    jobs = [(seed, poses[k], offsets[k], sphere, 2 * out_cols, 2 * out_rows) for k in range(frames)]
+    imgs = pool.map(_render_sequence_frame, jobs, chunksize=4) if pool is not None else [_render_sequence_frame(j) for j in jobs]
+    T_gt = [np.eye(4)] + [np.linalg.inv(poses[k - 1]) @ poses[k] for k in range(1, frames)]
+    return {"frames": imgs, "poses": poses, "T_gt": T_gt}

@@ -203,3 +203,18 @@ def test_bench_two_rank_flow_on_one_gpu(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["frames_per_s"] * d["ms_per_step"] * 1e-3 - 2 * 128) < 1e-6 * 256  # whole-job frames per step = both ranks' batches
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    assert d["world_size"] == 2 and [r["rank"] for r in d["per_rank"]] == [0, 1] and all(r["frames_per_s"] > 0 for r in d["per_rank"])
+    fs = d["full_solver"]  # BASELINE configs[2] timed in the same run
+    assert fs["value"] > 0 and fs["roofline"]["frac"] > 0 and fs["pose_delta_vs_cpu"]["cluster_labels_identical"]
+    assert fs["pose_delta_vs_cpu"]["rot_rad"] < 1e-4 and d["pose_delta_vs_cpu"]["rot_rad"] < 1e-4
+    # the sequences workload through the same two-rank flow
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                   "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "sequences", "--batch", "32",
+                                   "--steps", "3", "--warmup", "1", "--seq-distinct", "2", "--seq-frames", "16"], env=env, cwd=ROOT,
+                                  stderr=subprocess.STDOUT, timeout=900).decode()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    d = json.loads(lines[0])
+    assert d["world_size"] == 2 and d["config"]["distinct_sequences_per_rank"] == 2 and d["value"] > 0
+    assert abs(d["frames_per_s"] * d["ms_per_step"] * 1e-3 - 2 * 32) < 1e-6 * 64
+    assert d["pose_delta_vs_cpu"]["tracking_error_vs_ground_truth"]["trans_m_max"] < 0.02

@@ -60,7 +60,9 @@ enum {
 /* status bits in sf_frame_stats.status */
 enum {
     SF_STATUS_EIG_SKIPPED = 1, /* non-finite covariance: pose update skipped (reference FrontEnd.cpp:720-724) */
-    SF_STATUS_EMPTY_LEVEL = 2  /* a level had no valid pixel (reference divides by zero there, FrontEnd.cpp:505-509) */
+    SF_STATUS_EMPTY_LEVEL = 2, /* a level had no valid pixel (reference divides by zero there, FrontEnd.cpp:505-509) */
+    SF_STATUS_SYNC_TIMEOUT = 4 /* SF_VARIANT_CLUSTER: a workgroup waited too long for the others of its stream (they were not all
+                                  resident: something else occupied the GPU); the results of this frame are not valid */
 };
 
 /* The reference's parameter set: public members written by the drivers

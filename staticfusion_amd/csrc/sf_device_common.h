@@ -77,6 +77,8 @@ struct StreamState {
     float kb;
     int32_t last_level;             // image level of the last executed outer iteration
     int32_t last_first;             // 1 if that iteration ran on Warped := Pred (the first of a solve)
+    uint32_t sync_epoch;            // cluster build: tag of the last rendezvous of this stream's workgroups (sf_cluster.h)
+    int32_t last_slot;              // record slot of the last executed outer iteration (cluster build: may be a private one)
     float inv_max_c, inv_max_d;     // 1/max of the raw pre-weights of that iteration
     long long cum_frames, cum_irls, cum_outer, cum_pixel_iters;  // totals since sf_create
     long long prof[SF_PROF_SLOTS];  // cumulative 100 MHz ticks per stage (lane 0 of the workgroup)
@@ -110,6 +112,11 @@ struct KArgs {
     StreamState *state;      // [batch]
     sf_frame_stats *stats;   // [batch]
     int *queue;              // work-queue counter (zeroed before every launch)
+    // cluster build (sf_cluster.h): workgroups per stream; granules [batch][2][cluster_g][SF_SYNC_WORDS]. The record /
+    // accumulator arrays then hold batch * (1 + cluster_g) slots of n0 pixels: slot b is stream b's shared one, slot
+    // batch + b * cluster_g + r the private one of its workgroup r (coarse levels run redundantly per workgroup)
+    int cluster_g;
+    unsigned long long *sync;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -339,10 +346,10 @@ struct SplatWin {
 // Src::load(v, u, idx, z, xr, yr, iw) -> bool valid
 template <class Src>
 __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int cols_i, const Src &src, gptr<long long> acc_d,
-                                            gptr<long long> acc_i, LDS SplatWin &win, int tid) {
+                                            gptr<long long> acc_i, LDS SplatWin &win, int tid, int tile_first = 0, int tile_step = 1) {
     const int lane = tid & 63;
     const int tiles_v = (rows_i + SPLAT_TV - 1) / SPLAT_TV, tiles_u = (cols_i + SPLAT_TU - 1) / SPLAT_TU;
-    for (int tile = 0; tile < tiles_v * tiles_u; tile++) {
+    for (int tile = tile_first; tile < tiles_v * tiles_u; tile += tile_step) {  // a cluster's workgroups take every G-th tile
         const int tv0 = (tile % tiles_v) * SPLAT_TV, tu0 = (tile / tiles_v) * SPLAT_TU;
         // ---- phase 1: clear the window, load + project this lane's source pixels, window origin
         for (int q = tid; q < WIN_CELLS; q += SF_NT) {

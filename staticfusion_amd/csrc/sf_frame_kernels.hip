@@ -4,6 +4,7 @@
 // The host side (sf_hip.hip) reaches the kernels through the two extern "C" launchers at the end.
 #include <hip/hip_runtime.h>
 
+#include "sf_cluster.h"
 #include "sf_device_common.h"
 #include "sf_kmeans.h"
 #include "sf_pyramid.h"
@@ -30,8 +31,52 @@ union FrameShared {
     ResShared rs;
 };
 
+// the stage sequence of one stream; cs says whether this workgroup works alone or as one of a cluster (sf_cluster.h)
+__device__ __forceinline__ void run_stages(const KArgs &a, int b, int stage_mask, int im_count, LDS FrameShared &sh, LDS ClusterShared &cs, int tid) {
+    long long t0 = 0, t1 = 0;
+    long long *prof = a.state[b].prof;
+    const bool writer = cl_writer(cs);
+#ifdef SF_NO_STAGE_TIMED
+#define STAGE_TIMED(slot, call) call
+#else
+#define STAGE_TIMED(slot, call)               \
+    do {                                      \
+        call;                                 \
+        if (tid == 0 && writer) {             \
+            t1 = wall_clock64();              \
+            prof[slot] += t1 - t0;            \
+            t0 = t1;                          \
+        }                                     \
+    } while (0)
+#endif
+    const long long t_begin = wall_clock64();
+    t0 = t_begin;
+    if (stage_mask & ST_PYR_OLD) STAGE_TIMED(PF_PYR_OLD, stage_pyramid(a, b, true, tid, cs));
+    if (stage_mask & ST_PYR_NEW) STAGE_TIMED(PF_PYR_NEW, stage_pyramid(a, b, false, tid, cs));
+    if (stage_mask & ST_KMEANS) {
+        // ordered float sums: one workgroup clusters, the others of a cluster wait for its labels
+        if (writer) STAGE_TIMED(PF_KMEANS, stage_kmeans(a, b, *(LDS KmShared *)&sh.km, tid));
+        cluster_barrier(cs, tid);
+    }
+    if (stage_mask & ST_SOLVE) {
+        stage_solve(a, b, *(LDS SolveShared *)&sh.sv, cs, tid);
+        t0 = wall_clock64();
+    }
+    if (stage_mask & ST_RESIDUALS) STAGE_TIMED(PF_RESIDUALS, stage_residuals(a, b, im_count, *(LDS ResShared *)&sh.rs, cs, tid));
+    __syncthreads();
+    if (stage_mask & ST_SEGM_IMAGE) stage_segm_image(a, b, tid, cs);
+    if (stage_mask & ST_PUSH_HISTORY) stage_push_history(a, b, im_count, tid, cs);
+    if (tid == 0 && writer) {
+        t1 = wall_clock64();
+        prof[PF_SEGM_HIST] += t1 - t0;
+        prof[PF_TOTAL] += t1 - t_begin;
+    }
+}
+
+#ifndef SF_CLUSTER
 __global__ __launch_bounds__(SF_NT, 4) void sf_frame_kernel(const KArgs *__restrict__ ka, int stage_mask, int im_count) {
     __shared__ FrameShared sh;
+    __shared__ ClusterShared cs;
     __shared__ int s_next;
     const KArgs &a = *ka;
     const int tid = threadIdx.x;
@@ -41,47 +86,43 @@ __global__ __launch_bounds__(SF_NT, 4) void sf_frame_kernel(const KArgs *__restr
         const int b = __builtin_amdgcn_readfirstlane(s_next);  // provably wave-uniform: scalar branches around the barriers
         __syncthreads();
         if (b >= a.batch) break;
-        long long t0 = 0, t1 = 0;
-        long long *prof = a.state[b].prof;
-#ifdef SF_NO_STAGE_TIMED
-#define STAGE_TIMED(slot, call) call
-#else
-#define STAGE_TIMED(slot, call)               \
-    do {                                      \
-        call;                                 \
-        if (tid == 0) {                       \
-            t1 = wall_clock64();              \
-            prof[slot] += t1 - t0;            \
-            t0 = t1;                          \
-        }                                     \
-    } while (0)
-#endif
-        const long long t_begin = wall_clock64();
-        t0 = t_begin;
-        if (stage_mask & ST_PYR_OLD) STAGE_TIMED(PF_PYR_OLD, stage_pyramid(a, b, true, tid));
-        if (stage_mask & ST_PYR_NEW) STAGE_TIMED(PF_PYR_NEW, stage_pyramid(a, b, false, tid));
-        if (stage_mask & ST_KMEANS) STAGE_TIMED(PF_KMEANS, stage_kmeans(a, b, *(LDS KmShared *)&sh.km, tid));
-        if (stage_mask & ST_SOLVE) {
-            stage_solve(a, b, *(LDS SolveShared *)&sh.sv, tid);
-            t0 = wall_clock64();
-        }
-        if (stage_mask & ST_RESIDUALS) STAGE_TIMED(PF_RESIDUALS, stage_residuals(a, b, im_count, *(LDS ResShared *)&sh.rs, tid));
-        __syncthreads();
-        if (stage_mask & ST_SEGM_IMAGE) stage_segm_image(a, b, tid);
-        if (stage_mask & ST_PUSH_HISTORY) stage_push_history(a, b, im_count, tid);
-        if (tid == 0) {
-            t1 = wall_clock64();
-            prof[PF_SEGM_HIST] += t1 - t0;
-            prof[PF_TOTAL] += t1 - t_begin;
-        }
+        cluster_init(*(LDS ClusterShared *)&cs, tid, 1, 0, b, b, nullptr, 0);  // this workgroup alone, on the stream's own slot
+        run_stages(a, b, stage_mask, im_count, *(LDS FrameShared *)&sh, *(LDS ClusterShared *)&cs, tid);
         // NOTE: the loop body must END with a barrier. With a lane-0-only block here the compiler
         // fuses it with the lane-0-only queue pop at the loop top into an outer loop, and the other
         // lanes of wave 0 then spin on the barrier of the inner loop forever (observed hang).
         __syncthreads();
     }
 }
+#else
+// The cluster build: G workgroups per stream, fixed assignment (no queue: all workgroups of a stream must run at the same
+// time, so the grid never exceeds the CUs). Workgroup j of XCD x -- blocks are dealt to the XCDs round robin, an
+// observation the mapping only uses for speed -- serves stream (j / G) * 8 + x as rank j % G: the workgroups of a stream
+// share an L2.
+__global__ __launch_bounds__(SF_NT, 4) void sf_frame_kernel(const KArgs *__restrict__ ka, int stage_mask, int im_count) {
+    __shared__ FrameShared sh;
+    __shared__ ClusterShared cs;
+    const KArgs &a = *ka;
+    const int tid = threadIdx.x;
+    const int G = a.cluster_g;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int b = (j / G) * 8 + xcd, rank = j % G;
+    if (b >= a.batch) return;
+    StreamState &st = a.state[b];
+    cluster_init(*(LDS ClusterShared *)&cs, tid, G, rank, b, a.batch + b * G + rank, (gu64 *)a.sync + (size_t)b * 2 * G * SF_SYNC_WORDS,
+                 st.sync_epoch);
+    run_stages(a, b, stage_mask, im_count, *(LDS FrameShared *)&sh, *(LDS ClusterShared *)&cs, tid);
+    // the epoch carries over to the next launch (every workgroup counted the same rendezvous)
+    __syncthreads();
+    if (tid == 0 && rank == 0) {
+        st.sync_epoch = cs.epoch;
+        if (cs.failed) a.stats[b].status |= SF_STATUS_SYNC_TIMEOUT;
+    }
+}
+#endif
 
 // the IRLS passes alone (measurement support; never part of a solve)
+#ifndef SF_CLUSTER
 __global__ __launch_bounds__(SF_NT, 4) void sf_irls_pass_kernel(const KArgs *__restrict__ ka, int which, int variant, int reps, int slices) {
     __shared__ FrameShared sh;
     __shared__ int s_next;
@@ -115,6 +156,8 @@ __global__ __launch_bounds__(SF_NT, 4) void sf_irls_pass_kernel(const KArgs *__r
 }
 
 
+#endif  // !SF_CLUSTER
+
 // test support: the Jacobian rows of one stream's last outer iteration (sf_get_jacobian_rows); never part of a solve
 __global__ __launch_bounds__(SF_NT) void sf_debug_rows_kernel(const KArgs *__restrict__ ka, int b, float *out) {
     debug_rows(*ka, b, out, blockIdx.x * SF_NT + threadIdx.x, gridDim.x * SF_NT);
@@ -127,7 +170,9 @@ extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_launch_fr
     hipLaunchKernelGGL(sf_frame_kernel, dim3(grid), dim3(SF_NT), 0, st, ka, stage_mask, im_count);
 }
 extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_launch_irls_pass)(int grid, hipStream_t st, const KArgs *ka, int which, int variant, int reps, int slices) {
+#ifndef SF_CLUSTER
     hipLaunchKernelGGL(sf_irls_pass_kernel, dim3(grid), dim3(SF_NT), 0, st, ka, which, variant, reps, slices);
+#endif
 }
 extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_variant_geometry)(int *threads, int *blocks_per_cu) {
     *threads = SF_NT;

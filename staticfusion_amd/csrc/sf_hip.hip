@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "sf_cluster.h"
 #include "sf_device_common.h"
 #include "sf_input.h"
 #include "sf_predict.h"
@@ -36,11 +37,16 @@ extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_nt1024(int
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_irls_pass_nt1024(int, hipStream_t, const KArgs *, int, int, int, int);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_debug_rows_nt256(int, hipStream_t, const KArgs *, int, float *);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_debug_rows_nt1024(int, hipStream_t, const KArgs *, int, float *);
+extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_ntcluster(int, hipStream_t, const KArgs *, int, int);
+extern "C" __attribute__((visibility("hidden"))) void sf_launch_irls_pass_ntcluster(int, hipStream_t, const KArgs *, int, int, int, int);
+extern "C" __attribute__((visibility("hidden"))) void sf_launch_debug_rows_ntcluster(int, hipStream_t, const KArgs *, int, float *);
+extern "C" __attribute__((visibility("hidden"))) void sf_variant_geometry_ntcluster(int *, int *);
 extern "C" __attribute__((visibility("hidden"))) void sf_variant_geometry_nt256(int *, int *);
 extern "C" __attribute__((visibility("hidden"))) void sf_variant_geometry_nt1024(int *, int *);
-static const FrameVariant VARIANTS[2] = {
+static const FrameVariant VARIANTS[3] = {
     {SF_VARIANT_THROUGHPUT, "throughput", sf_variant_geometry_nt256, sf_launch_frame_nt256, sf_launch_irls_pass_nt256, sf_launch_debug_rows_nt256},
     {SF_VARIANT_LATENCY, "latency", sf_variant_geometry_nt1024, sf_launch_frame_nt1024, sf_launch_irls_pass_nt1024, sf_launch_debug_rows_nt1024},
+    {SF_VARIANT_CLUSTER, "cluster", sf_variant_geometry_ntcluster, sf_launch_frame_ntcluster, sf_launch_irls_pass_ntcluster, sf_launch_debug_rows_ntcluster},
 };
 
 // prediction := current; current := pool[frame_index[stream]] for every stream, 16 bytes per lane and plane
@@ -70,6 +76,7 @@ struct sf_handle {
     int device = 0;
     int max_blocks = 0;
     const FrameVariant *fv = &VARIANTS[0];
+    int cluster_grid = 0;  // SF_VARIANT_CLUSTER: blocks per launch (8 XCDs x streams per XCD x workgroups per stream)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
@@ -148,7 +155,7 @@ static int launch(sf_handle *h, int mask, int im_count) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         h->args_dirty = false;
     }
-    const int grid = std::min(h->k.batch, h->max_blocks);
+    const int grid = h->cluster_grid ? h->cluster_grid : std::min(h->k.batch, h->max_blocks);
     const bool timed = (mask & ST_SOLVE) != 0;
     if (timed) HIP_TRY(hipEventRecord(h->evk0, h->stream));
     h->fv->launch_frame(grid, h->stream, (const KArgs *)h->d_args, mask, im_count);
@@ -246,14 +253,14 @@ int sf_get_variant(const sf_handle *h, int *variant, int *threads, int *workgrou
     h->fv->geometry(&t, &per_cu);
     if (variant) *variant = h->fv->id;
     if (threads) *threads = t;
-    if (workgroups_per_stream) *workgroups_per_stream = 1;
+    if (workgroups_per_stream) *workgroups_per_stream = h->k.cluster_g ? h->k.cluster_g : 1;
     return SF_OK;
 }
 
 int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, int variant, sf_handle **out) {
     if (!p || !out || rows < 8 || cols < 8 || batch < 1) return fail(SF_ERR_ARG, "bad argument");
     if (variant < SF_VARIANT_AUTO || variant > SF_VARIANT_CLUSTER) return fail(SF_ERR_ARG, "unknown variant");
-    if (variant == SF_VARIANT_CLUSTER) return fail(SF_ERR_ARG, "SF_VARIANT_CLUSTER is not built into this library");
+
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(SF_ERR_DEVICE, "no HIP device visible: libsf_hip.so has no CPU fallback");
@@ -320,11 +327,27 @@ int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, 
             if (!std::strcmp(v, "latency")) h->fv = &VARIANTS[1];
         }
     } else {
-        h->fv = &VARIANTS[variant == SF_VARIANT_THROUGHPUT ? 0 : 1];
+        h->fv = &VARIANTS[variant == SF_VARIANT_THROUGHPUT ? 0 : (variant == SF_VARIANT_LATENCY ? 1 : 2)];
     }
     int wg_threads = 0, wg_per_cu = 0;
     h->fv->geometry(&wg_threads, &wg_per_cu);
     h->max_blocks = prop.multiProcessorCount * wg_per_cu;
+    size_t slots = batch;  // record / accumulator slots of n0 pixels
+    if (h->fv->id == SF_VARIANT_CLUSTER) {
+        // G workgroups (CUs) per stream, all of a launch resident at once: 8 XCDs x (CUs / 8) CUs, the workgroups of a
+        // stream on one XCD. Default: as many as fit (at most 16), SF_CLUSTER_G overrides.
+        const int per_xcd = prop.multiProcessorCount / 8, streams_per_xcd = (batch + 7) / 8;
+        int G = std::min(16, per_xcd / streams_per_xcd);
+        if (const char *v = std::getenv("SF_CLUSTER_G")) G = std::atoi(v);
+        if (G < 1 || G > SF_MAX_CLUSTER || G * streams_per_xcd > per_xcd) {
+            sf_destroy(h);
+            return fail(SF_ERR_ARG, "SF_VARIANT_CLUSTER: batch too large (or SF_CLUSTER_G out of range): every stream needs its "
+                                    "workgroups resident at once, at most CUs / 8 workgroups per XCD");
+        }
+        k.cluster_g = G;
+        h->cluster_grid = 8 * streams_per_xcd * G;
+        slots = (size_t)batch * (1 + G);
+    }
     HIP_OR_FREE(hipStreamCreate(&h->own_stream));
     h->stream = h->own_stream;
     HIP_OR_FREE(hipEventCreate(&h->ev0));
@@ -343,11 +366,12 @@ int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, 
             TRY_OR_FREE(dev_alloc(h, &k.dbg_inter[c], B * NT));
         }
     TRY_OR_FREE(dev_alloc(h, &k.labels, B * NT));
-    TRY_OR_FREE(dev_alloc(h, &k.acc_d, B * N0));
-    TRY_OR_FREE(dev_alloc(h, &k.acc_i, B * N0));
-    for (int q = 0; q < R_COUNT; q++) TRY_OR_FREE(dev_alloc(h, &k.rec[q], B * N0));
-    TRY_OR_FREE(dev_alloc(h, &k.rec_lab, B * N0));
-    TRY_OR_FREE(dev_alloc(h, &k.rec_null, B * N0));
+    TRY_OR_FREE(dev_alloc(h, &k.acc_d, slots * N0));
+    TRY_OR_FREE(dev_alloc(h, &k.acc_i, slots * N0));
+    for (int q = 0; q < R_COUNT; q++) TRY_OR_FREE(dev_alloc(h, &k.rec[q], slots * N0));
+    TRY_OR_FREE(dev_alloc(h, &k.rec_lab, slots * N0));
+    TRY_OR_FREE(dev_alloc(h, &k.rec_null, slots * N0));
+    if (k.cluster_g) TRY_OR_FREE(dev_alloc(h, &k.sync, B * 2 * k.cluster_g * SF_SYNC_WORDS));
     TRY_OR_FREE(dev_alloc(h, &k.hist_d, (size_t)SF_HISTORY * B * N0));
     TRY_OR_FREE(dev_alloc(h, &k.hist_i, (size_t)SF_HISTORY * B * N0));
     TRY_OR_FREE(dev_alloc(h, &k.b_img, B * N0));
@@ -370,6 +394,7 @@ int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, 
             for (int q = 0; q < 16; q++) s.hist_T[i][q] = (q % 5 == 0) ? 1.f : 0.f;
         s.kb = p->kb;
     }
+    for (size_t b = 0; b < B; b++) st[b].last_slot = (int32_t)b;
     HIP_OR_FREE(hipMemcpy(k.state, st.data(), B * sizeof(StreamState), hipMemcpyHostToDevice));
     {
         std::vector<float> half(B * N0, 0.5f);  // b_segm_perpixel.fill(0.5f)
@@ -740,7 +765,7 @@ int sf_get_lin_plane(sf_handle *h, int stream, int which, float *out, int *rows,
     if (rows) *rows = h->k.lrows[L];
     if (cols) *cols = h->k.lcols[L];
     if (!out) return SF_OK;
-    const size_t n = h->k.ln[L], o = (size_t)stream * h->k.n0;
+    const size_t n = h->k.ln[L], o = (size_t)st.last_slot * h->k.n0;  // the slot the last outer iteration ran on
     if (which == SF_LIN_NULL) {
         if (!h->k.p.debug_planes) return fail(SF_ERR_STATE, "the Null plane needs params.debug_planes = 1");
         std::vector<uint8_t> tmp(n);

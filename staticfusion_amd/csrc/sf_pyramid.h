@@ -5,6 +5,7 @@
 // (-ffp-contract=off), which makes the planes bit-identical to the CPU path.
 #pragma once
 
+#include "sf_cluster.h"
 #include "sf_device_common.h"
 
 // convMask(k) = v_mask(i)*v_mask(j)/36.f with k = i + 4j  (reference FrontEnd.cpp:146-149)
@@ -14,7 +15,8 @@ __device__ __forceinline__ float conv_mask(int k) {
     return vi * vj / 36.f;
 }
 
-__device__ __noinline__ void stage_pyramid(const KArgs &a, int b, bool old_im, int tid) {
+__device__ __noinline__ void stage_pyramid(const KArgs &a, int b, bool old_im, int tid, LDS ClusterShared &cs) {
+    const int G = cl_G(cs), rank = cl_rank(cs);  // a cluster's workgroups take every G-th block of SF_NT pixels of a level
     float *const *set = old_im ? a.pyr_pred : a.pyr_new;
     const auto depth = as_global(set[0] + (size_t)b * a.n_tot);
     const auto inten = as_global(set[1] + (size_t)b * a.n_tot);
@@ -24,10 +26,10 @@ __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, bool old_im, i
         const int rows_i = a.lrows[L], cols_i = a.lcols[L], n = a.ln[L];
         const auto d_here = depth + a.loff[L], i_here = inten + a.loff[L];
         if (L > 0) {
-            __syncthreads();  // level L-1 complete (written by this workgroup)
+            cluster_barrier(cs, tid);  // level L-1 complete (written by this workgroup / by the cluster's workgroups)
             const auto d_prev = depth + a.loff[L - 1], i_prev = inten + a.loff[L - 1];
             const int rows_p = a.lrows[L - 1];
-            for (int idx = tid; idx < n; idx += SF_NT) {
+            for (int idx = tid + rank * SF_NT; idx < n; idx += SF_NT * G) {
                 const int u = idx / rows_i, v = idx - u * rows_i;
                 const int u2 = 2 * u, v2 = 2 * v;
                 float dout, iout;
@@ -98,5 +100,5 @@ __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, bool old_im, i
             }
         }  // level 0 is the input itself
     }
-    __syncthreads();
+    cluster_barrier(cs, tid);
 }

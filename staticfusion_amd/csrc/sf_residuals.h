@@ -4,6 +4,7 @@
 //   ring-buffer push                      (reference StaticFusion-datasets.cpp:182-184)
 #pragma once
 
+#include "sf_cluster.h"
 #include "sf_device_common.h"
 #include "sf_smallmath.h"
 
@@ -20,10 +21,11 @@ __device__ __forceinline__ int level0_label(const KArgs &a, gptr<const uint8_t> 
     return a.p.segmentation_enabled ? (int)labels0[idx] : 0;
 }
 
-__device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, LDS ResShared &s, int tid) {
+__device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, LDS ResShared &s, LDS ClusterShared &cs, int tid) {
     StreamState &st = a.state[b];
     const int rows = a.lrows[0], cols = a.lcols[0], n = a.ln[0];
-    const size_t sb = (size_t)b * a.n_tot, rb = (size_t)b * a.n0;
+    const int G = cl_G(cs), rank = cl_rank(cs);
+    const size_t sb = (size_t)b * a.n_tot, rb = (size_t)cl_slot(cs) * a.n0;
     const auto dcur = as_global((const float *)a.pyr_new[0] + sb), icur = as_global((const float *)a.pyr_new[1] + sb);  // depthCurrent / intensityCurrent
     const auto labels0 = as_global((const uint8_t *)a.labels + sb);
     const int idx_to_warp = (index - SF_HISTORY) % SF_HISTORY;
@@ -46,11 +48,11 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, L
         s.lab_sum[tid] = 0;
         s.lab_cnt[tid] = 0;
     }
-    for (int idx = tid; idx < n; idx += SF_NT) {
+    for (int idx = tid + rank * SF_NT; idx < n; idx += SF_NT * G) {
         acc_d[idx] = 0;
         acc_i[idx] = 0;
     }
-    __syncthreads();
+    cluster_barrier(cs, tid);
 
     const float inv_f_i = 2.f * a.tan_half_fovh / float(cols);
     SplatGeom g;
@@ -77,21 +79,23 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, L
             return z != 0.f && dc != 0.f;
         }
     } src{dbuf, ibuf, dcur, inv_f_i, g.disp_u_i, g.disp_v_i};
-    tiled_splat(g, rows, cols, src, acc_d, acc_i, s.win, tid);
-    __syncthreads();
+    tiled_splat(g, rows, cols, src, acc_d, acc_i, s.win, tid, rank, G);
+    cluster_barrier(cs, tid);
 
     // residuals, cluster-wise (:1036-1068): per-lane running sums per label, flushed to the workgroup bins
     // (integer LDS atomics) when the label changes; SF_LOAD_BATCH pixels per trip with all loads issued first
     const float kph = a.p.k_photometric_res;
     int cur_lab = 0, cur_cnt = 0;
     long long cur_sum = 0;
-    for (int base = tid; base < n; base += SF_NT * SF_LOAD_BATCH) {
+    int px_begin, px_end;
+    cluster_range(cs, n, 1, px_begin, px_end);  // this workgroup's share of the level
+    for (int base = px_begin + tid; base < px_end; base += SF_NT * SF_LOAD_BATCH) {
         long long sd[SF_LOAD_BATCH], si[SF_LOAD_BATCH];
         float dc[SF_LOAD_BATCH], db[SF_LOAD_BATCH], ic[SF_LOAD_BATCH];
         int lb[SF_LOAD_BATCH];
 #pragma unroll
         for (int k = 0; k < SF_LOAD_BATCH; k++) {
-            const int idx = min(base + k * SF_NT, n - 1);
+            const int idx = min(base + k * SF_NT, px_end - 1);
             sd[k] = __hip_atomic_load(acc_d + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             si[k] = __hip_atomic_load(acc_i + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             dc[k] = dcur[idx];
@@ -101,7 +105,7 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, L
         }
 #pragma unroll
         for (int k = 0; k < SF_LOAD_BATCH; k++) {
-            if (!(base + k * SF_NT < n && si[k] != 0 && dc[k] != 0.f)) continue;
+            if (!(base + k * SF_NT < px_end && si[k] != 0 && dc[k] != 0.f)) continue;
             float dw, iw;
             normalise_acc(sd[k], si[k], dw, iw);
             if (dw == 0.f || lb[k] >= SF_NC) continue;
@@ -126,20 +130,32 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, L
         lds_add(&s.lab_cnt[cur_lab], cur_cnt);
     }
     __syncthreads();
+    // per-label sums (exact integers) and counts over the workgroups of the cluster
     if (tid < SF_NC) {
-        const int c = s.lab_cnt[tid];
-        const float sum = (float)((double)s.lab_sum[tid] * (1.0 / 4294967296.0));
+        put_i64(&cs.in[2 * tid], s.lab_sum[tid]);
+        cs.in[2 * SF_NC + tid] = (unsigned)s.lab_cnt[tid];
+    }
+    cluster_gather(cs, 3 * SF_NC, tid);
+    if (tid < SF_NC && cl_writer(cs)) {
+        long long t = 0;
+        int c = 0;
+        for (int p = 0; p < G; p++) {
+            t += get_i64(&cs.all[p * 3 * SF_NC + 2 * tid]);
+            c += (int)cs.all[p * 3 * SF_NC + 2 * SF_NC + tid];
+        }
+        const float sum = (float)((double)t * (1.0 / 4294967296.0));
         st.cluster_res[tid] = (c > 0) ? sum / float(2 * (c + 1)) : __int_as_float(0x7fc00000);
     }
-    __syncthreads();
+    cluster_barrier(cs, tid);  // perClusterAverageResidual is visible to buildSegmImage in every workgroup
 }
 
-__device__ __noinline__ void stage_segm_image(const KArgs &a, int b, int tid) {
+__device__ __noinline__ void stage_segm_image(const KArgs &a, int b, int tid, LDS ClusterShared &cs) {
     const StreamState &st = a.state[b];
     const int n = a.ln[0];
+    const int G = cl_G(cs), rank = cl_rank(cs);
     const auto labels0 = as_global((const uint8_t *)a.labels + (size_t)b * a.n_tot);
     const auto out = as_global(a.b_img + (size_t)b * a.n0);
-    for (int base = tid; base < n; base += SF_NT * SF_LOAD_BATCH) {
+    for (int base = tid + rank * SF_NT * SF_LOAD_BATCH; base < n; base += SF_NT * SF_LOAD_BATCH * G) {
         int lab[SF_LOAD_BATCH];
 #pragma unroll
         for (int k = 0; k < SF_LOAD_BATCH; k++) lab[k] = level0_label(a, labels0, min(base + k * SF_NT, n - 1));
@@ -157,13 +173,14 @@ __device__ __noinline__ void stage_segm_image(const KArgs &a, int b, int tid) {
     }
 }
 
-__device__ __noinline__ void stage_push_history(const KArgs &a, int b, int im_count, int tid) {
+__device__ __noinline__ void stage_push_history(const KArgs &a, int b, int im_count, int tid, LDS ClusterShared &cs) {
+    const int G = cl_G(cs), rank = cl_rank(cs);
     StreamState &st = a.state[b];
     const int slot = im_count % SF_HISTORY, n = a.ln[0];
     const auto dcur = as_global((const float *)a.pyr_new[0] + (size_t)b * a.n_tot), icur = as_global((const float *)a.pyr_new[1] + (size_t)b * a.n_tot);
     const auto dbuf = as_global(a.hist_d + ((size_t)slot * a.batch + b) * a.n0);
     const auto ibuf = as_global(a.hist_i + ((size_t)slot * a.batch + b) * a.n0);
-    for (int base = tid * 4; base < n; base += SF_NT * 4 * 2) {  // 16-byte copies, two per trip
+    for (int base = tid * 4 + rank * SF_NT * 8; base < n; base += SF_NT * 4 * 2 * G) {  // 16-byte copies, two per trip
         typedef float __attribute__((ext_vector_type(4))) f4;
         typedef __attribute__((address_space(1))) const f4 gcf4;
         typedef __attribute__((address_space(1))) f4 gf4;
@@ -182,5 +199,5 @@ __device__ __noinline__ void stage_push_history(const KArgs &a, int b, int im_co
             *(gf4 *)(ibuf + i1) = c1;
         }
     }
-    if (tid < 16) st.hist_T[slot][tid] = st.T[tid];
+    if (tid < 16 && cl_writer(cs)) st.hist_T[slot][tid] = st.T[tid];
 }

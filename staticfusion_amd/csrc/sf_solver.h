@@ -20,6 +20,7 @@
 // The Jacobian matrix A (2N x 6) of the reference is never materialised.
 #pragma once
 
+#include "sf_cluster.h"
 #include "sf_device_common.h"
 #include "sf_smallmath.h"
 
@@ -74,7 +75,9 @@ struct SolveShared {
     // IRLS
     float AtA[36], AtB[6], Var[6], prev_sol[6];
     float aver_res, aver_res_old, inv_max_c, inv_max_d, res_sqnorm;
-    int px_begin, px_end;  // pixel range of the level the streaming passes walk (the whole level in the product)
+    double sq_total;  // ||res||^2 of the last pass 2, summed over the workgroups of the cluster
+    int px_begin, px_end;  // pixel range of the level the streaming passes walk: this workgroup's share of the level
+    int rec_slot;          // record slot the passes stream (the stream's, or this workgroup's private one)
     double init_abs_c, init_abs_d;  // sum of wc |dct| and wd |ddt| over validPixels (raw pre-weights), from the linearisation
     int n_valid, ctrl, status, n_irls, n_outer, first;
     long long pixel_iters;
@@ -204,19 +207,20 @@ __device__ __forceinline__ void split_index(const LevelGeom &g, int idx, float &
 //  warp (reference FrontEnd.cpp:775-892), scatter part.  Normalisation happens when the
 //  accumulators are read by the linearisation.
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveShared &s, int tid) {
+__device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveShared &s, LDS ClusterShared &cs, int tid) {
     const int rows_i = a.lrows[L], cols_i = a.lcols[L], n = a.ln[L], o = a.loff[L];
-    const size_t sb = (size_t)b * a.n_tot;
+    const int G = cl_G(cs), rank = cl_rank(cs);
+    const size_t sb = (size_t)b * a.n_tot, rb = (size_t)cl_slot(cs) * a.n0;
     const auto dpred = as_global((const float *)a.pyr_pred[0] + sb + o), ipred = as_global((const float *)a.pyr_pred[1] + sb + o);
-    const auto acc_d = as_global(a.acc_d + (size_t)b * a.n0);
-    const auto acc_i = as_global(a.acc_i + (size_t)b * a.n0);
+    const auto acc_d = as_global(a.acc_d + rb);
+    const auto acc_i = as_global(a.acc_i + rb);
 
     if (tid == 0) inverse4_cm(s.T, s.Tinv, s.dwork);  // T = T_odometry.inverse()  (:800)
-    for (int idx = tid; idx < n; idx += SF_NT) {
+    for (int idx = tid + rank * SF_NT; idx < n; idx += SF_NT * G) {  // a cluster's workgroups zero every G-th block
         acc_d[idx] = 0;
         acc_i[idx] = 0;
     }
-    __syncthreads();
+    cluster_barrier(cs, tid);  // the accumulators are zero everywhere before anybody splats into them
 
     SplatGeom g;
     g.f = float(cols_i) / (2.f * a.tan_half_fovh);
@@ -241,8 +245,8 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
             return z != 0.f;
         }
     } src{dpred, ipred, level_coord(a, L)};
-    tiled_splat(g, rows_i, cols_i, src, acc_d, acc_i, s.win, tid);
-    __syncthreads();  // all atomics of this workgroup performed at L2
+    tiled_splat(g, rows_i, cols_i, src, acc_d, acc_i, s.win, tid, rank, G);
+    cluster_barrier(cs, tid);  // all atomics of the workgroup(s) performed at L2 / visible to the cluster
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -254,10 +258,11 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
 #define TILE_CPX 2
 #define TILE_EPT ((TILE_N + SF_NT - 1) / SF_NT)  // halo-tile elements per lane
 
-__device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool first, LDS SolveShared &s, int tid) {
+__device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool first, LDS SolveShared &s, LDS ClusterShared &cs, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const int rows_i = a.lrows[L], cols_i = a.lcols[L], o = a.loff[L];
-    const size_t sb = (size_t)b * a.n_tot, rb = (size_t)b * a.n0;
+    const int G = cl_G(cs), rank = cl_rank(cs);  // a cluster's workgroups take every G-th tile
+    const size_t sb = (size_t)b * a.n_tot, rb = (size_t)cl_slot(cs) * a.n0;
     const auto dnew = as_global((const float *)a.pyr_new[0] + sb + o), inew = as_global((const float *)a.pyr_new[1] + sb + o);
     const auto dpred = as_global((const float *)a.pyr_pred[0] + sb + o), ipred = as_global((const float *)a.pyr_pred[1] + sb + o);
     const auto acc_d = as_global((const long long *)a.acc_d + rb), acc_i = as_global((const long long *)a.acc_i + rb);
@@ -323,9 +328,9 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
-    LIN_PREFETCH(0);
+    if (rank < n_tiles) LIN_PREFETCH(rank);
 
-    for (int tile = 0; tile < n_tiles; tile++) {
+    for (int tile = rank; tile < n_tiles; tile += G) {
         const int tv0 = (tile % tiles_v) * TILE_V, tu0 = (tile / tiles_v) * TILE_U;
         __syncthreads();  // previous tile consumed (and the bin initialisation above)
 #pragma unroll
@@ -359,7 +364,7 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
         const int c_lab0 = seg ? pf_lab[0] : 0, c_lab1 = seg ? pf_lab[1] : 0;  // scalars: indexing by the loop
                                                                                  // counter below would go to scratch
         __syncthreads();
-        if (tile + 1 < n_tiles) LIN_PREFETCH(tile + 1);  // in flight while this tile is evaluated
+        if (tile + G < n_tiles) LIN_PREFETCH(tile + G);  // in flight while this tile is evaluated
 
 #pragma unroll 1
         for (int k = 0; k < TILE_CPX; k++) {
@@ -470,6 +475,12 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
         s.red[wave][1] = abs_d;
     }
     __syncthreads();
+    // this workgroup's partial results -> payload words; every workgroup of the cluster then receives all of them and
+    // combines them in rank order (maxima, counts and the fixed-point sums are order free; the two fp64 sums are added in
+    // the same order everywhere). The gather also is the barrier behind which the records may be read by everybody.
+    enum { W_TC = 0, W_TD, W_NV, W_AC, W_AD = W_AC + 2, W_PSUM = W_AD + 2, W_PSIZE = W_PSUM + 2 * SF_NC, W_PNN = W_PSIZE + SF_NC,
+           W_VCNT = W_PNN + SF_NC, W_LIN_WORDS = W_VCNT + SF_NC };
+    static_assert(W_LIN_WORDS <= SF_SYNC_WORDS, "payload of the linearisation rendezvous");
     if (tid == 0) {
         int tc = 0, td = 0, nv = 0;  // transformed minima, see above
         double ac = 0.0, ad = 0.0;
@@ -479,6 +490,31 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
             nv += s.redi[w];
             ac += s.red[w][0];
             ad += s.red[w][1];
+        }
+        cs.in[W_TC] = (unsigned)tc;
+        cs.in[W_TD] = (unsigned)td;
+        cs.in[W_NV] = (unsigned)nv;
+        put_f64(&cs.in[W_AC], ac);
+        put_f64(&cs.in[W_AD], ad);
+    }
+    if (seg && tid < SF_NC) {
+        put_i64(&cs.in[W_PSUM + 2 * tid], s.prior_sum[tid]);
+        cs.in[W_PSIZE + tid] = (unsigned)s.prior_size[tid];
+        cs.in[W_PNN + tid] = (unsigned)s.prior_nonnull[tid];
+        cs.in[W_VCNT + tid] = (unsigned)s.valid_cnt[tid];
+    }
+    const int n_words = seg ? (int)W_LIN_WORDS : (int)W_PSUM;
+    cluster_gather(cs, n_words, tid, true);
+    if (tid == 0) {
+        int tc = 0, td = 0, nv = 0;
+        double ac = 0.0, ad = 0.0;
+        for (int p = 0; p < G; p++) {
+            const LDS unsigned *w = &cs.all[p * n_words];
+            tc = max(tc, (int)w[W_TC]);
+            td = max(td, (int)w[W_TD]);
+            nv += (int)w[W_NV];
+            ac += get_f64(&w[W_AC]);
+            ad += get_f64(&w[W_AD]);
         }
         s.init_abs_c = ac;
         s.init_abs_d = ad;
@@ -491,16 +527,26 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
     }
     if (seg && tid < SF_NC) {  // reference SegmentationBackground.cpp:84-102
         const int l = tid;
+        long long psum = 0;
+        int psize = 0, pnn = 0, vcnt = 0;
+        for (int p = 0; p < G; p++) {
+            const LDS unsigned *w = &cs.all[p * n_words];
+            psum += get_i64(&w[W_PSUM + 2 * l]);
+            psize += (int)w[W_PSIZE + l];
+            pnn += (int)w[W_PNN + l];
+            vcnt += (int)w[W_VCNT + l];
+        }
+        s.valid_cnt[l] = vcnt;  // num_pix_label of the whole level (the b-solve's 1 / (2 (n + 1)))
         float bp = 0.f, lt = 0.f;
-        if (s.prior_size[l] != 0) {
-            const float ratio = float(s.prior_nonnull[l]) / float(s.prior_size[l]);
+        if (psize != 0) {
+            const float ratio = float(pnn) / float(psize);
             if (ratio < 0.1f) {
                 lt = 0.1f;
                 bp = -1.f;
             } else {
                 lt = ratio;
-                const float sum = (float)((double)s.prior_sum[l] * (1.0 / 4294967296.0));
-                bp = std_max(-1.f, std_min(2.f, sum / s.prior_nonnull[l]));
+                const float sum = (float)((double)psum * (1.0 / 4294967296.0));
+                bp = std_max(-1.f, std_min(2.f, sum / pnn));
             }
         }
         s.b_prior[l] = bp;
@@ -675,7 +721,7 @@ struct IrlsCtx {
 
 __device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, const LDS SolveShared &s) {
     IrlsCtx c;
-    const size_t rb = (size_t)b * a.n0;
+    const size_t rb = (size_t)uniform_i(s.rec_slot) * a.n0;
 #pragma unroll
     for (int q = 0; q < R_COUNT; q++) c.rp.p[q] = uniform_ptr((gcfloat *)(a.rec[q] + rb));
     c.rp.dnew = uniform_ptr((gcfloat *)(a.pyr_new[0] + (size_t)b * a.n_tot + a.loff[L]));
@@ -817,14 +863,26 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, LDS SolveS
     }
 }
 
-// wave 0: finish the reduction, AtA / AtB, Var = AtA.ldlt().solve(AtB) (reference :640-642)
-__device__ __noinline__ void irls_solve_normal(LDS SolveShared &s, int lane) {
-    if (lane < 27) {
+// all threads: the 27 sums of pass 1 over the waves of this workgroup, then over the workgroups of the cluster (fixed
+// orders: every workgroup ends up with the same bits) -> s.red[0][0..26]
+__device__ __forceinline__ void irls_reduce_normal(LDS SolveShared &s, LDS ClusterShared &cs, int tid) {
+    if (tid < 27) {
         double t = 0.0;
-        for (int w = 0; w < SF_NW; w++) t += s.red[w][lane];
-        s.red[0][lane] = t;
+        for (int w = 0; w < SF_NW; w++) t += s.red[w][tid];
+        put_f64(&cs.in[2 * tid], t);
     }
-    __builtin_amdgcn_wave_barrier();
+    cluster_gather(cs, 54, tid);
+    if (tid < 27) {
+        const int G = cl_G(cs);
+        double t = 0.0;
+        for (int p = 0; p < G; p++) t += get_f64(&cs.all[p * 54 + 2 * tid]);
+        s.red[0][tid] = t;
+    }
+    __syncthreads();
+}
+
+// wave 0: AtA / AtB from the reduced sums, Var = AtA.ldlt().solve(AtB) (reference :640-642)
+__device__ __noinline__ void irls_solve_normal(LDS SolveShared &s, int lane) {
     if (lane < 36) {
         const int i = lane / 6, j = lane - 6 * i;
         const int lo = min(i, j), hi = max(i, j);
@@ -843,6 +901,29 @@ __device__ __noinline__ void irls_solve_normal(LDS SolveShared &s, int lane) {
     ldlt_solve_wave<6>(s.M6, s.tr6, az, s.y6, lane);
     if (lane < 6) s.Var[lane] = s.y6[lane];
     if (lane < SF_NC) s.lab_sum[lane] = 0;
+}
+
+// all threads, after pass 2: the per-label sums (exact integers) and ||res||^2 over the workgroups of the cluster
+__device__ __forceinline__ void irls_reduce_residuals(LDS SolveShared &s, LDS ClusterShared &cs, int tid) {
+    if (tid < SF_NC) put_i64(&cs.in[2 * tid], s.lab_sum[tid]);
+    if (tid == SF_NC) {
+        double q = 0.0;
+        for (int w = 0; w < SF_NW; w++) q += s.red[w][27];
+        put_f64(&cs.in[2 * SF_NC], q);
+    }
+    cluster_gather(cs, 2 * SF_NC + 2, tid);
+    const int G = cl_G(cs);
+    if (tid < SF_NC) {
+        long long t = 0;
+        for (int p = 0; p < G; p++) t += get_i64(&cs.all[p * (2 * SF_NC + 2) + 2 * tid]);
+        s.lab_sum[tid] = t;
+    }
+    if (tid == SF_NC) {
+        double q = 0.0;
+        for (int p = 0; p < G; p++) q += get_f64(&cs.all[p * (2 * SF_NC + 2) + 2 * SF_NC]);
+        s.sq_total = q;
+    }
+    __syncthreads();
 }
 
 // non-negative float (< 2^20) -> Q32.32 fixed point without the emulated float->int64 conversion
@@ -958,9 +1039,7 @@ __device__ __noinline__ void irls_iteration_tail(const KArgs &a, LDS SolveShared
         for (int l = 0; l < SF_NC; l++) t += (double)s.aver_res_label[l];
         s.aver_res_old = s.aver_res;
         s.aver_res = (float)t / float(2 * N);
-        double q = 0.0;
-        for (int w = 0; w < SF_NW; w++) q += s.red[w][27];
-        s.res_sqnorm = (float)q;
+        s.res_sqnorm = (float)s.sq_total;
     }
     __builtin_amdgcn_wave_barrier();
     if (seg) {
@@ -998,12 +1077,13 @@ __device__ __noinline__ void irls_iteration_tail(const KArgs &a, LDS SolveShared
     }
 }
 
-__device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level, int kouter, LDS SolveShared &s, int tid) {
+__device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level, int kouter, LDS SolveShared &s, LDS ClusterShared &cs, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const bool seg = a.p.segmentation_enabled != 0;
     const int N = __builtin_amdgcn_readfirstlane(s.n_valid);
     const int n_outer_now = __builtin_amdgcn_readfirstlane(s.n_outer);
-    sf_outer_trace *tr = (n_outer_now < SF_MAX_OUTER) ? &a.stats[b].outer[n_outer_now] : nullptr;
+    // the trace is written by ONE workgroup of a cluster (all of them hold the same values)
+    sf_outer_trace *tr = (n_outer_now < SF_MAX_OUTER && cl_writer(cs)) ? &a.stats[b].outer[n_outer_now] : nullptr;
 
     // b initialisation (reference :603-607)
     if (tid < SF_NC) {
@@ -1017,8 +1097,11 @@ __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level,
         s.prev_sol[tid] = 0.f;
     }
     if (tid == 0) {
-        s.px_begin = 0;
-        s.px_end = a.ln[L];
+        int pb, pe;
+        cluster_range(cs, a.ln[L], 2, pb, pe);  // the passes walk pixel pairs
+        s.px_begin = pb;
+        s.px_end = pe;
+        s.rec_slot = cs.slot;
     }
     __syncthreads();
 
@@ -1056,12 +1139,14 @@ __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level,
         iters_done = k;
         irls_pass1<0>(a, b, L, s, tid);
         __syncthreads();
+        irls_reduce_normal(s, cs, tid);
         PROF_MARK(s, tid, PF_PASS1);
         if (wave == 0) irls_solve_normal(s, lane);
         __syncthreads();
         PROF_MARK(s, tid, PF_SOLVE6);
         irls_pass2<0>(a, b, L, s, tid);
         __syncthreads();
+        irls_reduce_residuals(s, cs, tid);
         PROF_MARK(s, tid, PF_PASS2);
         if (wave == 0) irls_iteration_tail(a, s, N, k, lane);
         __syncthreads();
@@ -1098,7 +1183,11 @@ __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level,
 // ---------------------------------------------------------------------------------------------
 //  the coarse-to-fine loop (reference FrontEnd.cpp:1091-1144)
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ void stage_solve(const KArgs &a, int b, LDS SolveShared &s, int tid) {
+// Levels of at most this many pixels are not worth a rendezvous per reduction: in the cluster build every workgroup runs
+// them on its own (redundantly, on a private record slot) and all arrive at bit-identical state.
+#define SF_CLUSTER_SOLO_PIXELS 8192
+
+__device__ __noinline__ void stage_solve(const KArgs &a, int b, LDS SolveShared &s, LDS ClusterShared &cs, int tid) {
     StreamState &st = a.state[b];
     if (tid < 16) s.T[tid] = (tid % 5 == 0) ? 1.f : 0.f;  // T_odometry.setIdentity()  (:1091)
     if (tid < 6) {
@@ -1122,18 +1211,20 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, LDS SolveShared 
         s.pixel_iters = 0;
     }
     __syncthreads();
+    const bool clustered = uniform_i(cs.full_G) > 1;
 
     int last_L = 0;
     for (int i = 0; i < a.levels; i++) {
+        const int L = a.levels - i - 1;  // image_level
+        if (clustered) cluster_set_solo(cs, tid, a.ln[L] <= SF_CLUSTER_SOLO_PIXELS);
         for (int k = 0; k < a.p.max_iter_per_level; k++) {
-            const int L = a.levels - i - 1;  // image_level
             last_L = L;
             const bool first = (i == 0) && (k == 0);
-            if (!first) solve_warp(a, b, L, s, tid);
+            if (!first) solve_warp(a, b, L, s, cs, tid);
             PROF_MARK(s, tid, PF_WARP);
-            solve_linearise(a, b, L, first, s, tid);
+            solve_linearise(a, b, L, first, s, cs, tid);
             PROF_MARK(s, tid, PF_LINEARISE);
-            solve_irls(a, b, L, i, k, s, tid);
+            solve_irls(a, b, L, i, k, s, cs, tid);
             if (tid == 0) {
                 s.n_outer++;
                 double s2 = 0.0;
@@ -1147,6 +1238,8 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, LDS SolveShared 
             if (brk) break;
         }
     }
+    const int last_slot = cl_slot(cs);
+    if (clustered) cluster_set_solo(cs, tid, false);
 
     // twist_odometry_old = R_inc^-1 * twist_odometry (reference :1139-1144)
     if (tid == 0) {
@@ -1163,36 +1256,41 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, LDS SolveShared 
                 acc += Rif[r * 3 + 2] * s.twist[half * 3 + 2];
                 s.twist_old[half * 3 + r] = acc;
             }
-        sf_frame_stats &fs = a.stats[b];
-        fs.n_outer = s.n_outer;
-        fs.n_irls = s.n_irls;
-        fs.pixel_iters = s.pixel_iters;
-        fs.status = s.status;
-        st.last_level = last_L;
-        st.last_first = s.first;
-        st.cum_frames += 1;
-        st.cum_irls += s.n_irls;
-        st.cum_outer += s.n_outer;
-        st.cum_pixel_iters += s.pixel_iters;
-        st.inv_max_c = s.inv_max_c;
-        st.inv_max_d = s.inv_max_d;
-        if (!a.p.segmentation_enabled) fs.kmeans_iters = 0;
     }
     __syncthreads();
-    if (tid < 16) st.T[tid] = s.T[tid];
-    if (tid < 6) {
-        st.twist_old[tid] = s.twist_old[tid];
-        st.twist[tid] = s.twist[tid];
-        st.twist_level[tid] = s.twist_level[tid];
+    if (cl_writer(cs)) {  // ONE workgroup of a cluster stores the stream's results (all of them hold the same values)
+        if (tid == 0) {
+            sf_frame_stats &fs = a.stats[b];
+            fs.n_outer = s.n_outer;
+            fs.n_irls = s.n_irls;
+            fs.pixel_iters = s.pixel_iters;
+            fs.status = s.status | (sync_failed(cs) ? SF_STATUS_SYNC_TIMEOUT : 0);
+            st.last_level = last_L;
+            st.last_first = s.first;
+            st.last_slot = last_slot;
+            st.cum_frames += 1;
+            st.cum_irls += s.n_irls;
+            st.cum_outer += s.n_outer;
+            st.cum_pixel_iters += s.pixel_iters;
+            st.inv_max_c = s.inv_max_c;
+            st.inv_max_d = s.inv_max_d;
+            if (!a.p.segmentation_enabled) fs.kmeans_iters = 0;
+        }
+        if (tid < 16) st.T[tid] = s.T[tid];
+        if (tid < 6) {
+            st.twist_old[tid] = s.twist_old[tid];
+            st.twist[tid] = s.twist[tid];
+            st.twist_level[tid] = s.twist_level[tid];
+        }
+        if (tid < 36) st.est_cov[tid] = s.est_cov[tid];
+        if (tid >= PF_WARP && tid <= PF_FILTER) st.prof[tid] += s.prof[tid];
+        if (tid < SF_NC) {
+            st.b_segm[tid] = s.b_segm[tid];
+            st.b_prior[tid] = s.b_prior[tid];
+            st.lambda_t_w[tid] = s.lambda_t_w[tid];
+        }
     }
-    if (tid < 36) st.est_cov[tid] = s.est_cov[tid];
-    if (tid >= PF_WARP && tid <= PF_FILTER) st.prof[tid] += s.prof[tid];
-    if (tid < SF_NC) {
-        st.b_segm[tid] = s.b_segm[tid];
-        st.b_prior[tid] = s.b_prior[tid];
-        st.lambda_t_w[tid] = s.lambda_t_w[tid];
-    }
-    __syncthreads();
+    cluster_barrier(cs, tid);  // the stream state is visible to the stages that follow (in every workgroup)
 }
 
 
@@ -1206,7 +1304,7 @@ __device__ __forceinline__ void debug_rows(const KArgs &a, int b, float *out, in
     const StreamState &st = a.state[b];
     const int L = st.last_level;
     const int n = a.ln[L], rows_i = a.lrows[L], cols_i = a.lcols[L];
-    const size_t rb = (size_t)b * a.n0;
+    const size_t rb = (size_t)st.last_slot * a.n0;
     const float f = float(cols_i) / (2.f * a.tan_half_fovh);
     LevelGeom g;
     g.rows_i = rows_i;
@@ -1256,6 +1354,7 @@ __device__ void microbench_pass(const KArgs &a, int b, int slice, int slices, in
     if (tid == 0) {
         s.inv_max_c = st.inv_max_c;
         s.inv_max_d = st.inv_max_d;
+        s.rec_slot = b;
         s.aver_res = 0.002f;
         s.first = 0;
         s.n_valid = a.ln[0];

@@ -231,7 +231,10 @@ def test_batch_streams_are_independent_and_deterministic(hip, pair):
         assert np.array_equal(bimg[i], bimg[3 + i])
     single = make_solver(hip, 240, 320, p, prs[1])
     single.process_frame(0)
-    assert np.array_equal(single.T(0), T[1])
+    if hip.default_variant == "cluster":  # the number of workgroups per stream (the partition of the sums) depends on the batch
+        assert np.abs(single.T(0) - T[1]).max() < 2e-6
+    else:
+        assert np.array_equal(single.T(0), T[1])
     for b in range(3):  # rigid transforms
         R = T[b][:3, :3].astype(np.float64)
         assert np.abs(R @ R.T - np.eye(3)).max() < 1e-5 and abs(np.linalg.det(R) - 1) < 1e-5

@@ -16,24 +16,32 @@
 //  wave-parallel pivoted LDL^T.  M is [N][N+1] floats in LDS (lower triangle used).
 //  Must be called by all 64 lanes of ONE wave.
 // ---------------------------------------------------------------------------------------------
+// DPP move that leaves lanes without a source (row edges, masked rows) at the identity of a max over keys (-1)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_i64_keep(long long b) {
+    const int lo = __builtin_amdgcn_update_dpp(-1, (int)(b & 0xffffffffll), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(-1, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return ((long long)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ long long sf_op_max64(long long a, long long b) {  // unsigned order: -1 is the identity's opposite, see below
+    return ((unsigned long long)(a + 1) > (unsigned long long)(b + 1)) ? a : b;     // keys + 1: the identity -1 becomes 0, the smallest
+}
+
 template <int N>
 __device__ inline bool ldlt_factor_wave(LDS volatile float *M, LDS volatile float *temp, LDS volatile int *transp, int lane) {
     constexpr int LD = N + 1;
     bool all_zero = false;
 #pragma unroll 1
     for (int k = 0; k < N; k++) {
-        // largest |diagonal| of the trailing block; the first maximum wins
-        float a = (lane >= k && lane < N) ? fabsf(M[lane * LD + lane]) : -1.f;
-        int idx = lane;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float a2 = __shfl_xor(a, o, 64);
-            const int i2 = __shfl_xor(idx, o, 64);
-            if (a2 > a || (a2 == a && i2 < idx)) {
-                a = a2;
-                idx = i2;
-            }
-        }
+        // largest |diagonal| of the trailing block; the first maximum wins. One 64-bit key per lane -- |a| (non-negative
+        // floats order like their bit patterns) above the complemented lane index -- and a max over the DPP network
+        // instead of six rounds of two LDS-crossbar shuffles.
+        const float a = (lane >= k && lane < N) ? fabsf(M[lane * LD + lane]) : 0.f;
+        // a NaN never replaces the running maximum of the scalar algorithm (x > best is false), unless it is the first element
+        const unsigned abits = (a != a) ? ((lane == k) ? 0xffffffffu : 0u) : __float_as_uint(a);
+        long long key = (lane >= k && lane < N) ? (long long)(((unsigned long long)abits << 32) | (unsigned)(63 - lane)) : -1ll;
+        SF_DPP_REDUCE(key, dpp_i64_keep, sf_op_max64)
+        const int idx = 63 - (int)(__builtin_amdgcn_readlane((int)(key & 0xffffffffll), 63) & 63);
         const int big = __builtin_amdgcn_readfirstlane(idx);
         if (lane == 0) transp[k] = big;
         if (big != k) {  // symmetric swap on the lower triangle: four disjoint element sets
@@ -83,54 +91,69 @@ __device__ inline bool ldlt_factor_wave(LDS volatile float *M, LDS volatile floa
     return all_zero;
 }
 
+__device__ __forceinline__ float readlane_f32(float x, int l) {  // the builtin is int -> int: a float argument would be CONVERTED
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
+}
+
 // Solves with the factors above. y is [N] floats in LDS holding b on entry and x on exit.
+// Lane i keeps y_i, row i of L (forward substitution) and column i of L (backward substitution) in registers -- 2 N
+// batched LDS reads -- and the substitutions run on v_readlane broadcasts: every y_i sees the operations of the scalar
+// algorithm in the same order (y_i -= L_ij y_j for ascending j, then descending j), without an LDS round trip per step.
 template <int N>
-__device__ inline void ldlt_solve_wave(LDS volatile const float *M, LDS volatile const int *transp, bool all_zero,
+__device__ inline void ldlt_solve_wave(LDS volatile const float *Mv, LDS volatile const int *transpv, bool all_zero,
                                        LDS volatile float *y, int lane) {
     constexpr int LD = N + 1;
-    if (lane == 0) {
-        for (int k = 0; k < N; k++) {
-            const int t = transp[k];
-            if (t != k) {
-                const float s = y[k];
-                y[k] = y[t];
-                y[t] = s;
-            }
+    const LDS float *M = (const LDS float *)Mv;
+    const LDS int *transp = (const LDS int *)transpv;
+    const int row = (lane < N) ? lane : 0;
+    float lrow[N], lcol[N];
+    int tr[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        lrow[j] = M[row * LD + j];  // L(lane, j), j < lane
+        lcol[j] = M[j * LD + row];  // L(j, lane), j > lane
+        tr[j] = transp[j];
+    }
+    float yi = y[row];
+    const float di = M[row * LD + row];
+    // P b
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const int t = __builtin_amdgcn_readfirstlane(tr[k]);
+        if (t != k) {
+            const float yk = readlane_f32(yi, k), yt = readlane_f32(yi, t);
+            yi = (lane == k) ? yt : ((lane == t) ? yk : yi);
         }
     }
-    __builtin_amdgcn_wave_barrier();
     if (!all_zero) {
-#pragma unroll 1
+#pragma unroll
         for (int j = 0; j < N; j++) {
-            const float yj = y[j];
-            if (lane > j && lane < N) y[lane] -= M[lane * LD + j] * yj;
-            __builtin_amdgcn_wave_barrier();
+            const float yj = readlane_f32(yi, j);
+            if (lane > j) yi -= lrow[j] * yj;
         }
     }
-    if (lane < N) {
-        const float di = all_zero ? 0.f : M[lane * LD + lane];
+    {
+        const float d = all_zero ? 0.f : di;
         const float tol = 1.17549435e-38f;  // std::numeric_limits<float>::min(), Eigen's LDLT tolerance
-        y[lane] = (fabsf(di) > tol) ? (y[lane] / di) : 0.f;
+        yi = (fabsf(d) > tol) ? (yi / d) : 0.f;
     }
-    __builtin_amdgcn_wave_barrier();
     if (!all_zero) {
-#pragma unroll 1
+#pragma unroll
         for (int j = N - 1; j >= 0; j--) {
-            const float yj = y[j];
-            if (lane < j) y[lane] -= M[j * LD + lane] * yj;
-            __builtin_amdgcn_wave_barrier();
+            const float yj = readlane_f32(yi, j);
+            if (lane < j) yi -= lcol[j] * yj;
         }
     }
-    if (lane == 0) {
-        for (int k = N - 1; k >= 0; k--) {
-            const int t = transp[k];
-            if (t != k) {
-                const float s = y[k];
-                y[k] = y[t];
-                y[t] = s;
-            }
+    // P^T x
+#pragma unroll
+    for (int k = N - 1; k >= 0; k--) {
+        const int t = __builtin_amdgcn_readfirstlane(tr[k]);
+        if (t != k) {
+            const float yk = readlane_f32(yi, k), yt = readlane_f32(yi, t);
+            yi = (lane == k) ? yt : ((lane == t) ? yk : yi);
         }
     }
+    if (lane < N) y[lane] = yi;
     __builtin_amdgcn_wave_barrier();
 }
 

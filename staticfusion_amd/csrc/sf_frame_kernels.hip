@@ -7,6 +7,9 @@
 #include "sf_cluster.h"
 #include "sf_device_common.h"
 #include "sf_kmeans.h"
+#ifdef SF_CLUSTER
+#include "sf_kmeans_cluster.h"
+#endif
 #include "sf_pyramid.h"
 #include "sf_residuals.h"
 #include "sf_smallmath.h"
@@ -27,6 +30,9 @@
 
 union FrameShared {
     KmShared km;
+#ifdef SF_CLUSTER
+    KmClusterShared kmc;
+#endif
     SolveShared sv;
     ResShared rs;
 };
@@ -54,9 +60,15 @@ __device__ __forceinline__ void run_stages(const KArgs &a, int b, int stage_mask
     if (stage_mask & ST_PYR_OLD) STAGE_TIMED(PF_PYR_OLD, stage_pyramid(a, b, true, tid, cs));
     if (stage_mask & ST_PYR_NEW) STAGE_TIMED(PF_PYR_NEW, stage_pyramid(a, b, false, tid, cs));
     if (stage_mask & ST_KMEANS) {
-        // ordered float sums: one workgroup clusters, the others of a cluster wait for its labels
-        if (writer) STAGE_TIMED(PF_KMEANS, stage_kmeans(a, b, *(LDS KmShared *)&sh.km, tid));
-        cluster_barrier(cs, tid);
+#ifdef SF_CLUSTER
+        if (cl_G(cs) > 1) {
+            STAGE_TIMED(PF_KMEANS, stage_kmeans_cluster(a, b, *(LDS KmClusterShared *)&sh.kmc, cs, tid));
+        } else
+#endif
+        {
+            STAGE_TIMED(PF_KMEANS, stage_kmeans(a, b, *(LDS KmShared *)&sh.km, tid));
+        }
+        cluster_barrier(cs, tid);  // the labels of every level are visible to every workgroup of the cluster
     }
     if (stage_mask & ST_SOLVE) {
         stage_solve(a, b, *(LDS SolveShared *)&sh.sv, cs, tid);

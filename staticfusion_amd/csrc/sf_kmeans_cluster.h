@@ -22,7 +22,7 @@
 #define KMC_MAX_OWN 12         // clusters a workgroup can own: 24 / G with G >= 2
 
 struct KmClShared {
-    float run[3][KMC_CHUNK];  // (z, x, y) of the members of this workgroup's clusters in the chunk: cluster by cluster, pixel order
+    alignas(16) float run[3][KMC_CHUNK];  // (z, x, y) of the members of this workgroup's clusters in the chunk: cluster by cluster, pixel order
     int wcnt[SF_NW][KMC_MAX_OWN];
 };
 struct KmClusterShared {
@@ -298,24 +298,29 @@ __device__ __noinline__ void stage_kmeans_cluster(const KArgs &a, int b, LDS KmC
                 const int r = tid - 3 * sum_c;
                 const LDS float *src = &kc.run[r][sum_o];
                 const int n = sum_n;
-                float v[8], w[8];
                 int j = 0;
-                if (n >= 8) {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) v[e] = src[e];
+                const int head = min(n, (4 - (sum_o & 3)) & 3);  // up to the first 16-byte boundary of the run
+                for (; j < head; j++) acc += src[j];
+                // eight values per trip from two 16-byte LDS reads, the next eight in flight meanwhile: the chain of additions
+                // is what remains (one LDS instruction per four values instead of one per value)
+                typedef LDS const vfloat4 lcf4;
+                vfloat4 v0, v1, w0, w1;
+                if (j + 8 <= n) {
+                    v0 = *(lcf4 *)(src + j);
+                    v1 = *(lcf4 *)(src + j + 4);
                 }
                 for (; j + 16 <= n; j += 8) {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) w[e] = src[j + 8 + e];
+                    w0 = *(lcf4 *)(src + j + 8);
+                    w1 = *(lcf4 *)(src + j + 12);
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int e = 0; e < 8; e++) acc += v[e];
-#pragma unroll
-                    for (int e = 0; e < 8; e++) v[e] = w[e];
+                    acc += v0.x; acc += v0.y; acc += v0.z; acc += v0.w;
+                    acc += v1.x; acc += v1.y; acc += v1.z; acc += v1.w;
+                    v0 = w0;
+                    v1 = w1;
                 }
                 if (j + 8 <= n) {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) acc += v[e];
+                    acc += v0.x; acc += v0.y; acc += v0.z; acc += v0.w;
+                    acc += v1.x; acc += v1.y; acc += v1.z; acc += v1.w;
                     j += 8;
                 }
                 for (; j < n; j++) acc += src[j];

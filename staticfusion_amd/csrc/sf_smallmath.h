@@ -284,6 +284,98 @@ __device__ inline void jacobi_eig6_wave(LDS volatile double *A, LDS volatile dou
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+//  6 x 6 double-precision algebra with ONE MATRIX ELEMENT PER LANE (lane 6 i + j holds element (i, j) in a register,
+//  36 lanes of one wave): a step that touches whole rows / columns is one instruction, partners are fetched with
+//  ds_bpermute, nothing goes through LDS memory.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(src << 2, (int)(b & 0xffffffffll));
+    const int hi = __builtin_amdgcn_ds_bpermute(src << 2, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// Gauss-Jordan inverse with partial pivoting: a = A(i, j) on entry, ai = A^-1(i, j) on exit. Every element sees exactly
+// the operations of inverse_double_lds (the oracle's inverse_double), so the result is bit-identical to it.
+__device__ inline void inverse6_lanes(double &a, double &ai, int lane) {
+    const int l = (lane < 36) ? lane : 0, i = l / 6, j = l - 6 * i;
+    ai = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        int p = c;  // pivot search: uniform, every lane looks at the same column in the same order
+        double pv = fabs(shfl_f64(a, 6 * c + c));
+#pragma unroll
+        for (int r = c + 1; r < 6; r++) {
+            const double v = fabs(shfl_f64(a, 6 * r + c));
+            if (v > pv) {
+                pv = v;
+                p = r;
+            }
+        }
+        const int prow = (i == c) ? p : ((i == p) ? c : i);  // rows c and p change places
+        a = shfl_f64(a, 6 * prow + j);
+        ai = shfl_f64(ai, 6 * prow + j);
+        const double inv = 1.0 / shfl_f64(a, 6 * c + c);
+        if (i == c) {
+            a *= inv;
+            ai *= inv;
+        }
+        const double f = shfl_f64(a, 6 * i + c);  // A(i, c) before this column is eliminated
+        const double pc = shfl_f64(a, 6 * c + j), pic = shfl_f64(ai, 6 * c + j);
+        if (i != c && f != 0.0) {
+            a -= f * pc;
+            ai -= f * pic;
+        }
+    }
+}
+
+// Jacobi eigen-decomposition of a symmetric 6 x 6: a = A(i, j) on entry; on exit the diagonal lanes hold the eigenvalues and
+// v = V(i, j) the eigenvectors (columns). Round-robin ordering: the 15 index pairs of a sweep in 5 rounds of 3 DISJOINT
+// pairs, whose rotations commute and are applied together -- every lane computes the rotation of its column's pair itself
+// (three partners' elements, the formulas of the cyclic algorithm), so a round costs what one rotation cost. The result is
+// an eigen-decomposition to the same accuracy as the cyclic order's (the oracle's), not the same bits: eigenvalues come out
+// in another order, vectors may change sign; the motion filter that consumes them (FrontEnd.cpp:726-760) is invariant to both.
+__device__ inline void jacobi6_lanes(double &a, double &v, int lane) {
+    const int l = (lane < 36) ? lane : 0, i = l / 6, j = l - 6 * i;
+    const bool in = lane < 36;
+    v = (i == j) ? 1.0 : 0.0;
+    // partner of index k in round r (tournament schedule): packed 3 bits per index
+    const unsigned sched[5] = {05 | 04 << 3 | 03 << 6 | 02 << 9 | 01 << 12 | 00 << 15, 04 | 02 << 3 | 01 << 6 | 05 << 9 | 00 << 12 | 03 << 15,
+                               03 | 05 << 3 | 04 << 6 | 00 << 9 | 02 << 12 | 01 << 15, 02 | 03 << 3 | 00 << 6 | 01 << 9 | 05 << 12 | 04 << 15,
+                               01 | 00 << 3 | 05 << 6 | 04 << 9 | 03 << 12 | 02 << 15};
+    for (int sweep = 0; sweep < 60; sweep++) {
+        const double sq = a * a;
+        const double off = wave_sum_f64((in && i < j) ? sq : 0.0), diag = wave_sum_f64((in && i == j) ? sq : 0.0);
+        if (off <= 1e-60 || off <= 1e-34 * diag) break;
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const int jp = (int)((sched[r] >> (3 * j)) & 7u), ip = (int)((sched[r] >> (3 * i)) & 7u);
+            const int p = min(j, jp), q = max(j, jp);  // the pair this lane's COLUMN belongs to
+            const double app = shfl_f64(a, 6 * p + p), aqq = shfl_f64(a, 6 * q + q), apq = shfl_f64(a, 6 * p + q);
+            double c = 1.0, sn = 0.0;
+            const bool rot = apq != 0.0;
+            if (rot) {
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                c = 1.0 / sqrt(t * t + 1.0);
+                sn = t * c;
+            }
+            // columns p, q of every row (A and V)
+            const double ap = shfl_f64(a, 6 * i + jp), vp = shfl_f64(v, 6 * i + jp);
+            if (rot) {
+                a = (j == p) ? (c * a - sn * ap) : (sn * ap + c * a);
+                v = (j == p) ? (c * v - sn * vp) : (sn * vp + c * v);
+            }
+            // rows of the pair this lane's ROW belongs to: its rotation is the one lane `i` (row 0, column i) computed
+            const double ci = shfl_f64(c, i), si = shfl_f64(sn, i);
+            const bool roti = __shfl((int)rot, i, 64) != 0;
+            const double ar = shfl_f64(a, 6 * ip + j);
+            if (roti) a = (i < ip) ? (ci * a - si * ar) : (si * ar + ci * a);
+        }
+    }
+}
+
 __device__ inline void skew_sq_d(const double w[3], double K[9], double K2[9]) {
     K[0] = 0;     K[1] = -w[2]; K[2] = w[1];
     K[3] = w[2];  K[4] = 0;     K[5] = -w[0];

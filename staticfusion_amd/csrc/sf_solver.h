@@ -564,12 +564,20 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
 // one lane would do), everything else runs on lane 0.
 __device__ __noinline__ void solve_filter_and_update(const KArgs &a, LDS SolveShared &s, int level, int lane) {
     // est_cov = AtA.inverse() * res.squaredNorm()
-    LDS double *Ad = s.dwork, *Ai = s.dwork + 36, *V = s.dwork + 72;
-    if (lane < 36) Ad[lane] = (double)s.AtA[lane];
+    LDS double *Ad = s.dwork, *V = s.dwork + 72;
+#ifdef SF_FILTER_PROFILE
+    long long ft = wall_clock64();
+#define FILTER_MARK(slot) do { if (lane == 0) { const long long n_ = wall_clock64(); s.prof[slot] += n_ - ft; ft = n_; } } while (0)
+#else
+#define FILTER_MARK(slot) do {} while (0)
+#endif
+    {
+        double aa = (lane < 36) ? (double)s.AtA[lane] : 0.0, ainv;
+        inverse6_lanes(aa, ainv, lane);
+        if (lane < 36) s.est_cov[lane] = (float)ainv * s.res_sqnorm;
+    }
     __builtin_amdgcn_wave_barrier();
-    inverse_double_wave6(Ad, Ai, lane);
-    if (lane < 36) s.est_cov[lane] = (float)Ai[lane] * s.res_sqnorm;
-    __builtin_amdgcn_wave_barrier();
+    FILTER_MARK(21);
 
     float twist[6];
     for (int i = 0; i < 6; i++) twist[i] = s.Var[i];
@@ -584,12 +592,17 @@ __device__ __noinline__ void solve_filter_and_update(const KArgs &a, LDS SolveSh
             if (lane == 0) s.status |= SF_STATUS_EIG_SKIPPED;
             return;
         }
-        if (lane < 36) {
-            const int i = lane / 6, j = lane - 6 * i;
-            S[lane] = (double)s.est_cov[(i >= j) ? i * 6 + j : j * 6 + i];  // the lower triangle, mirrored
+        {
+            const int l = (lane < 36) ? lane : 0, i = l / 6, j = l - 6 * i;
+            double sa = (double)s.est_cov[(i >= j) ? i * 6 + j : j * 6 + i], vv;  // the lower triangle, mirrored
+            jacobi6_lanes(sa, vv, lane);
+            if (lane < 36) {
+                S[lane] = sa;  // the diagonal holds the eigenvalues
+                V[lane] = vv;
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        jacobi_eig6_wave(S, V, lane);  // S diagonal = eigenvalues
+        FILTER_MARK(22);
         if (lane != 0) return;
         float kai_loc_sub[6], lt[6];
         log_twist_cm(s.T, lt);
@@ -626,6 +639,7 @@ __device__ __noinline__ void solve_filter_and_update(const KArgs &a, LDS SolveSh
     float tw[6];
     log_twist_cm(s.T, tw);
     for (int i = 0; i < 6; i++) s.twist[i] = tw[i];
+    FILTER_MARK(23);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1284,6 +1298,9 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, LDS SolveShared 
         }
         if (tid < 36) st.est_cov[tid] = s.est_cov[tid];
         if (tid >= PF_WARP && tid <= PF_FILTER) st.prof[tid] += s.prof[tid];
+#ifdef SF_FILTER_PROFILE
+        if (tid >= 21 && tid <= 23) st.prof[tid] += s.prof[tid];
+#endif
         if (tid < SF_NC) {
             st.b_segm[tid] = s.b_segm[tid];
             st.b_prior[tid] = s.b_prior[tid];

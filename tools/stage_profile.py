@@ -39,6 +39,11 @@ for k in s.STAGES:
     d = p1[k] - p0[k]
     print("  %-11s %8.1f us/frame  %5.1f %%" % (k, 1e6 * d / frames, 100 * d / tot))
 
+if a.lib and "filterprof" in a.lib:
+    import ctypes
+    t0 = (ctypes.c_int64 * 24)()
+    api.check(api.get_stage_profile(s.h, t0))
+    print("  filter: 6x6 inverse %.1f us, Jacobi %.1f us, rest (log / exp / products on one lane) %.1f us per frame" % tuple(1e-2 * t0[q] / (frames + 5 * a.batch) for q in (21, 22, 23)))
 if a.lib and "kmprof" in a.lib:
     import ctypes
     t = (ctypes.c_int64 * 24)()

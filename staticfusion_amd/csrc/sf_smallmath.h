@@ -27,72 +27,76 @@ __device__ __forceinline__ long long sf_op_max64(long long a, long long b) {  //
     return ((unsigned long long)(a + 1) > (unsigned long long)(b + 1)) ? a : b;     // keys + 1: the identity -1 becomes 0, the smallest
 }
 
+__device__ __forceinline__ float readlane_f32(float x, int l) {  // the builtin is int -> int: a float argument would be CONVERTED
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
+}
+
+// Lane i keeps ROW i of the factor in registers for the whole factorisation -- m[k] = L(row i, elimination step k) -- and
+// the rows never move: the symmetric row / column exchanges of the pivoting are book-keeping (`pos`, the position a row
+// currently has in the permuted order, decides ties exactly like the in-place algorithm: the first maximum wins), the
+// column of the pivot is read from the untouched input matrix, and the factor is stored in its permuted layout at the
+// end. Per step: one DPP maximum, k broadcasts (v_readlane) of the pivot row, 2 k multiply-adds per lane. Every number is
+// produced by the operation sequence of the unblocked left-looking algorithm (acc += L(i,j) (D_j L(k,j)) for ascending j;
+// L(i,k) = (A(i,k) - acc) / D_k), so the factor has the same bits as Eigen's / the oracle's.
 template <int N>
-__device__ inline bool ldlt_factor_wave(LDS volatile float *M, LDS volatile float *temp, LDS volatile int *transp, int lane) {
+__device__ inline bool ldlt_factor_wave(LDS volatile float *Mv, LDS volatile float *temp, LDS volatile int *transp, int lane) {
+    (void)temp;
     constexpr int LD = N + 1;
+    LDS float *M = (LDS float *)Mv;
+    const int row = (lane < N) ? lane : 0;
+    float m[N], dstep[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) m[j] = 0.f;
+    float diag = M[row * LD + row];
+    int pos = lane;
+    bool live = lane < N;
     bool all_zero = false;
-#pragma unroll 1
+#pragma unroll
     for (int k = 0; k < N; k++) {
-        // largest |diagonal| of the trailing block; the first maximum wins. One 64-bit key per lane -- |a| (non-negative
-        // floats order like their bit patterns) above the complemented lane index -- and a max over the DPP network
-        // instead of six rounds of two LDS-crossbar shuffles.
-        const float a = (lane >= k && lane < N) ? fabsf(M[lane * LD + lane]) : 0.f;
+        // largest |diagonal| among the rows not yet eliminated; the first POSITION wins. One 64-bit key per lane -- |a|
+        // (non-negative floats order like their bit patterns) above the complemented position -- and a DPP maximum.
+        const float a = live ? fabsf(diag) : 0.f;
         // a NaN never replaces the running maximum of the scalar algorithm (x > best is false), unless it is the first element
-        const unsigned abits = (a != a) ? ((lane == k) ? 0xffffffffu : 0u) : __float_as_uint(a);
-        long long key = (lane >= k && lane < N) ? (long long)(((unsigned long long)abits << 32) | (unsigned)(63 - lane)) : -1ll;
+        const unsigned abits = (a != a) ? ((pos == k) ? 0xffffffffu : 0u) : __float_as_uint(a);
+        long long key = live ? (long long)(((unsigned long long)abits << 32) | (unsigned)(63 - pos)) : -1ll;
         SF_DPP_REDUCE(key, dpp_i64_keep, sf_op_max64)
-        const int idx = 63 - (int)(__builtin_amdgcn_readlane((int)(key & 0xffffffffll), 63) & 63);
-        const int big = __builtin_amdgcn_readfirstlane(idx);
+        const int big = 63 - (int)(__builtin_amdgcn_readlane((int)(key & 0xffffffffll), 63) & 63);  // position of the pivot
+        const int p = __ffsll((long long)__ballot(live && pos == big)) - 1;                        // ... and its lane
         if (lane == 0) transp[k] = big;
-        if (big != k) {  // symmetric swap on the lower triangle: four disjoint element sets
-            if (lane < k) {
-                const float t = M[k * LD + lane];
-                M[k * LD + lane] = M[big * LD + lane];
-                M[big * LD + lane] = t;
-            }
-            if (lane > big && lane < N) {
-                const float t = M[lane * LD + k];
-                M[lane * LD + k] = M[lane * LD + big];
-                M[lane * LD + big] = t;
-            }
-            if (lane == k) {
-                const float t = M[k * LD + k];
-                M[k * LD + k] = M[big * LD + big];
-                M[big * LD + big] = t;
-            }
-            if (lane > k && lane < big) {
-                const float t = M[lane * LD + k];
-                M[lane * LD + k] = M[big * LD + lane];
-                M[big * LD + lane] = t;
-            }
+        if (live && pos == k) pos = big;  // the row at position k changes places with the pivot row
+        if (lane == p) pos = k;
+        const float x = M[row * LD + p];  // A(row, pivot) of the input matrix (symmetric: both triangles are filled)
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < k; j++) {
+            const float tj = dstep[j] * readlane_f32(m[j], p);  // temp[j] = D_j L(k, j)
+            acc += m[j] * tj;
         }
-        __builtin_amdgcn_wave_barrier();
+        float xm = x;
         if (k > 0) {
-            if (lane < k) temp[lane] = M[lane * LD + lane] * M[k * LD + lane];
-            __builtin_amdgcn_wave_barrier();
-            if (lane >= k && lane < N) {
-                float acc = 0.f;
-                for (int j = 0; j < k; j++) acc += M[lane * LD + j] * temp[j];
-                M[lane * LD + k] -= acc;
-            }
-            __builtin_amdgcn_wave_barrier();
+            xm = x - acc;
+            if (lane == p) diag -= acc;
         }
-        const float akk = M[k * LD + k];
+        const float akk = readlane_f32(diag, p);
+        dstep[k] = akk;
         const bool pivot_valid = fabsf(akk) > 0.f;
         if (k == 0 && !pivot_valid) {
             if (lane < N) transp[lane] = lane;
             all_zero = true;
             break;
         }
-        if (pivot_valid && lane > k && lane < N) M[lane * LD + k] /= akk;
-        __builtin_amdgcn_wave_barrier();
+        m[k] = (live && lane != p) ? (pivot_valid ? xm / akk : xm) : 0.f;
+        if (lane == p) live = false;
+    }
+    __builtin_amdgcn_wave_barrier();  // every read of the input matrix precedes the stores below
+    if (!all_zero && lane < N) {      // the factor in its permuted layout: this row sits at position `pos`
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            if (j < pos) M[pos * LD + j] = m[j];
+        M[pos * LD + pos] = diag;
     }
     __builtin_amdgcn_wave_barrier();
     return all_zero;
-}
-
-__device__ __forceinline__ float readlane_f32(float x, int l) {  // the builtin is int -> int: a float argument would be CONVERTED
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
 }
 
 // Solves with the factors above. y is [N] floats in LDS holding b on entry and x on exit.

@@ -57,8 +57,12 @@ __device__ __forceinline__ void run_stages(const KArgs &a, int b, int stage_mask
 #endif
     const long long t_begin = wall_clock64();
     t0 = t_begin;
-    if (stage_mask & ST_PYR_OLD) STAGE_TIMED(PF_PYR_OLD, stage_pyramid(a, b, true, tid, cs));
-    if (stage_mask & ST_PYR_NEW) STAGE_TIMED(PF_PYR_NEW, stage_pyramid(a, b, false, tid, cs));
+    if ((stage_mask & (ST_PYR_OLD | ST_PYR_NEW)) == (ST_PYR_OLD | ST_PYR_NEW) && cl_G(cs) > 1) {
+        STAGE_TIMED(PF_PYR_NEW, stage_pyramid(a, b, 3, tid, cs));  // a cluster: both pyramids behind one rendezvous per level
+    } else {
+        if (stage_mask & ST_PYR_OLD) STAGE_TIMED(PF_PYR_OLD, stage_pyramid(a, b, 1, tid, cs));
+        if (stage_mask & ST_PYR_NEW) STAGE_TIMED(PF_PYR_NEW, stage_pyramid(a, b, 2, tid, cs));
+    }
     if (stage_mask & ST_KMEANS) {
 #ifdef SF_CLUSTER
         if (cl_G(cs) > 1) {

@@ -20,10 +20,11 @@
 
 #define KMC_CHUNK (4 * SF_NT)  // pixels per collection round: one quad of consecutive pixels per thread
 #define KMC_MAX_OWN 12         // clusters a workgroup can own: 24 / G with G >= 2
+#define KMC_R 5                // chunks loaded and ranked together (the whole level 1 at QVGA: 4800 quads = 4.7 x 1024)
 
 struct KmClShared {
     alignas(16) float run[3][KMC_CHUNK];  // (z, x, y) of the members of this workgroup's clusters in the chunk: cluster by cluster, pixel order
-    int wcnt[SF_NW][KMC_MAX_OWN];
+    int wcnt[KMC_R][SF_NW][KMC_MAX_OWN];
 };
 struct KmClusterShared {
     KmShared km;
@@ -43,6 +44,246 @@ __device__ __forceinline__ void labels_rendezvous(LDS ClusterShared &cs, int tid
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) cs.in[0] = 0;
     cluster_gather(cs, 1, tid);
+}
+
+// One Lloyd iteration's ordered sums of the clusters this workgroup owns (KMeans.cpp:215-221), in pixel order, and the new
+// centres of those clusters -> cs.in[4 q + r] (r < 3: coordinate, 3: member count). Its own function: its own registers.
+__device__ __noinline__ void kmc_collect_and_sum(LDS KmClShared &kc, LDS ClusterShared &cs, gu32w *lab1w_, const __attribute__((address_space(1))) void *depth1q_,
+                                                 const LevelCoord lc1, int nq1, int n_chunks, int G, int rank, int nown, int tid,
+                                                 long long *prof_out) {
+    typedef __attribute__((address_space(1))) const vfloat4 gcf4;
+    gu32w *lab1w = uniform_ptr(lab1w_);
+    gcf4 *depth1q = uniform_ptr((gcf4 *)depth1q_);
+    const int lane = tid & 63, wave = tid >> 6;
+    G = uniform_i(G);
+    rank = uniform_i(rank);
+    nown = uniform_i(nown);
+    nq1 = uniform_i(nq1);
+    n_chunks = uniform_i(n_chunks);
+#ifdef SF_KMC_FINE
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tph = clock64();
+#define PH(i) do { if (tid == 0) { const long long n_ = clock64(); ph[i] += n_ - tph; tph = n_; } } while (0)
+#else
+#define PH(i) do {} while (0)
+#endif
+        // ---- ordered sums of the clusters this workgroup owns (KMeans.cpp:215-221), in pixel order.
+        // KMC_R chunks (a quad of consecutive pixels per thread and chunk) are loaded and ranked together; the members of the
+        // owned clusters are then compacted into LDS and added GROUP by group, a group being as many consecutive chunks as fit
+        // the LDS runs (at QVGA the whole level in one go unless this workgroup's clusters hold more than KMC_CHUNK pixels):
+        // two barriers and one long front-to-back pass per group instead of per chunk.
+        float acc = 0.f;  // thread (q, r) = tid < 3 nown: running sum of coordinate r over the members of cluster rank + q G
+        int total = 0;    // ... and the member count (all three threads of a cluster count)
+        for (int ch0 = 0; ch0 < n_chunks; ch0 += KMC_R) {
+            // per chunk only the quad's label word stays in a register; which pixels are members of an owned cluster is
+            // re-derived from it where needed and the depth of a member is loaded when it is scattered (registers: the
+            // function must not spill)
+            unsigned word[KMC_R];
+#pragma unroll
+            for (int c5 = 0; c5 < KMC_R; c5++) {
+                const int q = (ch0 + c5) * SF_NT + tid;
+                word[c5] = (q < nq1) ? ld_word_agent(lab1w + q) : 0xffffffffu;  // label 255: nobody's
+            }
+            // own index (0 .. nown-1) of pixel k of a quad, or -1. A label < 24 implies a valid depth (invalid pixels carry 24).
+            auto own_index = [&](unsigned w, int k) -> int {
+                const unsigned lb = (w >> (8 * k)) & 255u;
+                return (lb < SF_NC && (int)(lb % (unsigned)G) == rank) ? (int)(lb / (unsigned)G) : -1;
+            };
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            // the wave's member counts per chunk and owned cluster (lane c < nown holds cluster c's)
+#pragma unroll
+            for (int c5 = 0; c5 < KMC_R; c5++) {
+                int cnt_lane = 0;
+                for (int c = 0; c < nown; c++) {
+                    int tot = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) tot += __popcll(__ballot(own_index(word[c5], k) == c));
+                    if (lane == c) cnt_lane = tot;
+                }
+                if (lane < nown) kc.wcnt[c5][wave][lane] = cnt_lane;
+            }
+            PH(0);
+            __syncthreads();  // also: the previous group's sums have consumed kc.run
+            PH(1);
+            // the depths of the quads: issued now, in flight during the offset arithmetic, consumed by the scatter
+            vfloat4 dz4[KMC_R];
+#pragma unroll
+            for (int c5 = 0; c5 < KMC_R; c5++) {
+                const int q = (ch0 + c5) * SF_NT + tid;
+                dz4[c5] = depth1q[(q < nq1) ? q : 0];
+            }
+            // members of cluster c per chunk in earlier waves / in the whole chunk: lane w reads wave w's count, a DPP scan
+            // over the first 16 lanes gives every wave's prefix (one LDS read per (chunk, cluster) instead of one per wave);
+            // the results go back to the layout "lane c holds cluster c's numbers"
+            int before[KMC_R], members[KMC_R], chunk_all[KMC_R];
+#pragma unroll
+            for (int c5 = 0; c5 < KMC_R; c5++) {
+                before[c5] = 0;
+                members[c5] = 0;
+                chunk_all[c5] = 0;
+                for (int c = 0; c < nown; c++) {
+                    const int cnt = (lane < SF_NW) ? kc.wcnt[c5][lane][c] : 0;
+                    int incl = cnt;
+                    incl += dpp_i32<0x111, 0xf>(incl);
+                    incl += dpp_i32<0x112, 0xf>(incl);
+                    incl += dpp_i32<0x114, 0xf>(incl);
+                    incl += dpp_i32<0x118, 0xf>(incl);
+                    static_assert(SF_NW <= 16, "one DPP row of waves");
+                    const int bef = __builtin_amdgcn_readlane(incl - cnt, wave), mem = __builtin_amdgcn_readlane(incl, 15);
+                    if (lane == c) {
+                        before[c5] = bef;
+                        members[c5] = mem;
+                    }
+                    chunk_all[c5] += mem;
+                }
+            }
+            PH(2);
+            // groups of consecutive chunks whose members (all owned clusters together) fit the LDS runs
+            int g0 = 0;
+            while (g0 < KMC_R) {  // uniform: every lane derives the same group bounds from the same counts
+                int g1 = g0, fill = 0;
+#pragma unroll
+                for (int c5 = 0; c5 < KMC_R; c5++) {
+                    if (c5 >= g0 && c5 == g1 && (fill + chunk_all[c5] <= KMC_CHUNK || g1 == g0)) {
+                        fill += chunk_all[c5];
+                        g1 = c5 + 1;
+                    }
+                }
+                // within the group: cluster c's run = its members of chunk g0, then of chunk g0 + 1, ...
+                int grp_members = 0;
+#pragma unroll
+                for (int c5 = 0; c5 < KMC_R; c5++) grp_members += (c5 >= g0 && c5 < g1) ? members[c5] : 0;
+                int incl = grp_members;  // inclusive scan over the owned clusters (nown <= 12: one DPP row)
+                incl += dpp_i32<0x111, 0xf>(incl);
+                incl += dpp_i32<0x112, 0xf>(incl);
+                incl += dpp_i32<0x114, 0xf>(incl);
+                incl += dpp_i32<0x118, 0xf>(incl);
+                const int run_start = incl - grp_members;
+                int earlier = 0;  // members of cluster c in the group's earlier chunks
+#pragma unroll 1
+                for (int c5 = g0; c5 < g1; c5++) {  // a real loop (one copy of the body); the chunk's values are selected
+                    unsigned w5 = word[0];
+                    int bef5 = before[0], mem5 = members[0];
+                    vfloat4 d5 = dz4[0];
+#pragma unroll
+                    for (int e = 1; e < KMC_R; e++) {
+                        w5 = (c5 == e) ? word[e] : w5;
+                        bef5 = (c5 == e) ? before[e] : bef5;
+                        mem5 = (c5 == e) ? members[e] : mem5;
+                        d5 = (c5 == e) ? dz4[e] : d5;
+                    }
+                    const int my_base = run_start + earlier + bef5;  // lane c: where this wave's members of cluster c go
+                    const int q = (ch0 + c5) * SF_NT + tid;
+                    int qk[4], rk[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        qk[k] = own_index(w5, k);
+                        rk[k] = 0;
+                    }
+                    // rank of every member among the wave's members of ITS cluster in pixel order: lower lanes first, then lower k
+                    for (int c = 0; c < nown; c++) {
+                        int lower = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) lower += __popcll(__ballot(qk[k] == c) & lt);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            rk[k] = (qk[k] == c) ? lower : rk[k];
+                            lower += (qk[k] == c) ? 1 : 0;
+                        }
+                    }
+                    if (__any((qk[0] & qk[1] & qk[2] & qk[3]) >= 0)) {  // uniform: this wave holds a member in this chunk
+                        int u, v;
+                        split_uv(lc1, 4 * q, u, v);  // the quad's first pixel; the others follow down the column
+                        const float pz[4] = {d5.x, d5.y, d5.z, d5.w};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int base_k = __builtin_amdgcn_ds_bpermute(max(qk[k], 0) << 2, my_base);
+                            if (qk[k] >= 0) {
+                                const int pos = base_k + rk[k];
+                                kc.run[0][pos] = pz[k];
+                                kc.run[1][pos] = coord_x(lc1, u, pz[k]);
+                                kc.run[2][pos] = coord_y(lc1, v, pz[k]);
+                            }
+                            v++;
+                            if (v == lc1.rows_i) {
+                                v = 0;
+                                u++;
+                            }
+                        }
+                    }
+                    earlier += mem5;
+                }
+                const int sum_c = (tid < 3 * nown) ? tid / 3 : 0;
+                const int sum_n = __builtin_amdgcn_ds_bpermute(sum_c << 2, grp_members);
+                const int sum_o = __builtin_amdgcn_ds_bpermute(sum_c << 2, run_start);
+                PH(3);
+                __syncthreads();
+                PH(4);
+                if (tid < 3 * nown) {  // strictly front to back per sum
+                    const int r = tid - 3 * sum_c;
+                    const LDS float *src = &kc.run[r][sum_o];
+                    const int n = sum_n;
+                    int j = 0;
+                    const int head = min(n, (4 - (sum_o & 3)) & 3);  // up to the first 16-byte boundary of the run
+                    for (; j < head; j++) acc += src[j];
+                    // sixteen values per trip from four 16-byte LDS reads, the next sixteen in flight meanwhile: the chain of
+                    // additions is what remains
+                    typedef LDS const vfloat4 lcf4;
+                    vfloat4 v0, v1, v2, v3, w0, w1, w2, w3;
+#define KMC_LOAD16(a0, a1, a2, a3, at)      \
+    a0 = *(lcf4 *)(src + (at));             \
+    a1 = *(lcf4 *)(src + (at) + 4);         \
+    a2 = *(lcf4 *)(src + (at) + 8);         \
+    a3 = *(lcf4 *)(src + (at) + 12);
+#define KMC_ADD16(a0, a1, a2, a3)                                \
+    acc += a0.x; acc += a0.y; acc += a0.z; acc += a0.w;          \
+    acc += a1.x; acc += a1.y; acc += a1.z; acc += a1.w;          \
+    acc += a2.x; acc += a2.y; acc += a2.z; acc += a2.w;          \
+    acc += a3.x; acc += a3.y; acc += a3.z; acc += a3.w;
+                    // two register sets take turns (no copies): while one is added the other is in flight
+                    if (j + 16 <= n) { KMC_LOAD16(v0, v1, v2, v3, j) }
+                    for (; j + 48 <= n; j += 32) {
+                        KMC_LOAD16(w0, w1, w2, w3, j + 16)
+                        __builtin_amdgcn_sched_barrier(0);
+                        KMC_ADD16(v0, v1, v2, v3)
+                        KMC_LOAD16(v0, v1, v2, v3, j + 32)
+                        __builtin_amdgcn_sched_barrier(0);
+                        KMC_ADD16(w0, w1, w2, w3)
+                    }
+                    if (j + 32 <= n) {
+                        KMC_LOAD16(w0, w1, w2, w3, j + 16)
+                        __builtin_amdgcn_sched_barrier(0);
+                        KMC_ADD16(v0, v1, v2, v3)
+                        KMC_ADD16(w0, w1, w2, w3)
+                        j += 32;
+                    } else if (j + 16 <= n) {
+                        KMC_ADD16(v0, v1, v2, v3)
+                        j += 16;
+                    }
+#undef KMC_LOAD16
+#undef KMC_ADD16
+                    for (; j < n; j++) acc += src[j];
+                    total += n;
+                }
+                PH(5);
+                g0 = g1;
+                if (g0 < KMC_R) __syncthreads();  // the next group's scatter may overwrite the runs
+            }
+        }
+        // ---- the owned centres -> cs.in (KMeans.cpp:219-226)
+        if (tid < 4 * KMC_MAX_OWN) cs.in[tid] = 0u;
+        __syncthreads();
+        if (tid < 3 * nown) {
+            const int c = tid / 3, r = tid - 3 * c;
+            if (total > 0) acc /= float(total);
+            cs.in[4 * c + r] = __float_as_uint(acc);
+            if (r == 0) cs.in[4 * c + 3] = (unsigned)total;
+        }
+    PH(6);
+#ifdef SF_KMC_FINE
+    if (tid == 0 && prof_out)
+        for (int i = 0; i < 7; i++) prof_out[i] += ph[i];
+#endif
+#undef PH
 }
 
 __device__ __noinline__ void stage_kmeans_cluster(const KArgs &a, int b, LDS KmClusterShared &sh, LDS ClusterShared &cs, int tid) {
@@ -218,124 +459,8 @@ __device__ __noinline__ void stage_kmeans_cluster(const KArgs &a, int b, LDS KmC
         }
         labels_rendezvous(cs, tid);
         KMC_MARK(PF_KM_ASSIGN);
-        // ---- ordered sums of the clusters this workgroup owns (KMeans.cpp:215-221), chunk by chunk in pixel order
-        float acc = 0.f;  // thread (q, r) = tid < 3 nown: running sum of coordinate r over the members of cluster rank + q G
-        int total = 0;    // ... and the member count (all three threads of a cluster count)
-        for (int ch = 0; ch < n_chunks; ch++) {
-            const int q = ch * SF_NT + tid;
-            const bool in = q < nq1;
-            const int qq = in ? q : 0;
-            const unsigned word = ld_word_agent(lab1w + qq);
-            const vfloat4 dz4 = depth1q[qq];
-            const float pz[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
-            int qi[4];
-            bool mine[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const unsigned lb = (word >> (8 * k)) & 255u;
-                mine[k] = in && pz[k] != 0.f && lb < SF_NC && (int)(lb % (unsigned)G) == rank;
-                qi[k] = mine[k] ? (int)(lb / (unsigned)G) : -1;
-            }
-            // rank of every member among the members of its cluster in this wave, in pixel order (lane-major, then k), and the
-            // wave's member counts per owned cluster (lane c < nown holds cluster c's)
-            int rnk[4] = {0, 0, 0, 0};
-            int cnt_lane = 0;
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            for (int c = 0; c < nown; c++) {
-                unsigned long long m[4];
-                int lower = 0, tot = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    m[k] = __ballot(qi[k] == c);
-                    lower += __popcll(m[k] & lt);
-                    tot += __popcll(m[k]);
-                }
-                int within = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (qi[k] == c) rnk[k] = lower + within;
-                    within += (qi[k] == c) ? 1 : 0;
-                }
-                if (lane == c) cnt_lane = tot;
-            }
-            if (lane < nown) kc.wcnt[wave][lane] = cnt_lane;
-            __syncthreads();  // also: the previous chunk's sums have consumed kc.run
-            int before = 0, members = 0;
-            if (lane < nown) {
-                int cw[SF_NW];
-#pragma unroll
-                for (int w = 0; w < SF_NW; w++) cw[w] = kc.wcnt[w][lane];
-#pragma unroll
-                for (int w = 0; w < SF_NW; w++) {
-                    before += (w < wave) ? cw[w] : 0;
-                    members += cw[w];
-                }
-            }
-            int incl = members;  // lanes >= nown hold 0: inclusive scan over the owned clusters (nown <= 12: one DPP row)
-            incl += dpp_i32<0x111, 0xf>(incl);
-            incl += dpp_i32<0x112, 0xf>(incl);
-            incl += dpp_i32<0x114, 0xf>(incl);
-            incl += dpp_i32<0x118, 0xf>(incl);
-            const int run_start = incl - members;
-            const int my_base = run_start + before;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int base_k = __builtin_amdgcn_ds_bpermute(max(qi[k], 0) << 2, my_base);
-                if (mine[k]) {
-                    int u, v;
-                    split_uv(lc1, 4 * qq + k, u, v);
-                    const int pos = base_k + rnk[k];
-                    kc.run[0][pos] = pz[k];
-                    kc.run[1][pos] = coord_x(lc1, u, pz[k]);
-                    kc.run[2][pos] = coord_y(lc1, v, pz[k]);
-                }
-            }
-            const int sum_c = (tid < 3 * nown) ? tid / 3 : 0;
-            const int sum_n = __builtin_amdgcn_ds_bpermute(sum_c << 2, members);
-            const int sum_o = __builtin_amdgcn_ds_bpermute(sum_c << 2, run_start);
-            __syncthreads();
-            if (tid < 3 * nown) {  // strictly front to back per sum; the next eight values are in flight while eight are added
-                const int r = tid - 3 * sum_c;
-                const LDS float *src = &kc.run[r][sum_o];
-                const int n = sum_n;
-                int j = 0;
-                const int head = min(n, (4 - (sum_o & 3)) & 3);  // up to the first 16-byte boundary of the run
-                for (; j < head; j++) acc += src[j];
-                // eight values per trip from two 16-byte LDS reads, the next eight in flight meanwhile: the chain of additions
-                // is what remains (one LDS instruction per four values instead of one per value)
-                typedef LDS const vfloat4 lcf4;
-                vfloat4 v0, v1, w0, w1;
-                if (j + 8 <= n) {
-                    v0 = *(lcf4 *)(src + j);
-                    v1 = *(lcf4 *)(src + j + 4);
-                }
-                for (; j + 16 <= n; j += 8) {
-                    w0 = *(lcf4 *)(src + j + 8);
-                    w1 = *(lcf4 *)(src + j + 12);
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc += v0.x; acc += v0.y; acc += v0.z; acc += v0.w;
-                    acc += v1.x; acc += v1.y; acc += v1.z; acc += v1.w;
-                    v0 = w0;
-                    v1 = w1;
-                }
-                if (j + 8 <= n) {
-                    acc += v0.x; acc += v0.y; acc += v0.z; acc += v0.w;
-                    acc += v1.x; acc += v1.y; acc += v1.z; acc += v1.w;
-                    j += 8;
-                }
-                for (; j < n; j++) acc += src[j];
-                total += n;
-            }
-        }
-        // ---- the owned centres -> everybody (KMeans.cpp:219-226)
-        if (tid < 4 * KMC_MAX_OWN) cs.in[tid] = 0u;
-        __syncthreads();
-        if (tid < 3 * nown) {
-            const int c = tid / 3, r = tid - 3 * c;
-            if (total > 0) acc /= float(total);
-            cs.in[4 * c + r] = __float_as_uint(acc);
-            if (r == 0) cs.in[4 * c + 3] = (unsigned)total;
-        }
+        // ---- ordered sums of the clusters this workgroup owns (KMeans.cpp:215-221) -> cs.in
+        kmc_collect_and_sum(kc, cs, lab1w, depth1q, lc1, nq1, n_chunks, G, rank, nown, tid, writer ? &st.prof[16] : nullptr);
         cluster_gather(cs, 4 * KMC_MAX_OWN, tid);
         if (tid < 3 * SF_NC) {
             const int c = tid / 3, r = tid - 3 * c;

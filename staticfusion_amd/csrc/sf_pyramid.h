@@ -15,18 +15,22 @@ __device__ __forceinline__ float conv_mask(int k) {
     return vi * vj / 36.f;
 }
 
-__device__ __noinline__ void stage_pyramid(const KArgs &a, int b, bool old_im, int tid, LDS ClusterShared &cs) {
+// which: bit 0 = the Pred pyramid (createImagePyramid(true)), bit 1 = the new one (createImagePyramid(false)); both bits: the
+// two pyramids level by level together, one barrier per level for both (what a cluster pays a rendezvous for)
+__device__ __noinline__ void stage_pyramid(const KArgs &a, int b, int which, int tid, LDS ClusterShared &cs) {
     const int G = cl_G(cs), rank = cl_rank(cs);  // a cluster's workgroups take every G-th block of SF_NT pixels of a level
-    float *const *set = old_im ? a.pyr_pred : a.pyr_new;
-    const auto depth = as_global(set[0] + (size_t)b * a.n_tot);
-    const auto inten = as_global(set[1] + (size_t)b * a.n_tot);
     const float max_depth_dif = 0.1f;
 
     for (int L = 0; L < a.levels; L++) {
         const int rows_i = a.lrows[L], cols_i = a.lcols[L], n = a.ln[L];
-        const auto d_here = depth + a.loff[L], i_here = inten + a.loff[L];
-        if (L > 0) {
-            cluster_barrier(cs, tid);  // level L-1 complete (written by this workgroup / by the cluster's workgroups)
+        if (L > 0) cluster_barrier(cs, tid);  // level L-1 complete (written by this workgroup / by the cluster's workgroups)
+        for (int si = 0; si < 2; si++) {
+            if (L == 0 || !((which >> si) & 1)) continue;
+            float *const *set = (si == 0) ? a.pyr_pred : a.pyr_new;
+            const auto depth = as_global(set[0] + (size_t)b * a.n_tot);
+            const auto inten = as_global(set[1] + (size_t)b * a.n_tot);
+            const auto d_here = depth + a.loff[L], i_here = inten + a.loff[L];
+            {
             const auto d_prev = depth + a.loff[L - 1], i_prev = inten + a.loff[L - 1];
             const int rows_p = a.lrows[L - 1];
             for (int idx = tid + rank * SF_NT; idx < n; idx += SF_NT * G) {
@@ -97,6 +101,7 @@ __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, bool old_im, i
                 }
                 d_here[idx] = dout;
                 i_here[idx] = iout;  // xx / yy (:385-386) are recomputed by their consumers: level_coord()
+            }
             }
         }  // level 0 is the input itself
     }

@@ -170,6 +170,20 @@ __device__ __forceinline__ void cluster_barrier(LDS ClusterShared &cs, int tid) 
     __syncthreads();
 }
 
+// Rendezvous without fences: everything this workgroup wrote with agent-scope (sc1, write-through) stores or atomics has
+// left, and every workgroup of the cluster has got here. What was written THAT way may then be read by the others with
+// agent-scope loads (they bypass the reader's L1) -- the cheap hand-over for data both sides access with sc1 anyway
+// (warp accumulators: atomics + atomic loads; the K-means label words). Plain stores / plain loads need cluster_barrier.
+__device__ __forceinline__ void cluster_rendezvous(LDS ClusterShared &cs, int tid) {
+    if (cl_G(cs) == 1) {
+        __syncthreads();
+        return;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) cs.in[0] = 0;
+    cluster_gather(cs, 1, tid);
+}
+
 // helpers to move doubles / 64-bit integers through the 32-bit payload words
 __device__ __forceinline__ void put_f64(LDS unsigned *w, double v) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);

@@ -40,11 +40,7 @@ __device__ __forceinline__ unsigned ld_byte_agent(gcu8b *p) {
 }
 
 // the label words this workgroup wrote have left; everybody has written theirs
-__device__ __forceinline__ void labels_rendezvous(LDS ClusterShared &cs, int tid) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0) cs.in[0] = 0;
-    cluster_gather(cs, 1, tid);
-}
+__device__ __forceinline__ void labels_rendezvous(LDS ClusterShared &cs, int tid) { cluster_rendezvous(cs, tid); }
 
 // One Lloyd iteration's ordered sums of the clusters this workgroup owns (KMeans.cpp:215-221), in pixel order, and the new
 // centres of those clusters -> cs.in[4 q + r] (r < 3: coordinate, 3: member count). Its own function: its own registers.

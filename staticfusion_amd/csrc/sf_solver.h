@@ -216,11 +216,18 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
     const auto acc_i = as_global(a.acc_i + rb);
 
     if (tid == 0) inverse4_cm(s.T, s.Tinv, s.dwork);  // T = T_odometry.inverse()  (:800)
-    for (int idx = tid + rank * SF_NT; idx < n; idx += SF_NT * G) {  // a cluster's workgroups zero every G-th block
-        acc_d[idx] = 0;
-        acc_i[idx] = 0;
+    // a cluster's workgroups zero every G-th block. Agent-scope (write-through) stores: the cells are only ever touched by
+    // agent-scope atomics and atomic loads after this, so the two hand-overs below need no fence (sf_cluster.h)
+    for (int idx = tid + rank * SF_NT; idx < n; idx += SF_NT * G) {
+        if (G > 1) {
+            __hip_atomic_store(acc_d + idx, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(acc_i + idx, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {  // one workgroup: plain stores keep the lines in L2 for the atomics that follow
+            acc_d[idx] = 0;
+            acc_i[idx] = 0;
+        }
     }
-    cluster_barrier(cs, tid);  // the accumulators are zero everywhere before anybody splats into them
+    cluster_rendezvous(cs, tid);  // the accumulators are zero everywhere before anybody splats into them
 
     SplatGeom g;
     g.f = float(cols_i) / (2.f * a.tan_half_fovh);
@@ -246,7 +253,7 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
         }
     } src{dpred, ipred, level_coord(a, L)};
     tiled_splat(g, rows_i, cols_i, src, acc_d, acc_i, s.win, tid, rank, G);
-    cluster_barrier(cs, tid);  // all atomics of the workgroup(s) performed at L2 / visible to the cluster
+    cluster_rendezvous(cs, tid);  // all atomics of the workgroup(s) performed: the linearisation reads the cells with atomic loads
 }
 
 // ---------------------------------------------------------------------------------------------

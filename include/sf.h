@@ -290,6 +290,11 @@ int SF_FN(init_model_from_frame)(sf_handle *h, int stream, const float pose[16],
  * exactly this about the previous frame's getPredictedImages: it re-renders the HIGH-confidence target but reads the
  * low-confidence one. *dense = 0 before the first prediction. */
 int SF_FN(get_prediction_dense)(sf_handle *h, int *dense);
+/* The same per stream: *dense = Reconstruction::denseEnough of the last prediction rendered INTO `stream` (a batched
+ * sf_map_predict_frames serves many sequences: each one's kb switch, StaticFusion-imagesequenceassoc.cpp:157-163, needs its
+ * own flag); 0 for a stream the handle's LAST prediction call did not render into (the flags of a call are kept until
+ * the next one). sf_get_prediction_dense reports the first job of the last call. */
+int SF_FN(get_prediction_dense_stream)(sf_handle *h, int stream, int *dense);
 /* depthPrediction / intensityPrediction (column-major float, rows*cols each; either may be NULL). */
 int SF_FN(get_prediction)(sf_handle *h, int stream, float *depth, float *intensity);
 

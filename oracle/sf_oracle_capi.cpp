@@ -28,6 +28,8 @@ struct sf_handle {
     float depth_cutoff = 4.5f;  // FrontEnd.cpp:168
     bool have_frame = false;
     bool pred_dense = false;
+    std::vector<char> pred_dense_stream;  // per stream: denseEnough of the prediction the last call rendered into it
+    bool in_predict_batch = false;
     std::vector<std::vector<uint16_t>> depth_mm, filtered_mm;
     std::vector<std::vector<float>> depth_metric;
     std::vector<std::vector<uint8_t>> color;
@@ -597,6 +599,9 @@ int sfo_predict_from_model(sf_handle *h, int stream, const float *surfels, int c
     auto &s = *h->s[stream];
     h->pred_dense = sfo::predict_from_model(surfels, count, t_inv, mp, h->rows, h->cols, h->filtered_mm[stream].data(), h->color[stream].data(),
                             s.b_segm_perpixel.d.data(), s.depthPrediction.d.data(), s.intensityPrediction.d.data());
+    if (!h->in_predict_batch) h->pred_dense_stream.assign(size_t(h->batch), 0);  // the flags of a call are kept until the next one
+    h->pred_dense_stream.resize(size_t(h->batch), 0);
+    h->pred_dense_stream[size_t(stream)] = h->pred_dense ? 1 : 0;
     return SF_OK;
 }
 int sfo_predict_from_model_device(sf_handle *h, int stream, const void *s, int count, const float pose[16], const sf_model_params *p) {
@@ -615,6 +620,12 @@ int sfo_init_model_from_frame(sf_handle *h, int stream, const float pose[16], co
 int sfo_get_prediction_dense(sf_handle *h, int *dense) {
     if (!h || !dense) return fail(SF_ERR_ARG, "null");
     *dense = h->pred_dense ? 1 : 0;
+    return SF_OK;
+}
+int sfo_get_prediction_dense_stream(sf_handle *h, int stream, int *dense) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!dense) return fail(SF_ERR_ARG, "null");
+    *dense = (size_t(stream) < h->pred_dense_stream.size() && h->pred_dense_stream[size_t(stream)]) ? 1 : 0;
     return SF_OK;
 }
 int sfo_get_prediction(sf_handle *h, int stream, float *depth, float *intensity) {
@@ -681,9 +692,17 @@ int sfo_map_predict_frames(sf_handle *h, int n, const int *streams, sf_map *cons
     for (int q = 0; q < n; q++)
         for (int r = 0; r < q; r++)
             if (streams[r] == streams[q]) return fail(SF_ERR_ARG, "the same stream twice in one batch (its prediction would be written twice)");
-    for (int q = 0; q < n; q++)
-        if (int e = sfo_map_predict(h, streams[q], maps[q], p)) return e;
-    return SF_OK;
+    h->pred_dense_stream.assign(size_t(h->batch), 0);
+    h->in_predict_batch = true;
+    int err = SF_OK;
+    bool first_dense = false;
+    for (int q = 0; q < n && !err; q++) {
+        err = sfo_map_predict(h, streams[q], maps[q], p);
+        if (q == 0) first_dense = h->pred_dense;
+    }
+    if (n > 0) h->pred_dense = first_dense;  // sf_get_prediction_dense: the first job of the last call (as the MI355X library)
+    h->in_predict_batch = false;
+    return err;
 }
 int sfo_map_info(sf_map *m, int *count, int *tick, float pose[16], int stats[4]) {
     if (!m) return fail(SF_ERR_ARG, "null");

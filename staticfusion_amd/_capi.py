@@ -129,6 +129,7 @@ SIGNATURES = {
     "init_model_from_frame": (C.c_int, [_H, C.c_int, _fp, C.POINTER(SfModelParams), C.c_int, _fp, _ip]),
     "get_prediction": (C.c_int, [_H, C.c_int, _fp, _fp]),
     "get_prediction_dense": (C.c_int, [_H, _ip]),
+    "get_prediction_dense_stream": (C.c_int, [_H, C.c_int, _ip]),
     "map_create": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p)]),
     "map_destroy": (None, [C.c_void_p]),
     "map_fuse_frame": (C.c_int, [_H, C.c_int, C.c_void_p, _fp, C.c_float, C.POINTER(SfModelParams)]),
@@ -328,6 +329,11 @@ class Solver:
         """Reconstruction::denseEnough of the last prediction (what checkIfDenseEnough reports one frame later)"""
         d = C.c_int32()
         self.api.check(self.api.get_prediction_dense(self.h, C.byref(d)))
+        return bool(d.value)
+
+    def prediction_dense_stream(self, stream):
+        d = C.c_int32()
+        self.api.check(self.api.get_prediction_dense_stream(self.h, stream, C.byref(d)))
         return bool(d.value)
 
     def prediction(self, stream=0):

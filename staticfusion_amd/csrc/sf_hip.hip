@@ -76,6 +76,7 @@ struct sf_handle {
     int device = 0;
     int max_blocks = 0;
     const FrameVariant *fv = &VARIANTS[0];
+    std::vector<struct sf_map *> maps;  // live maps created from this handle: sf_destroy releases their memory and orphans them
     int cluster_grid = 0;  // SF_VARIANT_CLUSTER: blocks per launch (8 XCDs x streams per XCD x workgroups per stream)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -98,10 +99,11 @@ struct sf_handle {
     int *pr_dense = nullptr;                // per batched map: 2 ints (density sum; init-model counts)
     size_t pr_maps = 0;                     // how many maps the two blocks above are sized for
     bool pr_rendered = false;
+    std::vector<int> pr_job_of_stream;      // per stream: index of the job of the last predict batch that rendered into it, or -1
     vfloat4 *pr_rays = nullptr;             // view ray per pixel for the intrinsics below (sf_predict_rays_kernel)
     float pr_rays_for[4] = {0.f, 0.f, 0.f, 0.f};
     float *pr_surfels = nullptr;
-    size_t pr_capacity = 0;
+    size_t pr_floats = 0;                   // capacity of pr_surfels in floats (12 per surfel)
     // argument tables of the batched map kernels (sf_predict.h, sf_fusion.h): device block + the host copy it is filled from
     void *tab_dev = nullptr;
     size_t tab_bytes = 0;
@@ -147,6 +149,38 @@ static int dev_alloc(sf_handle *h, T **p, size_t count) {
     return SF_OK;
 }
 
+// Grow a device block of the handle to at least `count` elements: geometric growth (a map that gains a few surfels every
+// frame must not allocate every frame) and the old block is released -- after the stream has drained, nothing queued still
+// reads it -- instead of living on until sf_destroy.
+template <class T>
+static int dev_grow(sf_handle *h, T **p, size_t *capacity, size_t count) {
+    if (*capacity >= count) return SF_OK;
+    const size_t want = std::max(count, *capacity + *capacity / 2 + 1024);
+    T *old = *p;
+    T *fresh = nullptr;
+    if (int e = dev_alloc(h, &fresh, want)) return e;
+    if (old) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (auto it = h->allocs.begin(); it != h->allocs.end(); ++it)
+            if (*it == (void *)old) {
+                h->allocs.erase(it);
+                break;
+            }
+        HIP_TRY(hipFree(old));
+    }
+    *p = fresh;
+    *capacity = want;
+    return SF_OK;
+}
+
+// Cluster launches need every one of their workgroups resident at once (sf_cluster.h): two of them must not share the
+// GPU. All cluster launches of the process on one device are therefore chained through an event -- a launch waits (on the
+// device) for the previous cluster launch of ANY handle. Kernels of other kinds on other streams are the caller's business:
+// if they keep workgroups of a cluster launch from being scheduled, the frame reports SF_STATUS_SYNC_TIMEOUT.
+#include <mutex>
+static std::mutex g_cluster_mu;
+static hipEvent_t g_cluster_done[64] = {};
+
 static int launch(sf_handle *h, int mask, int im_count) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemsetAsync(h->k.queue, 0, sizeof(int), h->stream));
@@ -158,8 +192,18 @@ static int launch(sf_handle *h, int mask, int im_count) {
     const int grid = h->cluster_grid ? h->cluster_grid : std::min(h->k.batch, h->max_blocks);
     const bool timed = (mask & ST_SOLVE) != 0;
     if (timed) HIP_TRY(hipEventRecord(h->evk0, h->stream));
-    h->fv->launch_frame(grid, h->stream, (const KArgs *)h->d_args, mask, im_count);
-    HIP_TRY(hipGetLastError());
+    if (h->cluster_grid && h->device < 64) {
+        std::lock_guard<std::mutex> lock(g_cluster_mu);
+        hipEvent_t &ev = g_cluster_done[h->device];
+        if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        else HIP_TRY(hipStreamWaitEvent(h->stream, ev, 0));
+        h->fv->launch_frame(grid, h->stream, (const KArgs *)h->d_args, mask, im_count);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev, h->stream));
+    } else {
+        h->fv->launch_frame(grid, h->stream, (const KArgs *)h->d_args, mask, im_count);
+        HIP_TRY(hipGetLastError());
+    }
     if (timed) {
         HIP_TRY(hipEventRecord(h->evk1, h->stream));
         h->solver_timed = true;
@@ -224,10 +268,12 @@ static int validate_params(const sf_params *p, int levels) {
     return SF_OK;
 }
 
+static void orphan_maps(sf_handle *h);  // defined with struct sf_map below
 void sf_destroy(sf_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    orphan_maps(h);  // maps outliving their handle: their memory is freed now, every later call on them fails cleanly
     for (void *p : h->allocs) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -318,13 +364,14 @@ int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, 
     HIP_OR_FREE(hipGetDeviceProperties(&prop, device));
     // Few streams: one 1024-thread workgroup per stream and CU gives each stream four times the lanes (1.6-1.8x
     // lower latency, and higher throughput up to ~2 streams per CU); many streams: four 256-thread workgroups per CU.
-    // sf_create_ex names the build explicitly; for SF_VARIANT_AUTO the environment variable SF_VARIANT=throughput|latency
+    // sf_create_ex names the build explicitly; for SF_VARIANT_AUTO the environment variable SF_VARIANT=throughput|latency|cluster
     // may still override the choice by batch size (A/B tooling).
     h->fv = &VARIANTS[(batch <= 2 * prop.multiProcessorCount) ? 1 : 0];
     if (variant == SF_VARIANT_AUTO) {
         if (const char *v = std::getenv("SF_VARIANT")) {
             if (!std::strcmp(v, "throughput")) h->fv = &VARIANTS[0];
             if (!std::strcmp(v, "latency")) h->fv = &VARIANTS[1];
+            if (!std::strcmp(v, "cluster")) h->fv = &VARIANTS[2];
         }
     } else {
         h->fv = &VARIANTS[variant == SF_VARIANT_THROUGHPUT ? 0 : (variant == SF_VARIANT_LATENCY ? 1 : 2)];
@@ -444,6 +491,7 @@ int sf_set_kb(sf_handle *h, int stream, float kb) {
 }
 int sf_set_hip_stream(sf_handle *h, void *hip_stream) {
     if (!h) return fail(SF_ERR_ARG, "null");
+    HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return SF_OK;
@@ -1057,6 +1105,9 @@ static int predict_batch(sf_handle *h, const std::vector<PredictJob> &jobs, cons
     hipLaunchKernelGGL(sf_predict_resolve_kernel, dim3(pix_blocks, nm), dim3(256), 0, h->stream, d_tab);
     HIP_TRY(hipGetLastError());
     h->pr_rendered = true;
+    // the density sums of this batch live in pr_dense[2 q] until the next prediction call: which job served which stream
+    h->pr_job_of_stream.assign((size_t)h->k.batch, -1);
+    for (size_t q = 0; q < jobs.size(); q++) h->pr_job_of_stream[(size_t)jobs[q].stream] = (int)q;
     return SF_OK;
 }
 static int predict_launch(sf_handle *h, int stream, const float *d_surfels, int count, const float pose[16], const sf_model_params *p) {
@@ -1067,10 +1118,7 @@ int sf_predict_from_model(sf_handle *h, int stream, const float *surfels, int co
     if ((!surfels && count > 0) || count < 0 || !pose || !p) return fail(SF_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     if (int e = input_alloc(h)) return e;
-    if (h->pr_capacity < (size_t)count) {
-        if (int e = dev_alloc(h, &h->pr_surfels, (size_t)count * 12)) return e;  // grows; the old block is freed with the handle
-        h->pr_capacity = count;
-    }
+    if (int e = dev_grow(h, &h->pr_surfels, &h->pr_floats, (size_t)count * 12)) return e;
     if (count) HIP_TRY(hipMemcpyAsync(h->pr_surfels, surfels, (size_t)count * 12 * sizeof(float), hipMemcpyHostToDevice, h->stream));
     if (int e = predict_launch(h, stream, h->pr_surfels, count, pose, p)) return e;
     HIP_TRY(hipStreamSynchronize(h->stream));  // the host surfel buffer is free again; the staging block may be reused
@@ -1106,10 +1154,7 @@ int sf_init_model_from_frame(sf_handle *h, int stream, const float pose[16], con
     if (!h->have_frame) return fail(SF_ERR_STATE, "sf_init_model_from_frame needs a loaded frame (sf_load_frame + sf_filter_depth)");
     HIP_TRY(hipSetDevice(h->device));
     const size_t n = h->k.n0;
-    if (h->pr_capacity < n) {
-        if (int e = dev_alloc(h, &h->pr_surfels, n * 12)) return e;
-        h->pr_capacity = n;
-    }
+    if (int e = dev_grow(h, &h->pr_surfels, &h->pr_floats, n * 12)) return e;
     if (int e = results_scratch(h, 1)) return e;
     InitModelArgs a;
     a.depth_metric = h->in_depth_metric + (size_t)stream * n;
@@ -1134,6 +1179,19 @@ int sf_get_prediction_dense(sf_handle *h, int *dense) {
     if (!h->pr_rendered) return SF_OK;  // nothing rendered yet
     int sum = 0;
     if (int e = d2h(h, &sum, h->pr_dense, sizeof sum)) return e;
+    const int rw = h->k.cols / 40, rh = h->k.rows / 40;
+    *dense = (rw * rh > 0) && (float(sum) / float(rh * rw) > 0.25f);
+    return SF_OK;
+}
+int sf_get_prediction_dense_stream(sf_handle *h, int stream, int *dense) {
+    if (int e = check_stream(h, stream)) return e;
+    if (!dense) return fail(SF_ERR_ARG, "null");
+    *dense = 0;
+    if (!h->pr_rendered || h->pr_job_of_stream.empty()) return SF_OK;
+    const int q = h->pr_job_of_stream[(size_t)stream];
+    if (q < 0) return SF_OK;  // not part of the last prediction call
+    int sum = 0;
+    if (int e = d2h(h, &sum, h->pr_dense + (size_t)q * 2, sizeof sum)) return e;
     const int rw = h->k.cols / 40, rh = h->k.rows / 40;
     *dense = (rw * rh > 0) && (float(sum) / float(rh * rw) > 0.25f);
     return SF_OK;
@@ -1200,12 +1258,33 @@ int sf_map_create(sf_handle *h, int capacity, sf_map **out) {
         sf_map_destroy(m);
         return e;
     }
+    h->maps.push_back(m);
     *out = m;
     return SF_OK;
 }
+static void map_release(sf_map *m) {  // device memory of a map (its handle's device is current, its stream drained)
+    for (void *q : m->allocs) (void)hipFree(q);
+    m->allocs.clear();
+}
+static void orphan_maps(sf_handle *h) {
+    for (sf_map *m : h->maps) {
+        map_release(m);
+        m->h = nullptr;
+    }
+    h->maps.clear();
+}
 void sf_map_destroy(sf_map *m) {
     if (!m) return;
-    for (void *q : m->allocs) (void)hipFree(q);
+    if (sf_handle *h = m->h) {  // the handle is alive: its device, after its queued work
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+        for (auto it = h->maps.begin(); it != h->maps.end(); ++it)
+            if (*it == m) {
+                h->maps.erase(it);
+                break;
+            }
+        map_release(m);
+    }  // else: sf_destroy of the handle already released the memory and left the map as an empty shell
     delete m;
 }
 static void pose_compose(const float *a, const float *b, float *out) {  // Eigen::Matrix4f product, column-major
@@ -1237,6 +1316,10 @@ int sf_map_fuse_frames(sf_handle *h, int n, const int *streams, sf_map *const *m
     std::vector<InitModelArgs> init;
     std::vector<FuseArgs> fuse;
     std::vector<int> init_of, fuse_of;  // batch index of each table entry
+    // the maps' new poses / epochs are held here and committed together with count and tick only after the results have
+    // been read back: a failed upload, launch or copy leaves every map as it was (a retry must not compose in_pose twice)
+    std::vector<float> new_pose((size_t)n * 16);
+    std::vector<int> new_epoch((size_t)n);
     int max_count = 0, max_cand = 0, max_elems = 0;
     for (int q = 0; q < n; q++) {
         sf_map *m = maps[q];
@@ -1246,12 +1329,15 @@ int sf_map_fuse_frames(sf_handle *h, int n, const int *streams, sf_map *const *m
         const float *depth_filtered = h->k.pyr_new[0] + (size_t)stream * h->k.n_tot;
         const uint8_t *color = h->in_color + (size_t)stream * npx * 3;
         const float *b_img = h->k.b_img + (size_t)stream * npx;
+        float *pose_q = new_pose.data() + (size_t)q * 16;
+        std::memcpy(pose_q, m->pose, sizeof m->pose);
+        new_epoch[q] = m->epoch;
         if (m->tick == 1) {  // Reconstruction.cpp:255-262
-            if (in_pose) pose_compose(m->pose, in_pose, m->pose);
+            if (in_pose) pose_compose(m->pose, in_pose, pose_q);
             InitModelArgs a;
             a.depth_metric = depth_metric; a.depth_filtered = depth_filtered; a.color = color; a.b_img = b_img;
             a.rows = h->k.rows; a.cols = h->k.cols; a.time = m->tick;
-            for (int k = 0; k < 16; k++) a.pose[k] = m->pose[k];
+            for (int k = 0; k < 16; k++) a.pose[k] = pose_q[k];
             a.cx = p->cx; a.cy = p->cy; a.fx = p->fx; a.fy = p->fy; a.max_depth = p->max_depth;
             a.out = m->buf[0];
             a.count = h->res_dev + (size_t)q * 8;
@@ -1261,27 +1347,27 @@ int sf_map_fuse_frames(sf_handle *h, int n, const int *streams, sf_map *const *m
         }
         float last_pose[16];
         std::memcpy(last_pose, m->pose, sizeof last_pose);
-        pose_compose(m->pose, in_pose, m->pose);                                        // :268
+        pose_compose(m->pose, in_pose, pose_q);                                         // :268
         FuseArgs a;
         a.depth_metric = depth_metric; a.depth_filtered = depth_filtered; a.color = color; a.b_img = b_img;
         a.rows = h->k.rows; a.cols = h->k.cols;
-        for (int k = 0; k < 16; k++) a.pose[k] = m->pose[k];
-        invert_pose(m->pose, a.t_inv);
+        for (int k = 0; k < 16; k++) a.pose[k] = pose_q[k];
+        invert_pose(pose_q, a.t_inv);
         a.cx = p->cx; a.cy = p->cy; a.fx = p->fx; a.fy = p->fy;
         a.camz = float(1.0 / double(p->fx)); a.camw = float(1.0 / double(p->fy));       // GlobalModel.cpp:365-368
         a.max_depth = p->max_depth; a.conf_threshold = p->conf_high;
-        a.weighting = sf_fusion_weighting(last_pose, m->pose, weight_multiplier);        // :270-282
+        a.weighting = sf_fusion_weighting(last_pose, pose_q, weight_multiplier);         // :270-282
         a.time = m->tick; a.time_delta = p->time_delta;
         a.src = m->buf[0]; a.dst = m->buf[1]; a.out = m->buf[0];
         a.count = m->count; a.capacity = m->capacity;
         a.keys = m->keys; a.winner = m->winner;
         a.occ = m->occ; a.occ_words = (a.rows * 4 + 63) / 64;
-        if (m->epoch + 2 > 255) {  // the 8-bit tag is used up: one real clear, then count again
+        if (new_epoch[q] + 2 > 255) {  // the 8-bit tag is used up: one real clear, then count again
             HIP_TRY(hipMemsetAsync(m->keys, 0xff, npx * 16 * sizeof(unsigned long long), h->stream));
-            m->epoch = 0;
+            m->epoch = new_epoch[q] = 0;  // the key image IS cleared from here on, whatever happens next
         }
-        a.tag_first = 255u - (unsigned)(m->epoch + 1); a.tag_merged = 255u - (unsigned)(m->epoch + 2);
-        m->epoch += 2;
+        a.tag_first = 255u - (unsigned)(new_epoch[q] + 1); a.tag_merged = 255u - (unsigned)(new_epoch[q] + 2);
+        new_epoch[q] += 2;
         a.par = m->tick % 2;
         a.cand_rows = (a.rows - a.par + 1) / 2; a.cand_cols = (a.cols - a.par + 1) / 2;
         a.n_cand = a.cand_rows * a.cand_cols;
@@ -1323,6 +1409,10 @@ int sf_map_fuse_frames(sf_handle *h, int n, const int *streams, sf_map *const *m
     std::vector<int> res((size_t)n * 8);
     if (int e = d2h(h, res.data(), h->res_dev, res.size() * sizeof(int))) return e;
     int overflow = -1;
+    for (int q = 0; q < n; q++) {  // commit
+        std::memcpy(maps[q]->pose, new_pose.data() + (size_t)q * 16, sizeof maps[q]->pose);
+        maps[q]->epoch = new_epoch[q];
+    }
     for (int q : init_of) {
         sf_map *m = maps[q];
         m->count = res[(size_t)q * 8];
@@ -1373,6 +1463,7 @@ int sf_map_info(sf_map *m, int *count, int *tick, float pose[16], int stats[4]) 
 }
 int sf_map_download(sf_map *m, float *surfels, int max_count) {
     if (!m || (!surfels && max_count > 0) || max_count < 0) return fail(SF_ERR_ARG, "bad argument");
+    if (!m->h) return fail(SF_ERR_STATE, "the handle this map was created from has been destroyed");
     const size_t k = (size_t)std::min(max_count, m->count);
     if (k) return d2h(m->h, surfels, m->buf[0], k * 12 * sizeof(float));
     return SF_OK;
@@ -1380,6 +1471,7 @@ int sf_map_download(sf_map *m, float *surfels, int max_count) {
 int sf_map_upload(sf_map *m, const float *surfels, int count, const float pose[16], int tick) {
     if (!m || (!surfels && count > 0) || count < 0 || !pose || tick < 1) return fail(SF_ERR_ARG, "bad argument");
     if (count > m->capacity) return fail(SF_ERR_ARG, "count exceeds the map's capacity");
+    if (!m->h) return fail(SF_ERR_STATE, "the handle this map was created from has been destroyed");
     HIP_TRY(hipSetDevice(m->h->device));
     if (count) {
         HIP_TRY(hipMemcpyAsync(m->buf[0], surfels, (size_t)count * 12 * sizeof(float), hipMemcpyHostToDevice, m->h->stream));
@@ -1392,6 +1484,7 @@ int sf_map_upload(sf_map *m, const float *surfels, int count, const float pose[1
 }
 int sf_map_get_index_map(sf_map *m, uint32_t *out) {
     if (!m || !out) return fail(SF_ERR_ARG, "null");
+    if (!m->h) return fail(SF_ERR_STATE, "the handle this map was created from has been destroyed");
     if (!m->have_index) return fail(SF_ERR_STATE, "no index map yet (sf_map_fuse_frame with tick > 1 renders it)");
     HIP_TRY(hipSetDevice(m->h->device));
     const size_t n = m->h->k.n0 * 16;

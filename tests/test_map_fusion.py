@@ -365,6 +365,45 @@ def batch_walk(api, n_frames, batched):
     return out
 
 
+def test_per_stream_density_flags_and_orphaned_maps(ora):
+    """sf_get_prediction_dense_stream: every sequence of a batched prediction has its own denseEnough flag (its kb switch,
+    StaticFusion-imagesequenceassoc.cpp:157-163); a map that outlives its handle fails cleanly instead of touching freed
+    memory (same checks on the HIP library: test_hip_density_flags_and_orphaned_maps)."""
+    _density_and_orphans(ora, orphans_fail=False)  # the oracle's maps own plain host memory
+
+
+def _density_and_orphans(api, orphans_fail=True):
+    s = make_solver(api, ROWS, COLS, driver_params(api), batch=3)
+    maps = [SurfelMap(s) for _ in range(3)]
+    depth, rgb = synthetic_view(np.eye(4), sphere=False)
+    thin = depth.copy()
+    thin[:, : COLS - 2] = 0  # a sliver of a model: the 1/40 samples see almost nothing
+    for q, d in enumerate((depth, thin, depth)):
+        load_view(s, d, rgb, np.full(24, 0.9, np.float32), stream=q, finish=(q == 2))
+    SurfelMap.fuse_frames(s, [0, 1, 2], maps, None)
+    assert not any(s.prediction_dense_stream(q) for q in range(3))  # nothing predicted yet
+    SurfelMap.predict_frames(s, [0, 1], maps[:2])
+    assert [s.prediction_dense_stream(q) for q in range(3)] == [True, False, False]  # stream 2 was not part of the call
+    assert s.prediction_dense() is True  # the first job of the last call
+    maps[2].predict(2)
+    assert [s.prediction_dense_stream(q) for q in range(3)] == [False, False, True]  # the flags of a call last until the next one
+    # a failed fuse leaves the map as it was: pose, tick and count
+    before = maps[0].info()
+    with pytest.raises(SfError):
+        SurfelMap.fuse_frames(s, [0, 0], [maps[0], maps[0]], [np.eye(4), np.eye(4)])
+    after = maps[0].info()
+    assert before["tick"] == after["tick"] and before["count"] == after["count"] and np.array_equal(before["pose"], after["pose"])
+    # the handle goes first
+    m = maps[0]
+    s.close()
+    assert m.info()["count"] > 0
+    if orphans_fail:
+        with pytest.raises(SfError):
+            m.download()
+    for mm in maps:
+        mm.close()  # destroying an orphaned map is fine
+
+
 def same_batch_results(a, b):
     for k, (fa, fb) in enumerate(zip(a, b)):
         assert len(fa) == len(fb)
@@ -394,6 +433,11 @@ def test_batched_calls_equal_single_calls_on_the_oracle(ora):
 # ------------------------------------------------------------------------------------------------
 #  GPU: HIP vs oracle
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_hip_density_flags_and_orphaned_maps(hip_auto):
+    _density_and_orphans(hip_auto)
+
+
 @pytest.mark.gpu
 def test_hip_matches_the_independent_python_derivation(hip):
     g, frames, preds = _fusion_fixture(hip)

@@ -287,14 +287,7 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
     const float disp_u_i = 0.5f * float(cols_i - 1);
     const float disp_v_i = 0.5f * float(rows_i - 1);
     const float epsilon_intensity = 1e-6f, epsilon_depth = 0.005f;
-    const float kz = a.p.kz;
 
-    if (tid < SF_NC) {
-        s.prior_sum[tid] = 0;
-        s.prior_size[tid] = 0;
-        s.prior_nonnull[tid] = 0;
-        s.valid_cnt[tid] = 0;
-    }
     // The raw pre-weights w = sqrt(1 / (eps + e)) are needed only through their image maximum (:505-509), and w is a
     // monotonic (non-increasing) function of e in float arithmetic too -- every step of it is -- so max w = w(min e),
     // bit for bit: the pass tracks min e and evaluates the division and the square root once, at the end.
@@ -380,13 +373,12 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
             const bool inside = (v < rows_i && u < cols_i);
             const int e = lv + lu * TILE_LV;
             const int idx = v + u * rows_i;
-            bool valid = false, nonnull = false;
+            bool valid = false;
             int lab = SF_NC;
             float ddt_ = 0.f;
             if (inside) {
                 const float dn = s.lt.t_dn[e], dw = s.lt.t_dw[e];
                 const bool nul = s.lt.t_null[e] != 0;
-                nonnull = !nul;
                 const float dct_ = s.lt.t_in[e] - s.lt.t_iw[e];
                 ddt_ = dn - dw;
                 lab = seg ? (k ? c_lab1 : c_lab0) : ((dn != 0.f) ? 0 : SF_NC);
@@ -422,7 +414,11 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                     abs_d += (double)(vrsq(0.01f + error_l_d) * fabsf(ddt_));
                     n_valid++;
                 }
-                rec[R_DW][idx] = valid ? dw : -dw;  // the SIGN carries validPixels (valid => dw > 0): the passes need no label plane for it
+                // the SIGN carries validPixels (valid => dw > 0): the passes need no label plane for it. A NEGATIVE warped depth
+                // (a point behind the camera that still projects into the image: a diverged pose) stays negative = not valid;
+                // the segmentation prior then sees its magnitude (solve_seg_prior), the one place where this differs from the
+                // reference, which carries such a pixel through with its sign
+                rec[R_DW][idx] = valid ? dw : -fabsf(dw);
                 rec[R_DCU][idx] = dcu_;
                 rec[R_DCV][idx] = dcv_;
                 rec[R_DCT][idx] = dct_;
@@ -456,14 +452,6 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                     a.dbg_inter[3][q] = y_i;
                 }
             }
-            if (seg) {
-                // computeSegPrior (reference SegmentationBackground.cpp:65-81), per-wave aggregation
-                const bool labelled = inside && lab != SF_NC;
-                wave_label_count(labelled, lab, s.prior_size, lane);
-                wave_label_count(labelled && nonnull, lab, s.prior_nonnull, lane);
-                wave_label_add_i64(labelled && nonnull, lab, to_fix(1.f - kz * fabsf(ddt_), FIX_RES, 1.0e6f), s.prior_sum, lane);
-                wave_label_count(valid, lab, s.valid_cnt, lane);
-            }
         }
     }
 
@@ -485,9 +473,7 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
     // this workgroup's partial results -> payload words; every workgroup of the cluster then receives all of them and
     // combines them in rank order (maxima, counts and the fixed-point sums are order free; the two fp64 sums are added in
     // the same order everywhere). The gather also is the barrier behind which the records may be read by everybody.
-    enum { W_TC = 0, W_TD, W_NV, W_AC, W_AD = W_AC + 2, W_PSUM = W_AD + 2, W_PSIZE = W_PSUM + 2 * SF_NC, W_PNN = W_PSIZE + SF_NC,
-           W_VCNT = W_PNN + SF_NC, W_LIN_WORDS = W_VCNT + SF_NC };
-    static_assert(W_LIN_WORDS <= SF_SYNC_WORDS, "payload of the linearisation rendezvous");
+    enum { W_TC = 0, W_TD, W_NV, W_AC, W_AD = W_AC + 2, W_LIN_WORDS = W_AD + 2 };
     if (tid == 0) {
         int tc = 0, td = 0, nv = 0;  // transformed minima, see above
         double ac = 0.0, ad = 0.0;
@@ -504,13 +490,7 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
         put_f64(&cs.in[W_AC], ac);
         put_f64(&cs.in[W_AD], ad);
     }
-    if (seg && tid < SF_NC) {
-        put_i64(&cs.in[W_PSUM + 2 * tid], s.prior_sum[tid]);
-        cs.in[W_PSIZE + tid] = (unsigned)s.prior_size[tid];
-        cs.in[W_PNN + tid] = (unsigned)s.prior_nonnull[tid];
-        cs.in[W_VCNT + tid] = (unsigned)s.valid_cnt[tid];
-    }
-    const int n_words = seg ? (int)W_LIN_WORDS : (int)W_PSUM;
+    const int n_words = (int)W_LIN_WORDS;
     cluster_gather(cs, n_words, tid, true);
     if (tid == 0) {
         int tc = 0, td = 0, nv = 0;
@@ -532,12 +512,89 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
         s.inv_max_d = (nv > 0) ? 1.f / md : 0.f;
         if (nv == 0) s.status |= SF_STATUS_EMPTY_LEVEL;
     }
-    if (seg && tid < SF_NC) {  // reference SegmentationBackground.cpp:84-102
-        const int l = tid;
+    __syncthreads();
+}
+
+#undef LIN_PREFETCH
+
+// ---------------------------------------------------------------------------------------------
+//  computeSegPrior (reference SegmentationBackground.cpp:53-103): per cluster the pixel count, the count of non-Null
+//  pixels, the sum of 1 - kz |ddt| over them -- and validPixels per cluster for the b-solve (:651). A streaming pass over the
+//  level right after the linearisation: new depth, stored warped depth (its sign carries validPixels) and the label byte,
+//  9 bytes per pixel. Each lane walks consecutive pixel pairs of a column band, where labels are coherent: it keeps running
+//  totals for the label of its last pixel and flushes them with four LDS integer atomics when the label changes (the sums
+//  are integers / Q32.32: exact, order free). The linearisation itself used to aggregate these per tile with wave ballots
+//  and 64-bit DPP sums -- more instructions than the stencil.
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ void solve_seg_prior(const KArgs &a, int b, int L, LDS SolveShared &s, LDS ClusterShared &cs, int tid) {
+    const int n = a.ln[L];
+    const float kz = a.p.kz;
+    const size_t sb = (size_t)b * a.n_tot + a.loff[L], rb = (size_t)cl_slot(cs) * a.n0;
+    const auto dnew = uniform_ptr((gcfloat *)(a.pyr_new[0] + sb));
+    const auto dwp = uniform_ptr((gcfloat *)(a.rec[R_DW] + rb));
+    const auto labp = uniform_ptr((gcu8 *)(a.labels + sb));
+    if (tid < SF_NC) {
+        s.prior_sum[tid] = 0;
+        s.prior_size[tid] = 0;
+        s.prior_nonnull[tid] = 0;
+        s.valid_cnt[tid] = 0;
+    }
+    __syncthreads();
+    int pb, pe;
+    cluster_range(cs, n, 2, pb, pe);
+    int cur = 0, c_size = 0, c_nn = 0, c_valid = 0;
+    long long c_sum = 0;
+    auto flush = [&]() {
+        if (c_size) {
+            lds_add(&s.prior_size[cur], c_size);
+            if (c_nn) {
+                lds_add(&s.prior_nonnull[cur], c_nn);
+                lds_add(&s.prior_sum[cur], c_sum);
+            }
+            if (c_valid) lds_add(&s.valid_cnt[cur], c_valid);
+        }
+    };
+    for (int i0 = pb + tid * 2; i0 < pe; i0 += SF_NT * 2) {
+        float dn[2], dw[2];
+        int lab[2];
+        load_plane<2>(dnew, i0, dn);
+        load_plane<2>(dwp, i0, dw);
+        load_labels<2>(labp, i0, lab);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            if (lab[j] == SF_NC) continue;  // invalid new depth: in no cluster
+            if (lab[j] != cur) {
+                flush();
+                cur = lab[j];
+                c_size = c_nn = c_valid = 0;
+                c_sum = 0;
+            }
+            c_size++;
+            const float dwa = fabsf(dw[j]);
+            if (dn[j] != 0.f && dwa != 0.f) {  // not Null
+                c_nn++;
+                c_sum += to_fix(1.f - kz * fabsf(dn[j] - dwa), FIX_RES, 1.0e6f);
+            }
+            c_valid += (dw[j] > 0.f) ? 1 : 0;
+        }
+    }
+    flush();
+    __syncthreads();
+    enum { W_PSUM = 0, W_PSIZE = 2 * SF_NC, W_PNN = W_PSIZE + SF_NC, W_VCNT = W_PNN + SF_NC, W_WORDS = W_VCNT + SF_NC };
+    static_assert(W_WORDS <= SF_SYNC_WORDS, "payload of the prior rendezvous");
+    if (tid < SF_NC) {
+        put_i64(&cs.in[W_PSUM + 2 * tid], s.prior_sum[tid]);
+        cs.in[W_PSIZE + tid] = (unsigned)s.prior_size[tid];
+        cs.in[W_PNN + tid] = (unsigned)s.prior_nonnull[tid];
+        cs.in[W_VCNT + tid] = (unsigned)s.valid_cnt[tid];
+    }
+    cluster_gather(cs, W_WORDS, tid);
+    if (tid < SF_NC) {  // reference SegmentationBackground.cpp:84-102
+        const int l = tid, G = cl_G(cs);
         long long psum = 0;
         int psize = 0, pnn = 0, vcnt = 0;
         for (int p = 0; p < G; p++) {
-            const LDS unsigned *w = &cs.all[p * n_words];
+            const LDS unsigned *w = &cs.all[p * W_WORDS];
             psum += get_i64(&w[W_PSUM + 2 * l]);
             psize += (int)w[W_PSIZE + l];
             pnn += (int)w[W_PNN + l];
@@ -561,8 +618,6 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
     }
     __syncthreads();
 }
-
-#undef LIN_PREFETCH
 
 // ---------------------------------------------------------------------------------------------
 //  filterEstimateAndComputeT (reference FrontEnd.cpp:713-772) + est_cov (:689). One lane.
@@ -1244,6 +1299,7 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, LDS SolveShared 
             if (!first) solve_warp(a, b, L, s, cs, tid);
             PROF_MARK(s, tid, PF_WARP);
             solve_linearise(a, b, L, first, s, cs, tid);
+            if (a.p.segmentation_enabled) solve_seg_prior(a, b, L, s, cs, tid);
             PROF_MARK(s, tid, PF_LINEARISE);
             solve_irls(a, b, L, i, k, s, cs, tid);
             if (tid == 0) {

@@ -33,20 +33,41 @@ __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, int which, int
             {
             const auto d_prev = depth + a.loff[L - 1], i_prev = inten + a.loff[L - 1];
             const int rows_p = a.lrows[L - 1];
-            for (int idx = tid + rank * SF_NT; idx < n; idx += SF_NT * G) {
-                const int u = idx / rows_i, v = idx - u * rows_i;
+            // A wave produces 62 consecutive pixels of the level (column-major: consecutive rows v of a column u); lanes 0 and 63
+            // are halo lanes. Every lane loads rows 2v, 2v+1 of the four input columns 2u-1 .. 2u+2 as 8-byte pairs (8 loads
+            // for both channels instead of 32 single taps) and gets the rows above / below, 2v-1 and 2v+2, from its neighbour
+            // lanes over the DPP network (wave_shr / wave_shl): the 4 x 4 block of the reference, no tap fetched twice by a
+            // wave. Where the neighbour lane sits in another column the pixel is a border pixel and does not use those rows.
+            const int lane = tid & 63, wave = tid >> 6;
+            const int n_chunks = (n + 61) / 62;
+            typedef __attribute__((address_space(1))) const vfloat2 gcf2;
+            for (int chunk = wave + rank * SF_NW; chunk < n_chunks; chunk += SF_NW * G) {
+                const int idx = chunk * 62 + lane - 1;
+                const bool produce = lane >= 1 && lane <= 62 && idx < n;
+                const int idc = min(max(idx, 0), n - 1);
+                const int u = idc / rows_i, v = idc - u * rows_i;
                 const int u2 = 2 * u, v2 = 2 * v;
                 float dout, iout;
+                float db[16], ib[16];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int col = min(max(u2 - 1 + c, 0), 2 * cols_i - 1);  // clamped: a border pixel does not use what is outside
+                    const vfloat2 dd = *(gcf2 *)(d_prev + (v2 + col * rows_p));
+                    const vfloat2 ii = *(gcf2 *)(i_prev + (v2 + col * rows_p));
+                    db[1 + 4 * c] = dd.x;
+                    db[2 + 4 * c] = dd.y;
+                    ib[1 + 4 * c] = ii.x;
+                    ib[2 + 4 * c] = ii.y;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {  // row 2v-1 = the lane above's row 2(v-1)+1, row 2v+2 = the lane below's row 2(v+1)
+                    db[0 + 4 * c] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(db[2 + 4 * c]), 0x138, 0xf, 0xf, false));
+                    ib[0 + 4 * c] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ib[2 + 4 * c]), 0x138, 0xf, 0xf, false));
+                    db[3 + 4 * c] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(db[1 + 4 * c]), 0x130, 0xf, 0xf, false));
+                    ib[3 + 4 * c] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ib[1 + 4 * c]), 0x130, 0xf, 0xf, false));
+                }
+                if (!produce) continue;
                 if ((v > 0) && (v < rows_i - 1) && (u > 0) && (u < cols_i - 1)) {
-                    float db[16], ib[16];
-#pragma unroll
-                    for (int c = 0; c < 4; c++)
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int src = (v2 - 1 + r) + (u2 - 1 + c) * rows_p;
-                            db[r + 4 * c] = d_prev[src];
-                            ib[r + 4 * c] = i_prev[src];
-                        }
                     float d0 = db[5], d1 = db[6], d2 = db[9], d3 = db[10];
                     if (d1 < d0) { const float t = d1; d1 = d0; d0 = t; }
                     if (d3 < d2) { const float t = d3; d3 = d2; d2 = t; }
@@ -79,15 +100,14 @@ __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, int which, int
                         dout = 0.f;
                     }
                 } else {
-                    float db[4], ib[4];
+                    // the 2 x 2 block (rows 2v, 2v+1 of columns 2u, 2u+1): part of what the lane holds
+                    const float b4d[4] = {db[1 + 4 * 1], db[2 + 4 * 1], db[1 + 4 * 2], db[2 + 4 * 2]};
+                    const float b4i[4] = {ib[1 + 4 * 1], ib[2 + 4 * 1], ib[1 + 4 * 2], ib[2 + 4 * 2]};
 #pragma unroll
-                    for (int c = 0; c < 2; c++)
-#pragma unroll
-                        for (int r = 0; r < 2; r++) {
-                            const int src = (v2 + r) + (u2 + c) * rows_p;
-                            db[r + 2 * c] = d_prev[src];
-                            ib[r + 2 * c] = i_prev[src];
-                        }
+                    for (int q = 0; q < 4; q++) {
+                        db[q] = b4d[q];
+                        ib[q] = b4i[q];
+                    }
                     iout = 0.25f * ((ib[0] + ib[2]) + (ib[1] + ib[3]));
                     float new_d = 0.f;
                     unsigned cont = 0;

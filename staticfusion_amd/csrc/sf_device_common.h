@@ -237,11 +237,17 @@ __device__ __forceinline__ float sqf(float x) { return x * x; }
 __device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }
 __device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }
 
+// (long long)(y * scale) without the emulated float -> int64 conversion: v = y * scale (|v| <= 2^52 for every use here, the
+// split works up to 2^57) is cut exactly into trunc(v / 2^26) and the remainder (both exact in float: v has 24 significant
+// bits), each converted with the native 32-bit instruction. Truncation toward zero like the C conversion, bit for bit.
 __device__ __forceinline__ long long to_fix(float x, float scale, float lim) {
     float y = x;
     if (!(y < lim)) y = lim;  // also catches NaN
     if (!(y > -lim)) y = -lim;
-    return (long long)(y * scale);
+    const float v = y * scale;
+    const float vh = truncf(v * (1.f / 67108864.f));
+    const float vl = v - vh * 67108864.f;
+    return (long long)(int)vh * 67108864ll + (long long)(int)vl;
 }
 
 // aggregate a per-lane 64-bit value into bins[label], one LDS atomic per distinct label per wave

@@ -98,23 +98,20 @@ __device__ __forceinline__ void km_search_n(const LDS KmShared &s, const int (&l
                                             const float (&py)[N], const bool (&act)[N], int (&best)[N], int *trips = nullptr) {
     float best_d[N], lim[N];
     vfloat2 cd[N];
-    bool run[N];
 #pragma unroll
     for (int k = 0; k < N; k++) {
         const vfloat4 c0 = s.cent4[last[k]];
         best[k] = last[k];
         best_d[k] = sqdist3(c0.x, c0.y, c0.z, pz[k], px[k], py[k]);
-        lim[k] = 4.f * best_d[k];
+        // the rows of candidates are sorted by distance, so "this candidate is farther than 4 d_last" stays true once it is:
+        // no per-pixel "still running" flag is needed, and a pixel that is not searched gets a limit nothing passes
+        lim[k] = act[k] ? 4.f * best_d[k] : -1.f;
         cd[k] = s.cand[last[k] * SF_NC + 1];
-        run[k] = act[k];
     }
     for (int li = 1; li < SF_NC; li++) {
         bool any = false;
 #pragma unroll
-        for (int k = 0; k < N; k++) {
-            run[k] = run[k] && !(cd[k].x > lim[k]);
-            any = any || run[k];
-        }
+        for (int k = 0; k < N; k++) any = any || !(cd[k].x > lim[k]);
         if (!__any(any)) break;
 #ifdef SF_KM_FINE_PROFILE
         if (trips) (*trips)++;
@@ -133,7 +130,7 @@ __device__ __forceinline__ void km_search_n(const LDS KmShared &s, const int (&l
         for (int k = 0; k < N; k++) {
             const int c = __float_as_int(cd[k].y);
             const float dl = sqdist3(cc[k].x, cc[k].y, cc[k].z, pz[k], px[k], py[k]);
-            const bool upd = run[k] && (dl < best_d[k]);
+            const bool upd = !(cd[k].x > lim[k]) && (dl < best_d[k]);
             best_d[k] = upd ? dl : best_d[k];
             best[k] = upd ? c : best[k];
             cd[k] = cdn[k];

@@ -459,32 +459,39 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
     // ------------------------------------------------------------------ labels at full resolution
     km_sort_centres(s, tid);
     {
-        const int rows0 = a.lrows[0], n0 = a.ln[0];
-        for (int base = tid; base < n0; base += SF_NT * SF_LOAD_BATCH) {
+        // A wave labels 8 x 8 pixel blocks (lane = 8 columns x 8 rows), SF_LOAD_BATCH blocks in lock step: the trips of the
+        // lock-step search are set by the pixel that needs most, and a compact block mostly lies inside one cluster where a
+        // 64-pixel column segment crosses two or three borders. (No order to respect here, unlike in the Lloyd pass.)
+        const int rows0 = a.lrows[0], cols0 = a.lcols[0];
+        const int bv = (rows0 + 7) / 8, bu = (cols0 + 7) / 8, n_blocks = bv * bu;
+        const int dv = lane & 7, du = lane >> 3;
+        for (int blk0 = wave * SF_LOAD_BATCH; blk0 < n_blocks; blk0 += SF_NW * SF_LOAD_BATCH) {
             float pz[SF_LOAD_BATCH], px[SF_LOAD_BATCH], py[SF_LOAD_BATCH];
-            int low[SF_LOAD_BATCH];
+            int low[SF_LOAD_BATCH], pidx[SF_LOAD_BATCH];
+            bool in[SF_LOAD_BATCH];
 #pragma unroll
             for (int q = 0; q < SF_LOAD_BATCH; q++) {
-                const int idx = min(base + q * SF_NT, n0 - 1);
-                const int u = idx / rows0, v = idx - u * rows0;
-                pz[q] = depth[idx];
-                px[q] = coord_x(lc0, u, pz[q]);
-                py[q] = coord_y(lc0, v, pz[q]);
-                low[q] = labels[o1 + (v / 2) + (u / 2) * rows_km];
+                const int blk = min(blk0 + q, n_blocks - 1);
+                const int u = (blk / bv) * 8 + du, v = (blk - (blk / bv) * bv) * 8 + dv;
+                in[q] = (blk0 + q < n_blocks) && u < cols0 && v < rows0;
+                const int uc = min(u, cols0 - 1), vc = min(v, rows0 - 1);
+                pidx[q] = vc + uc * rows0;
+                pz[q] = depth[pidx[q]];
+                px[q] = coord_x(lc0, uc, pz[q]);
+                py[q] = coord_y(lc0, vc, pz[q]);
+                low[q] = labels[o1 + (vc / 2) + (uc / 2) * rows_km];
             }
             bool act[SF_LOAD_BATCH];
             int start[SF_LOAD_BATCH], lab[SF_LOAD_BATCH];
 #pragma unroll
             for (int q = 0; q < SF_LOAD_BATCH; q++) {
-                act[q] = (base + q * SF_NT < n0) && pz[q] != 0.f;
+                act[q] = in[q] && pz[q] != 0.f;
                 start[q] = (low[q] == SF_NC) ? 0 : low[q];
             }
             km_search_n<SF_LOAD_BATCH>(s, start, pz, px, py, act, lab);
 #pragma unroll
-            for (int q = 0; q < SF_LOAD_BATCH; q++) {
-                const int idx = base + q * SF_NT;
-                if (idx < n0) labels[idx] = (uint8_t)(act[q] ? lab[q] : SF_NC);
-            }
+            for (int q = 0; q < SF_LOAD_BATCH; q++)
+                if (in[q]) labels[pidx[q]] = (uint8_t)(act[q] ? lab[q] : SF_NC);
         }
     }
     if (tid < SF_NC) s.conn[tid] = 1u << tid;

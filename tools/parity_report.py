@@ -84,7 +84,7 @@ def main():
     oracle_cache = {}
     for lib_name, path in libs.items():
         base = Api(path, "sf_")
-        for variant in ("throughput", "latency"):
+        for variant in ("throughput", "latency", "cluster"):
             api = base.with_variant(variant)
             for cfg, mk, sphere in (("configs[1] static, seg off", lambda a: config2_params(a, levels=3), False),
                                     ("configs[2] sphere, full solver", lambda a: driver_params(a), True)):

@@ -249,6 +249,13 @@ __device__ __forceinline__ long long to_fix(float x, float scale, float lim) {
     const float vl = v - vh * 67108864.f;
     return (long long)(int)vh * 67108864ll + (long long)(int)vl;
 }
+// the same value for |lim * scale| < 2^31: one conversion (truncation toward zero, like the two-step form above)
+__device__ __forceinline__ int to_fix_i32(float x, float scale, float lim) {
+    float y = x;
+    if (!(y < lim)) y = lim;
+    if (!(y > -lim)) y = -lim;
+    return (int)(y * scale);
+}
 
 // aggregate a per-lane 64-bit value into bins[label], one LDS atomic per distinct label per wave
 __device__ __forceinline__ void wave_label_add_i64(bool active, int lab, long long v, LDS long long *bins, int lane) {
@@ -316,6 +323,21 @@ struct SplatGeom {
     int cols_lim, rows_lim, rows_i;
 };
 
+// a * w for a 64-bit fixed-point value |a| < 2^55 and a weight 0 <= w < 2^23: the low word times w as one 32 x 32 -> 64
+// product, the (small, signed) high word through the 24-bit multiplier. Equal to the plain 64-bit product, in 3 instructions.
+__device__ __forceinline__ long long mul_i64_w(long long a, int w) {
+    const unsigned long long lo = (unsigned long long)(unsigned)a * (unsigned)w;
+    const int hi = __mul24((int)(a >> 32), w) + (int)(lo >> 32);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// the packed increment of an intensity cell, (w << ACC_W_SHIFT) + w * jf, for a 32-bit fixed-point intensity: one signed
+// 32 x 32 -> 64 product, the weight added into the high word
+__device__ __forceinline__ long long mul_packed_w(int jf, int w) {
+    const long long p = (long long)jf * (long long)w;
+    const int hi = (int)(p >> 32) + (w << (ACC_W_SHIFT - 32));
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)p);
+}
+
 // depth / intensity of a target pixel from its fixed-point accumulators: sum(w * value) / sum(w).
 // The integer sums are exact; one int64 -> float conversion and one IEEE float division round twice
 // (<= 1 ulp from the exact quotient, the same order as the reference's own float accumulation).
@@ -366,8 +388,10 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
             win.vmin = 0x7fffffff;
             win.umin = 0x7fffffff;
         }
-        int uw[SPLAT_PX], vw[SPLAT_PX];
-        long long dfix[SPLAT_PX], ifix[SPLAT_PX];
+        // target pixel (qu, qv) and the centi-pixel offsets (ru, rv) inside it: uwarp = 100 qu + ru (reference FrontEnd.cpp:819-853)
+        int qu[SPLAT_PX], ru[SPLAT_PX], qv[SPLAT_PX], rv[SPLAT_PX];
+        long long dfix[SPLAT_PX];
+        int ifix[SPLAT_PX];
         bool ok[SPLAT_PX];
         float z[SPLAT_PX], xr[SPLAT_PX], yr[SPLAT_PX], iw[SPLAT_PX];
 #pragma unroll
@@ -377,27 +401,30 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
             const int idx = inside ? v + u * rows_i : 0;
             ok[k] = src.load(v, u, idx, z[k], xr[k], yr[k], iw[k]) && inside;
         }
-        int vmin = 0x7fffffff, umin = 0x7fffffff;
+        int vtop = 0, utop = 0;  // max over the lane's valid pixels of INT_MAX - q (q >= 0): the wave maximum gives the minimum
 #pragma unroll
         for (int k = 0; k < SPLAT_PX; k++) {
             const float x_w = g.T[0] * xr[k] + g.T[1] * yr[k] + g.T[2] * z[k] + g.T[3];
             const float y_w = g.T[4] * xr[k] + g.T[5] * yr[k] + g.T[6] * z[k] + g.T[7];
             const float depth_w = g.T[8] * xr[k] + g.T[9] * yr[k] + g.T[10] * z[k] + g.T[11];
-            uw[k] = cvt_trunc_x86(100.f * (g.f * x_w / depth_w + g.disp_u_i));
-            vw[k] = cvt_trunc_x86(100.f * (g.f * y_w / depth_w + g.disp_v_i));
-            ok[k] = ok[k] && (uw[k] >= 0) && (uw[k] < g.cols_lim) && (vw[k] >= 0) && (vw[k] < g.rows_lim);
+            const int uw = cvt_trunc_x86(100.f * (g.f * x_w / depth_w + g.disp_u_i));
+            const int vw = cvt_trunc_x86(100.f * (g.f * y_w / depth_w + g.disp_v_i));
+            ok[k] = ok[k] && (uw >= 0) && (uw < g.cols_lim) && (vw >= 0) && (vw < g.rows_lim);
+            const unsigned uu = ok[k] ? (unsigned)uw : 0u, vv = ok[k] ? (unsigned)vw : 0u;  // non-negative: unsigned division
+            qu[k] = (int)(uu / 100u);
+            ru[k] = (int)(uu - 100u * (unsigned)qu[k]);
+            qv[k] = (int)(vv / 100u);
+            rv[k] = (int)(vv - 100u * (unsigned)qv[k]);
             dfix[k] = to_fix(depth_w, FIX_DEPTH, 1000.f);
-            ifix[k] = to_fix(iw[k], FIX_INTENS, 4.f);
+            ifix[k] = to_fix_i32(iw[k], FIX_INTENS, 4.f);
             if (ok[k]) {
-                vmin = min(vmin, vw[k] / 100);
-                umin = min(umin, uw[k] / 100);
+                vtop = max(vtop, 0x7fffffff - qv[k]);
+                utop = max(utop, 0x7fffffff - qu[k]);
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            vmin = min(vmin, __shfl_down(vmin, o, 64));
-            umin = min(umin, __shfl_down(umin, o, 64));
-        }
+        SF_DPP_REDUCE(vtop, dpp_i32, sf_op_maxi)
+        SF_DPP_REDUCE(utop, dpp_i32, sf_op_maxi)
+        const int vmin = 0x7fffffff - __builtin_amdgcn_readlane(vtop, 63), umin = 0x7fffffff - __builtin_amdgcn_readlane(utop, 63);
         __syncthreads();  // window cleared, origin initialised
         if (lane == 0) {
             lds_min(&win.vmin, vmin);
@@ -406,35 +433,45 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
         __syncthreads();
         const int wv0 = uniform_i(win.vmin), wu0 = uniform_i(win.umin);
         // ---- phase 2: splat into the window (LDS atomics), or straight to global if outside
-        auto add = [&](int v, int u, int w, long long df, long long jf) {
+        auto add = [&](int v, int u, int w, long long df, int jf) {
             const int dv = v - wv0, du = u - wu0;
             if (dv >= 0 && dv < WIN_V && du >= 0 && du < WIN_U) {
                 const int c = dv + du * WIN_V;
-                lds_add(&win.d[c], (long long)w * df);
-                lds_add(&win.i[c], ((long long)w << ACC_W_SHIFT) + (long long)w * jf);
+                lds_add(&win.d[c], mul_i64_w(df, w));
+                lds_add(&win.i[c], mul_packed_w(jf, w));
             } else {
                 const int t = v + u * g.rows_i;
-                gatomic_add(acc_d + t, (long long)w * df);
-                gatomic_add(acc_i + t, ((long long)w << ACC_W_SHIFT) + (long long)w * jf);
+                gatomic_add(acc_d + t, mul_i64_w(df, w));
+                gatomic_add(acc_i + t, mul_packed_w(jf, w));
             }
         };
 #pragma unroll
         for (int k = 0; k < SPLAT_PX; k++) {
             if (!ok[k]) continue;
-            const int uwarp = uw[k], vwarp = vw[k];
-            const int uwarp_l = uwarp - uwarp % 100, uwarp_r = uwarp_l + 100;
-            const int vwarp_d = vwarp - vwarp % 100, vwarp_u = vwarp_d + 100;
-            const int delta_r = uwarp_r - uwarp, delta_l = 100 - delta_r;
-            const int delta_u = vwarp_u - vwarp, delta_d = 100 - delta_u;
+            const int delta_l = ru[k], delta_r = 100 - ru[k], delta_d = rv[k], delta_u = 100 - rv[k];
+            const long long df = dfix[k];
+            const int jf = ifix[k];
             if (min(delta_r, delta_l) + min(delta_u, delta_d) < 5) {  // within 5 centi-pixels of a pixel centre
-                add(delta_u > delta_d ? vwarp_d / 100 : vwarp_u / 100, delta_r > delta_l ? uwarp_l / 100 : uwarp_r / 100, 200,
-                    dfix[k], ifix[k]);
+                add(delta_u > delta_d ? qv[k] : qv[k] + 1, delta_r > delta_l ? qu[k] : qu[k] + 1, 200, df, jf);
             } else {
-                const int v_d = vwarp_d / 100, u_l = uwarp_l / 100;
-                add(v_d + 1, u_l + 1, delta_l + delta_d, dfix[k], ifix[k]);
-                add(v_d + 1, u_l, delta_r + delta_d, dfix[k], ifix[k]);
-                add(v_d, u_l + 1, delta_l + delta_u, dfix[k], ifix[k]);
-                add(v_d, u_l, delta_r + delta_u, dfix[k], ifix[k]);
+                const int dv0 = qv[k] - wv0, du0 = qu[k] - wu0;  // >= 0: the window origin is the tile's minimum
+                if (dv0 < WIN_V - 1 && du0 < WIN_U - 1) {        // the 2 x 2 block lies in the window: one test, four fixed offsets
+                    const int c = dv0 + du0 * WIN_V;
+                    const int w11 = delta_l + delta_d, w10 = delta_r + delta_d, w01 = delta_l + delta_u, w00 = delta_r + delta_u;
+                    lds_add(&win.d[c + WIN_V + 1], mul_i64_w(df, w11));
+                    lds_add(&win.i[c + WIN_V + 1], mul_packed_w(jf, w11));
+                    lds_add(&win.d[c + 1], mul_i64_w(df, w10));
+                    lds_add(&win.i[c + 1], mul_packed_w(jf, w10));
+                    lds_add(&win.d[c + WIN_V], mul_i64_w(df, w01));
+                    lds_add(&win.i[c + WIN_V], mul_packed_w(jf, w01));
+                    lds_add(&win.d[c], mul_i64_w(df, w00));
+                    lds_add(&win.i[c], mul_packed_w(jf, w00));
+                } else {
+                    add(qv[k] + 1, qu[k] + 1, delta_l + delta_d, df, jf);
+                    add(qv[k] + 1, qu[k], delta_r + delta_d, df, jf);
+                    add(qv[k], qu[k] + 1, delta_l + delta_u, df, jf);
+                    add(qv[k], qu[k], delta_r + delta_u, df, jf);
+                }
             }
         }
         __syncthreads();

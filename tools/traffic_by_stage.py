@@ -1,6 +1,6 @@
 """HBM bytes per stage group: the per-frame calls of include/sf.h issued one by one (each is its own launch of
 sf_frame_kernel with a stage mask), to be run under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`.
-The last 5 dispatches are, in order: pyramid(old) | pyramid(new)+K-means+solver | residuals | segm image | ring push."""
+The last 7 dispatches are, in order: pyramid(old) | pyramid(new) | K-means (or pyramid(new) again without segmentation) | K-means + solver | residuals | segm image | ring push."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import argparse
@@ -22,7 +22,12 @@ for im in range(6):
     s.process_frame(im)
 s.synchronize()
 s.build_pyramid(True)
-s.run_solver(True)
+s.build_pyramid(False)
+if p.segmentation_enabled:
+    s.kmeans()
+else:
+    s.build_pyramid(False)  # keeps the number of launches the same
+s.run_solver(False)
 s.residuals_vs_history(6)
 s.build_segm_image()
 s.push_history(6)

@@ -26,12 +26,13 @@ def load(d):
         pass
     return disp, pmc
 dt, _ = load("$OUT/trace"); df, pf = load("$OUT/fetch"); dw, pw = load("$OUT/write")
-names = ["pyramid(old)", "pyramid(new)+kmeans+solver", "residuals vs history", "segm image", "ring push"]
+names = ["pyramid(old)", "pyramid(new)", "kmeans alone (static: pyramid(new) again)", "kmeans+solver (runSolver(false))", "residuals vs history", "segm image", "ring push"]
+NS = len(names)
 print("workload $WL batch $B: per-launch HBM bytes (reads = 2 x FETCH_SIZE, gfx950), MB per stream")
 tot = 0
-for k in range(5):
-    rd = 2 * pf[df[-5 + k][4]] * 1024; wr = pw[dw[-5 + k][4]] * 1024; ms = (dt[-5 + k][3] - dt[-5 + k][2]) * 1e-6
+for k in range(NS):
+    rd = 2 * pf[df[-NS + k][4]] * 1024; wr = pw[dw[-NS + k][4]] * 1024; ms = (dt[-NS + k][3] - dt[-NS + k][2]) * 1e-6
     tot += rd + wr
     print("  %-28s %8.3f ms  read %7.3f MB  write %7.3f MB  -> %6.2f TB/s" % (names[k], ms, rd / $B / 1e6, wr / $B / 1e6, (rd + wr) / ms / 1e9))
-print("  total %.2f MB per stream" % (tot / $B / 1e6))
+print("  total %.2f MB per stream (K-means counted twice with segmentation, pyramid(new) twice without)" % (tot / $B / 1e6))
 PY

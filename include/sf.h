@@ -412,7 +412,8 @@ int SF_FN(get_counters)(sf_handle *h, int64_t *frames, int64_t *n_irls, int64_t 
  * 5 IRLS setup 6 IRLS pass 1 7 6x6 solve 8 IRLS pass 2 9 b-solve/convergence 10 filter/update
  * 11 residuals-vs-history 12 segm image + history push 13 total; 14..20 K-means sub-stages
  * (init, centre sort, assignment, stable partition, sequential sums, level-0 labels, connectivity +
- * label pyramid). */
+ * label pyramid); 23 is a counter, not a timer: warp tiles that were replayed because some of their targets fell
+ * outside the tile's accumulation window (one-workgroup builds). */
 int SF_FN(get_stage_profile)(sf_handle *h, int64_t ticks[24]);
 /* The IRLS streaming passes in isolation: `reps` executions of pass `which` (1 = weights + normal
  * equations, 2 = residuals + label sums) over the level-0 records of every stream left by the last

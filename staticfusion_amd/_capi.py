@@ -491,6 +491,12 @@ class Solver:
         self.api.check(self.api.get_stage_profile(self.h, t))
         return {n: t[i] * 1e-8 for i, n in enumerate(self.STAGES)}
 
+    def splat_replays(self):
+        """warp tiles replayed for targets outside their accumulation window (slot 23 of the stage profile: a counter)"""
+        t = (C.c_int64 * 24)()
+        self.api.check(self.api.get_stage_profile(self.h, t))
+        return int(t[23])
+
     def microbench_pass(self, which, variant, reps):
         ms = C.c_float()
         self.api.check(self.api.microbench_pass(self.h, which, variant, reps, C.byref(ms)))

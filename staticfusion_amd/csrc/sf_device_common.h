@@ -29,7 +29,9 @@
 enum {
     PF_PYR_OLD = 0, PF_PYR_NEW, PF_KMEANS, PF_WARP, PF_LINEARISE, PF_IRLS_INIT, PF_PASS1, PF_SOLVE6, PF_PASS2,
     PF_TAIL, PF_FILTER, PF_RESIDUALS, PF_SEGM_HIST, PF_TOTAL,
-    PF_KM_INIT, PF_KM_SORT, PF_KM_ASSIGN, PF_KM_PARTITION, PF_KM_SUM, PF_KM_LABEL0, PF_KM_CONN_PYR, SF_PROF_SLOTS = 24
+    PF_KM_INIT, PF_KM_SORT, PF_KM_ASSIGN, PF_KM_PARTITION, PF_KM_SUM, PF_KM_LABEL0, PF_KM_CONN_PYR,
+    PF_SPLAT_REPLAYS = 23,  // not a timer: warp tiles replayed for targets outside their window (tiled_splat, lazy mode)
+    SF_PROF_SLOTS = 24
 };
 
 // record planes written by the linearisation and streamed by the IRLS passes.  Only what cannot be
@@ -365,19 +367,51 @@ __device__ __forceinline__ void normalise_acc(long long sd, long long packed, fl
 #define WIN_U (SPLAT_TU + 6)
 #define WIN_CELLS (WIN_V * WIN_U)
 
+#define SPLAT_MAX_LAZY_TILES 512
 struct SplatWin {
     long long d[WIN_CELLS];
     long long i[WIN_CELLS];  // packed like the global cell
     int vmin, umin;
+    unsigned ovf[SPLAT_MAX_LAZY_TILES / 32];  // lazy mode: tiles with targets outside their window (replayed at the end)
 };
+// Lazy zeroing (one workgroup per stream only): instead of a pass that zeroes the whole accumulator image before the
+// splat, the tile loop zeroes the accumulator COLUMNS a window reaches right before the first window that reaches them
+// (windows move left to right with the source tiles, a watermark keeps what is done). The lines are still in L2 when the
+// window's atomics arrive a few microseconds later, so a cell costs one write-back instead of a zero write, a fetch
+// and a second write-back. Targets outside a tile's window (rare: strong local stretch) cannot go straight to the
+// global cells then -- their column may not be zeroed yet -- so the tile is flagged and replayed after the last tile.
+__device__ __forceinline__ bool splat_lazy_ok(int rows_i, int cols_i, int G) {
+    const int tiles = ((rows_i + SPLAT_TV - 1) / SPLAT_TV) * ((cols_i + SPLAT_TU - 1) / SPLAT_TU);
+    return G == 1 && tiles <= SPLAT_MAX_LAZY_TILES;
+}
 
 // Src::load(v, u, idx, z, xr, yr, iw) -> bool valid
 template <class Src>
 __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int cols_i, const Src &src, gptr<long long> acc_d,
-                                            gptr<long long> acc_i, LDS SplatWin &win, int tid, int tile_first = 0, int tile_step = 1) {
+                                            gptr<long long> acc_i, LDS SplatWin &win, int tid, int tile_first = 0, int tile_step = 1,
+                                            bool lazy = false, long long *replayed = nullptr) {
     const int lane = tid & 63;
     const int tiles_v = (rows_i + SPLAT_TV - 1) / SPLAT_TV, tiles_u = (cols_i + SPLAT_TU - 1) / SPLAT_TU;
-    for (int tile = tile_first; tile < tiles_v * tiles_u; tile += tile_step) {  // a cluster's workgroups take every G-th tile
+    const int n_tiles = tiles_v * tiles_u;
+    int zcol = 0;  // lazy: accumulator columns [0, zcol) are zero or hold sums already
+    if (lazy) {
+        if (tid < SPLAT_MAX_LAZY_TILES / 32) win.ovf[tid] = 0;  // ordered before its first use by the tile loop's barriers
+    }
+    // lazy: a second walk over the tiles (it >= n_tiles) replays the flagged ones for their out-of-window targets
+    for (int it = tile_first; it < (lazy ? 2 * n_tiles : n_tiles); it += tile_step) {  // a cluster's workgroups take every G-th tile
+        const bool replay = it >= n_tiles;
+        const int tile = replay ? it - n_tiles : it;
+        if (replay) {
+            if (it == n_tiles) {  // every tile flushed: zero what no window reached; the flags are complete
+                for (int idx = zcol * rows_i + tid; idx < cols_i * rows_i; idx += SF_NT) {
+                    acc_d[idx] = 0;
+                    acc_i[idx] = 0;
+                }
+                __syncthreads();
+            }
+            if (!((uniform_i((int)win.ovf[tile >> 5]) >> (tile & 31)) & 1)) continue;
+            if (tid == 0 && replayed) *replayed += 1;  // diagnostic counter (slot 23 of sf_get_stage_profile)
+        }
         const int tv0 = (tile % tiles_v) * SPLAT_TV, tu0 = (tile / tiles_v) * SPLAT_TU;
         // ---- phase 1: clear the window, load + project this lane's source pixels, window origin
         for (int q = tid; q < WIN_CELLS; q += SF_NT) {
@@ -432,13 +466,29 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
         }
         __syncthreads();
         const int wv0 = uniform_i(win.vmin), wu0 = uniform_i(win.umin);
+        if (lazy && !replay && wu0 != 0x7fffffff) {  // zero the columns this window reaches first (stores ordered before the
+                                                     // flush's atomics by the barrier in front of phase 3)
+            const int need = min(cols_i, wu0 + WIN_U);
+            if (need > zcol) {
+                for (int idx = zcol * rows_i + tid; idx < need * rows_i; idx += SF_NT) {
+                    acc_d[idx] = 0;
+                    acc_i[idx] = 0;
+                }
+                zcol = need;
+            }
+        }
+        bool outside = false;  // lazy: this lane had a target outside the window
         // ---- phase 2: splat into the window (LDS atomics), or straight to global if outside
         auto add = [&](int v, int u, int w, long long df, int jf) {
             const int dv = v - wv0, du = u - wu0;
             if (dv >= 0 && dv < WIN_V && du >= 0 && du < WIN_U) {
-                const int c = dv + du * WIN_V;
-                lds_add(&win.d[c], mul_i64_w(df, w));
-                lds_add(&win.i[c], mul_packed_w(jf, w));
+                if (!replay) {
+                    const int c = dv + du * WIN_V;
+                    lds_add(&win.d[c], mul_i64_w(df, w));
+                    lds_add(&win.i[c], mul_packed_w(jf, w));
+                }
+            } else if (lazy && !replay) {
+                outside = true;
             } else {
                 const int t = v + u * g.rows_i;
                 gatomic_add(acc_d + t, mul_i64_w(df, w));
@@ -456,6 +506,7 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
             } else {
                 const int dv0 = qv[k] - wv0, du0 = qu[k] - wu0;  // >= 0: the window origin is the tile's minimum
                 if (dv0 < WIN_V - 1 && du0 < WIN_U - 1) {        // the 2 x 2 block lies in the window: one test, four fixed offsets
+                    if (replay) continue;
                     const int c = dv0 + du0 * WIN_V;
                     const int w11 = delta_l + delta_d, w10 = delta_r + delta_d, w01 = delta_l + delta_u, w00 = delta_r + delta_u;
                     lds_add(&win.d[c + WIN_V + 1], mul_i64_w(df, w11));
@@ -474,8 +525,12 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
                 }
             }
         }
+        if (lazy && !replay && __any(outside)) {
+            if (lane == 0) lds_or(&win.ovf[tile >> 5], 1u << (tile & 31));
+        }
         __syncthreads();
         // ---- phase 3: add the touched cells to the global accumulators (consecutive lanes -> consecutive v)
+        if (!replay)
         for (int q = tid; q < WIN_CELLS; q += SF_NT) {
             const long long packed = win.i[q];
             if (packed == 0) continue;  // sum(w) >= 1 makes a touched cell non-zero

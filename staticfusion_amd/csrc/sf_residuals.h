@@ -48,11 +48,13 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, L
         s.lab_sum[tid] = 0;
         s.lab_cnt[tid] = 0;
     }
+    const bool lazy = splat_lazy_ok(rows, cols, G);  // see solve_warp
+    if (!lazy)
     for (int idx = tid + rank * SF_NT; idx < n; idx += SF_NT * G) {  // agent-scope stores: see solve_warp
         if (G > 1) {
             __hip_atomic_store(acc_d + idx, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(acc_i + idx, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {  // one workgroup: plain stores keep the lines in L2 for the atomics that follow
+        } else {
             acc_d[idx] = 0;
             acc_i[idx] = 0;
         }
@@ -84,7 +86,7 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, L
             return z != 0.f && dc != 0.f;
         }
     } src{dbuf, ibuf, dcur, inv_f_i, g.disp_u_i, g.disp_v_i};
-    tiled_splat(g, rows, cols, src, acc_d, acc_i, s.win, tid, rank, G);
+    tiled_splat(g, rows, cols, src, acc_d, acc_i, s.win, tid, rank, G, lazy, &st.prof[PF_SPLAT_REPLAYS]);
     cluster_rendezvous(cs, tid);
 
     // residuals, cluster-wise (:1036-1068): per-lane running sums per label, flushed to the workgroup bins

@@ -218,16 +218,18 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
     if (tid == 0) inverse4_cm(s.T, s.Tinv, s.dwork);  // T = T_odometry.inverse()  (:800)
     // a cluster's workgroups zero every G-th block. Agent-scope (write-through) stores: the cells are only ever touched by
     // agent-scope atomics and atomic loads after this, so the two hand-overs below need no fence (sf_cluster.h)
+    const bool lazy = splat_lazy_ok(rows_i, cols_i, G);  // one workgroup: the splat zeroes the cells itself, window by window
+    if (!lazy)
     for (int idx = tid + rank * SF_NT; idx < n; idx += SF_NT * G) {
         if (G > 1) {
             __hip_atomic_store(acc_d + idx, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(acc_i + idx, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {  // one workgroup: plain stores keep the lines in L2 for the atomics that follow
+        } else {
             acc_d[idx] = 0;
             acc_i[idx] = 0;
         }
     }
-    cluster_rendezvous(cs, tid);  // the accumulators are zero everywhere before anybody splats into them
+    cluster_rendezvous(cs, tid);  // the accumulators are zero everywhere before anybody splats into them (and s.Tinv is set)
 
     SplatGeom g;
     g.f = float(cols_i) / (2.f * a.tan_half_fovh);
@@ -252,7 +254,7 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
             return z != 0.f;
         }
     } src{dpred, ipred, level_coord(a, L)};
-    tiled_splat(g, rows_i, cols_i, src, acc_d, acc_i, s.win, tid, rank, G);
+    tiled_splat(g, rows_i, cols_i, src, acc_d, acc_i, s.win, tid, rank, G, lazy, &a.state[b].prof[PF_SPLAT_REPLAYS]);
     cluster_rendezvous(cs, tid);  // all atomics of the workgroup(s) performed: the linearisation reads the cells with atomic loads
 }
 

@@ -180,6 +180,31 @@ def test_frame_sequence_with_history(hip, ora):
         assert (a.n_outer, a.n_irls) == (b.n_outer, b.n_irls), k
 
 
+def test_warp_with_targets_outside_the_tile_windows(hip, ora, pair):
+    """A patch of picket fence (3-pixel bands at a third of the depth) in the predicted depth image, under a sideways
+    motion: neighbouring source pixels of the patch move by very different amounts, so the targets of its tiles do not fit
+    their accumulation windows. The one-workgroup builds then take the replay path of the splat (the accumulator columns
+    are zeroed lazily there, sf_device_common.h) -- the counter in slot 23 of the stage profile says that they really did
+    -- and the warped images still equal the oracle's. (The rest of the image keeps the estimate well conditioned.)"""
+    pr = pair(seed=21, rows=240, cols=320, xi=(0.05, 0.0, 0.0, 0.0, 0.0, 0.0))
+    d_old = pr["old"][0].copy()
+    patch = np.zeros((240, 320), bool)
+    patch[90:150, 130:190] = True
+    patch &= ((np.arange(320) // 3) % 2 == 0)[None, :]
+    d_old[patch] *= 0.3
+    fence = {"new": pr["new"], "old": (d_old, pr["old"][1])}
+    sg, so = solve_both(hip, ora, 240, 320, lambda a: driver_params(a, debug_planes=1), fence)
+    assert_traces_match(sg, so, tol_twist=1e-5, tol_b=3e-4)
+    for L in range(4):  # level 4 is warped once: Warped := Pred
+        for ch in range(2):
+            assert_planes_close(sg.plane(capi.SET_WARPED, ch, L), so.plane(capi.SET_WARPED, ch, L), frac=0.97)
+    rot, trans = pose_delta(so.T(), sg.T())
+    assert rot <= POSE_TOL and trans <= POSE_TOL
+    assert np.array_equal(sg.labels(0), so.labels(0))
+    if hip.default_variant != "cluster":  # a cluster zeroes the cells up front and sends such targets straight to them
+        assert sg.splat_replays() > 0, "the scene did not exercise the replay path"
+
+
 def test_edge_cases(hip, ora, pair):
     z = np.zeros((60, 80), np.float32)
     for api in (hip, ora):

@@ -108,7 +108,7 @@ struct KArgs {
     float *rec[R_COUNT];  // [plane][batch][n0]
     uint8_t *rec_lab;     // [batch][n0]  label of a valid pixel, SF_INVALID_LABEL otherwise
     uint8_t *rec_null;    // [batch][n0]  Null mask of the last linearisation
-    uint8_t *km_lab_tmp;  // unused for now
+    const uint8_t *km_seed_lab;  // [ln[1]] label of the nearest K-means seed of every level-1 pixel (image-size constant, built at sf_create)
     float *hist_d, *hist_i;  // [SF_HISTORY][batch][n0]
     float *b_img;            // [batch][n0]
     StreamState *state;      // [batch]
@@ -348,6 +348,24 @@ __device__ __forceinline__ void normalise_acc(long long sd, long long packed, fl
     const float wf = (float)(unsigned)((packed - si) >> ACC_W_SHIFT);
     dw = ((float)sd * (1.f / 67108864.f)) / wf;
     iw = ((float)si * (1.f / FIX_INTENS)) / wf;
+}
+
+// initializeKMeans (reference KMeans.cpp:63-101): the seed a level-1 pixel starts with is the nearest of 24 seed positions
+// that depend on the image size only, in the reference's unsigned wrap-around arithmetic. One table per handle
+// (KArgs::km_seed_lab, built by sf_seed_label_kernel at sf_create) instead of 24 squared distances per pixel and frame.
+__device__ __forceinline__ unsigned km_seed_u(int cols_km, int l) { return (unsigned)roundf((unsigned)(l + 1) * (float(cols_km) / float(SF_NC + 1))); }
+__device__ __forceinline__ unsigned km_seed_v(int rows_km, int l) { return (unsigned)roundf((unsigned)(l % 5 + 1) * (float(rows_km) / float(5 + 1))); }  // 5 = ceil(sqrt(24))
+__device__ __forceinline__ unsigned km_nearest_seed(int rows_km, int cols_km, unsigned u, unsigned v) {
+    unsigned lab = SF_NC, min_dist = 1000000u;
+    for (unsigned l = 0; l < SF_NC; l++) {
+        const unsigned dv = v - km_seed_v(rows_km, (int)l), du = u - km_seed_u(cols_km, (int)l);  // unsigned wrap-around as in the reference
+        const unsigned q = dv * dv + du * du;
+        if (q < min_dist) {
+            lab = l;
+            min_dist = q;
+        }
+    }
+    return lab;
 }
 
 #define SF_LOAD_BATCH 4  // independent pixels whose loads are issued before any of them is consumed

@@ -51,6 +51,14 @@ static const FrameVariant VARIANTS[3] = {
 
 // prediction := current; current := pool[frame_index[stream]] for every stream, 16 bytes per lane and plane
 // (sf_advance_sequences_device). grid = (slices, batch).
+// the nearest K-means seed of every level-1 pixel (KArgs::km_seed_lab): once per handle, with the device arithmetic
+__global__ __launch_bounds__(256) void sf_seed_label_kernel(uint8_t *out, int rows_km, int cols_km) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows_km * cols_km) return;
+    const int u = idx / rows_km, v = idx - u * rows_km;
+    out[idx] = (uint8_t)km_nearest_seed(rows_km, cols_km, (unsigned)u, (unsigned)v);
+}
+
 __global__ __launch_bounds__(256) void sf_advance_kernel(float *cur_d, float *cur_i, float *pred_d, float *pred_i, const float *pool_d,
                                                          const float *pool_i, const int *frame_index, int n0, int n_tot) {
     const int b = blockIdx.y;
@@ -414,6 +422,12 @@ int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, 
             TRY_OR_FREE(dev_alloc(h, &k.dbg_inter[c], B * NT));
         }
     TRY_OR_FREE(dev_alloc(h, &k.labels, B * NT));
+    {
+        uint8_t *seed = nullptr;  // levels >= 2: level 1 exists (K-means works there)
+        const size_t n1 = (k.levels >= 2) ? (size_t)k.ln[1] : 4;
+        TRY_OR_FREE(dev_alloc(h, &seed, (n1 + 3) & ~(size_t)3));
+        k.km_seed_lab = seed;
+    }
     TRY_OR_FREE(dev_alloc(h, &k.acc_d, slots * N0));
     TRY_OR_FREE(dev_alloc(h, &k.acc_i, slots * N0));
     for (int q = 0; q < R_COUNT; q++) TRY_OR_FREE(dev_alloc(h, &k.rec[q], slots * N0));
@@ -444,6 +458,12 @@ int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, 
     }
     for (size_t b = 0; b < B; b++) st[b].last_slot = (int32_t)b;
     HIP_OR_FREE(hipMemcpy(k.state, st.data(), B * sizeof(StreamState), hipMemcpyHostToDevice));
+    if (k.levels >= 2) {
+        const int n1 = k.ln[1];
+        hipLaunchKernelGGL(sf_seed_label_kernel, dim3((n1 + 255) / 256), dim3(256), 0, 0, const_cast<uint8_t *>(k.km_seed_lab), k.lrows[1], k.lcols[1]);
+        HIP_OR_FREE(hipGetLastError());
+        HIP_OR_FREE(hipStreamSynchronize(0));
+    }
     {
         std::vector<float> half(B * N0, 0.5f);  // b_segm_perpixel.fill(0.5f)
         HIP_OR_FREE(hipMemcpy(k.b_img, half.data(), B * N0 * sizeof(float), hipMemcpyHostToDevice));

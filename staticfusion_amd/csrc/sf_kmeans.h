@@ -171,38 +171,26 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
     // ------------------------------------------------------------------ initializeKMeans (K1)
     const int rows_km = a.lrows[1], cols_km = a.lcols[1], n1 = a.ln[1], o1 = a.loff[1];
     if (tid < SF_NC) {
-        const unsigned vert_div = 5;  // ceil(sqrt(24))
-        const float u_div = float(cols_km) / float(SF_NC + 1);
-        const float v_div = float(rows_km) / float(vert_div + 1);
-        s.useed[tid] = (unsigned)roundf((unsigned)(tid + 1) * u_div);
-        s.vseed[tid] = (unsigned)roundf((unsigned)(tid % vert_div + 1) * v_div);
+        s.useed[tid] = km_seed_u(cols_km, tid);
+        s.vseed[tid] = km_seed_v(rows_km, tid);
         s.prefix[tid] = 0;
     }
-    __syncthreads();
-    for (int base = tid; base < n1; base += SF_NT * SF_LOAD_BATCH) {
-        float dz[SF_LOAD_BATCH];
+    {
+        const auto seed_lab = as_global(a.km_seed_lab);
+        for (int base = tid; base < n1; base += SF_NT * SF_LOAD_BATCH) {
+            float dz[SF_LOAD_BATCH];
+            unsigned sl[SF_LOAD_BATCH];
 #pragma unroll
-        for (int k = 0; k < SF_LOAD_BATCH; k++) dz[k] = depth[o1 + min(base + k * SF_NT, n1 - 1)];
-#pragma unroll
-        for (int k = 0; k < SF_LOAD_BATCH; k++) {
-            const int idx = base + k * SF_NT;
-            if (idx >= n1) continue;
-            int ui, vi;
-            split_uv(lc1, idx, ui, vi);
-            const unsigned u = (unsigned)ui, v = (unsigned)vi;
-            unsigned lab = SF_NC;
-            if (dz[k] != 0.f) {
-                unsigned min_dist = 1000000u;
-                for (unsigned l = 0; l < SF_NC; l++) {
-                    const unsigned dv = v - s.vseed[l], du = u - s.useed[l];  // unsigned wrap-around as in the reference
-                    const unsigned q = dv * dv + du * du;
-                    if (q < min_dist) {
-                        lab = l;
-                        min_dist = q;
-                    }
-                }
+            for (int k = 0; k < SF_LOAD_BATCH; k++) {
+                const int idx = min(base + k * SF_NT, n1 - 1);
+                dz[k] = depth[o1 + idx];
+                sl[k] = seed_lab[idx];
             }
-            labels[o1 + idx] = (uint8_t)lab;
+#pragma unroll
+            for (int k = 0; k < SF_LOAD_BATCH; k++) {
+                const int idx = base + k * SF_NT;
+                if (idx < n1) labels[o1 + idx] = (uint8_t)((dz[k] != 0.f) ? sl[k] : SF_NC);
+            }
         }
     }
     __syncthreads();
@@ -402,16 +390,28 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
 #pragma unroll
                     for (int q = 0; q < 8; q++) v[q] = src[q];
                 }
-                for (; j + 16 <= n; j += 8) {
+                while (j + 24 <= n) {  // v = elements [j, j + 8); the two register sets take turns (no copies)
 #pragma unroll
                     for (int q = 0; q < 8; q++) w[q] = src[j + 8 + q];
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int q = 0; q < 8; q++) acc += v[q];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) v[q] = w[q];
+                    for (int q = 0; q < 8; q++) v[q] = src[j + 16 + q];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) acc += w[q];
+                    j += 16;
                 }
-                if (j + 8 <= n) {
+                if (j + 16 <= n) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) w[q] = src[j + 8 + q];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) acc += v[q];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) acc += w[q];
+                    j += 16;
+                } else if (j + 8 <= n) {
 #pragma unroll
                     for (int q = 0; q < 8; q++) acc += v[q];
                     j += 8;

@@ -314,38 +314,22 @@ __device__ __noinline__ void stage_kmeans_cluster(const KArgs &a, int b, LDS KmC
 
     // ------------------------------------------------------------------ initializeKMeans (K1): seed labels by pixel share
     if (tid < SF_NC) {
-        const unsigned vert_div = 5;  // ceil(sqrt(24))
-        const float u_div = float(cols_km) / float(SF_NC + 1);
-        const float v_div = float(rows_km) / float(vert_div + 1);
-        s.useed[tid] = (unsigned)roundf((unsigned)(tid + 1) * u_div);
-        s.vseed[tid] = (unsigned)roundf((unsigned)(tid % vert_div + 1) * v_div);
+        s.useed[tid] = km_seed_u(cols_km, tid);
+        s.vseed[tid] = km_seed_v(rows_km, tid);
         s.prefix[tid] = 0;
     }
     __syncthreads();
-    for (int q = qb1 + tid; q < qe1; q += SF_NT) {
-        const vfloat4 dz4 = depth1q[q];
-        const float dz[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
-        unsigned word = 0;
+    {
+        const auto seed_w = as_global((const unsigned *)a.km_seed_lab);  // the table of sf_kmeans.h, four pixels per word
+        for (int q = qb1 + tid; q < qe1; q += SF_NT) {
+            const vfloat4 dz4 = depth1q[q];
+            const float dz[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
+            const unsigned sw = seed_w[q];
+            unsigned word = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int ui, vi;
-            split_uv(lc1, 4 * q + k, ui, vi);
-            const unsigned u = (unsigned)ui, v = (unsigned)vi;
-            unsigned lab = SF_NC;
-            if (dz[k] != 0.f) {
-                unsigned min_dist = 1000000u;
-                for (unsigned l = 0; l < SF_NC; l++) {
-                    const unsigned dv = v - s.vseed[l], du = u - s.useed[l];  // unsigned wrap-around as in the reference
-                    const unsigned d2 = dv * dv + du * du;
-                    if (d2 < min_dist) {
-                        lab = l;
-                        min_dist = d2;
-                    }
-                }
-            }
-            word |= lab << (8 * k);
+            for (int k = 0; k < 4; k++) word |= ((dz[k] != 0.f) ? ((sw >> (8 * k)) & 255u) : (unsigned)SF_NC) << (8 * k);
+            st_word_agent(lab1w + q, word);
         }
-        st_word_agent(lab1w + q, word);
     }
     labels_rendezvous(cs, tid);
 

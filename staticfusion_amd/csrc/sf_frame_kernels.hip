@@ -57,8 +57,8 @@ __device__ __forceinline__ void run_stages(const KArgs &a, int b, int stage_mask
 #endif
     const long long t_begin = wall_clock64();
     t0 = t_begin;
-    if ((stage_mask & (ST_PYR_OLD | ST_PYR_NEW)) == (ST_PYR_OLD | ST_PYR_NEW) && cl_G(cs) > 1) {
-        STAGE_TIMED(PF_PYR_NEW, stage_pyramid(a, b, 3, tid, cs));  // a cluster: both pyramids behind one rendezvous per level
+    if ((stage_mask & (ST_PYR_OLD | ST_PYR_NEW)) == (ST_PYR_OLD | ST_PYR_NEW)) {
+        STAGE_TIMED(PF_PYR_NEW, stage_pyramid(a, b, 3, tid, cs));  // both pyramids behind one barrier / rendezvous per level
     } else {
         if (stage_mask & ST_PYR_OLD) STAGE_TIMED(PF_PYR_OLD, stage_pyramid(a, b, 1, tid, cs));
         if (stage_mask & ST_PYR_NEW) STAGE_TIMED(PF_PYR_NEW, stage_pyramid(a, b, 2, tid, cs));
@@ -78,10 +78,14 @@ __device__ __forceinline__ void run_stages(const KArgs &a, int b, int stage_mask
         stage_solve(a, b, *(LDS SolveShared *)&sh.sv, cs, tid);
         t0 = wall_clock64();
     }
-    if (stage_mask & ST_RESIDUALS) STAGE_TIMED(PF_RESIDUALS, stage_residuals(a, b, im_count, *(LDS ResShared *)&sh.rs, cs, tid));
+    // the frame loop pushes the current images into the ring slot the residual stage has just read (im_count % 5 both):
+    // the residual pass then stores them as it goes, having loaded them anyway
+    const bool push_in_residuals = (stage_mask & ST_RESIDUALS) && (stage_mask & ST_PUSH_HISTORY);
+    if (stage_mask & ST_RESIDUALS)
+        STAGE_TIMED(PF_RESIDUALS, stage_residuals(a, b, im_count, push_in_residuals, *(LDS ResShared *)&sh.rs, cs, tid));
     __syncthreads();
     if (stage_mask & ST_SEGM_IMAGE) stage_segm_image(a, b, tid, cs);
-    if (stage_mask & ST_PUSH_HISTORY) stage_push_history(a, b, im_count, tid, cs);
+    if (stage_mask & ST_PUSH_HISTORY) stage_push_history(a, b, im_count, !push_in_residuals, tid, cs);
     if (tid == 0 && writer) {
         t1 = wall_clock64();
         prof[PF_SEGM_HIST] += t1 - t0;

@@ -21,7 +21,7 @@ __device__ __forceinline__ int level0_label(const KArgs &a, gptr<const uint8_t> 
     return a.p.segmentation_enabled ? (int)labels0[idx] : 0;
 }
 
-__device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, LDS ResShared &s, LDS ClusterShared &cs, int tid) {
+__device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, bool push, LDS ResShared &s, LDS ClusterShared &cs, int tid) {
     StreamState &st = a.state[b];
     const int rows = a.lrows[0], cols = a.lcols[0], n = a.ln[0];
     const int G = cl_G(cs), rank = cl_rank(cs);
@@ -31,6 +31,11 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, L
     const int idx_to_warp = (index - SF_HISTORY) % SF_HISTORY;
     const auto dbuf = as_global((const float *)a.hist_d + ((size_t)idx_to_warp * a.batch + b) * a.n0);
     const auto ibuf = as_global((const float *)a.hist_i + ((size_t)idx_to_warp * a.batch + b) * a.n0);
+    // push: the slot warped from is the slot depthBuffer[index % 5] = depthCurrent goes to (datasets.cpp:182-184); the pass
+    // below stores the current images there once it has read the old depth of a pixel (everything else that reads the
+    // slot -- the splat -- is behind the rendezvous in front of the pass)
+    const auto dpush = as_global(a.hist_d + ((size_t)idx_to_warp * a.batch + b) * a.n0);
+    const auto ipush = as_global(a.hist_i + ((size_t)idx_to_warp * a.batch + b) * a.n0);
     const auto acc_d = as_global(a.acc_d + rb), acc_i = as_global(a.acc_i + rb);
 
     if (tid == 0) {
@@ -110,6 +115,16 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, L
             ic[k] = icur[idx];
             lb[k] = level0_label(a, labels0, idx);
         }
+        if (push) {
+#pragma unroll
+            for (int k = 0; k < SF_LOAD_BATCH; k++) {
+                const int idx = base + k * SF_NT;
+                if (idx < px_end) {
+                    dpush[idx] = dc[k];
+                    ipush[idx] = ic[k];
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < SF_LOAD_BATCH; k++) {
             if (!(base + k * SF_NT < px_end && si[k] != 0 && dc[k] != 0.f)) continue;
@@ -180,10 +195,11 @@ __device__ __noinline__ void stage_segm_image(const KArgs &a, int b, int tid, LD
     }
 }
 
-__device__ __noinline__ void stage_push_history(const KArgs &a, int b, int im_count, int tid, LDS ClusterShared &cs) {
+// copy_images = false: the residual stage of this launch has stored the images already, only the pose is pushed
+__device__ __noinline__ void stage_push_history(const KArgs &a, int b, int im_count, bool copy_images, int tid, LDS ClusterShared &cs) {
     const int G = cl_G(cs), rank = cl_rank(cs);
     StreamState &st = a.state[b];
-    const int slot = im_count % SF_HISTORY, n = a.ln[0];
+    const int slot = im_count % SF_HISTORY, n = copy_images ? a.ln[0] : 0;
     const auto dcur = as_global((const float *)a.pyr_new[0] + (size_t)b * a.n_tot), icur = as_global((const float *)a.pyr_new[1] + (size_t)b * a.n_tot);
     const auto dbuf = as_global(a.hist_d + ((size_t)slot * a.batch + b) * a.n0);
     const auto ibuf = as_global(a.hist_i + ((size_t)slot * a.batch + b) * a.n0);

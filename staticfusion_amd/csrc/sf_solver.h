@@ -423,7 +423,7 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                 rec[R_DW][idx] = valid ? dw : -fabsf(dw);
                 rec[R_DCU][idx] = dcu_;
                 rec[R_DCV][idx] = dcv_;
-                rec[R_DCT][idx] = dct_;
+                rec[R_DCT][idx] = (valid || dbg) ? dct_ : 0.f;  // 0 outside validPixels: the passes run branch-free over every pixel
                 rec[R_DDU][idx] = ddu_;
                 rec[R_DDV][idx] = ddv_;
                 if (seg || dbg) rec_lab[idx] = valid ? (uint8_t)(seg ? lab : 0) : (uint8_t)SF_INVALID_LABEL;
@@ -779,8 +779,8 @@ __device__ __forceinline__ bool sanitize(RecVec<VEC> &r, int j) {
     const bool ok = r.v[R_DW][j] > 0.f;  // the linearisation stores -dw (or -0) outside validPixels
     r.dn[j] = ok ? r.dn[j] : 1.f;
     r.v[R_DW][j] = ok ? r.v[R_DW][j] : 1.f;
-#pragma unroll
-    for (int q = R_DCU; q < R_COUNT; q++) r.v[q][j] = ok ? r.v[q][j] : 0.f;
+    // the four gradients and dct of such a pixel are stored as 0 by the linearisation (dct keeps its value in the debug-plane
+    // mode only): nothing to do for them here
     r.lab[j] = ok ? r.lab[j] : 0;
     return ok;
 }

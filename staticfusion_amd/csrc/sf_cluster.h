@@ -25,7 +25,7 @@
 
 #include "sf_device_common.h"
 
-#define SF_SYNC_WORDS 192      // 32-bit payload words per workgroup and rendezvous
+#define SF_SYNC_WORDS 128      // 32-bit payload words per workgroup and rendezvous (the largest gather moves 120)
 #define SF_MAX_CLUSTER 32      // workgroups per stream (one XCD has 32 CUs)
 #define SF_SYNC_SPIN_LIMIT (1u << 21)
 

@@ -379,10 +379,15 @@ __device__ __forceinline__ unsigned km_nearest_seed(int rows_km, int cols_km, un
 //  Integer sums => the result is independent of both orders.
 // ---------------------------------------------------------------------------------------------
 #define SPLAT_TV 64
+#ifndef SPLAT_TU
 #define SPLAT_TU ((SF_NT == 256 ? 4 : 2) * SF_NT / 64)
+#endif
 #define SPLAT_PX ((SPLAT_TV * SPLAT_TU) / SF_NT)  // source pixels per lane and tile
-#define WIN_V (SPLAT_TV + 6)
-#define WIN_U (SPLAT_TU + 6)
+#ifndef SPLAT_MARGIN
+#define SPLAT_MARGIN 6  // window cells beyond the tile size in each direction (a rigid warp is locally a shift: rarely more)
+#endif
+#define WIN_V (SPLAT_TV + SPLAT_MARGIN)
+#define WIN_U (SPLAT_TU + SPLAT_MARGIN)
 #define WIN_CELLS (WIN_V * WIN_U)
 
 #define SPLAT_MAX_LAZY_TILES 512

@@ -15,7 +15,10 @@
 #include "sf_smallmath.h"
 #include "sf_solver.h"
 
-#define SF_BLOCKS_PER_CU (1024 / SF_NT)  // 16 waves per CU at <= 128 VGPRs (5 x 256 per CU measured 3 % slower: DESIGN.md §9)
+#ifndef SF_OCC
+#define SF_OCC 4
+#endif
+#define SF_BLOCKS_PER_CU (SF_OCC * 256 / SF_NT)  // 16 waves per CU at <= 128 VGPRs (5 x 256 per CU measured 3 % slower: DESIGN.md §9)
 // __launch_bounds__(threads, 4): the second HIP parameter is the minimum number of WAVES PER SIMD, not workgroups per
 // CU: 4 waves per SIMD = 16 waves per CU = <= 128 VGPRs for every workgroup size
 #define SF_PASTE2(a, b) a##b
@@ -94,7 +97,7 @@ __device__ __forceinline__ void run_stages(const KArgs &a, int b, int stage_mask
 }
 
 #ifndef SF_CLUSTER
-__global__ __launch_bounds__(SF_NT, 4) void sf_frame_kernel(const KArgs *__restrict__ ka, int stage_mask, int im_count) {
+__global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__restrict__ ka, int stage_mask, int im_count) {
     __shared__ FrameShared sh;
     __shared__ ClusterShared cs;
     __shared__ int s_next;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(SF_NT, 4) void sf_frame_kernel(const KArgs *__restr
 // time, so the grid never exceeds the CUs). Workgroup j of XCD x -- blocks are dealt to the XCDs round robin, an
 // observation the mapping only uses for speed -- serves stream (j / G) * 8 + x as rank j % G: the workgroups of a stream
 // share an L2.
-__global__ __launch_bounds__(SF_NT, 4) void sf_frame_kernel(const KArgs *__restrict__ ka, int stage_mask, int im_count) {
+__global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__restrict__ ka, int stage_mask, int im_count) {
     __shared__ FrameShared sh;
     __shared__ ClusterShared cs;
     const KArgs &a = *ka;
@@ -197,4 +200,9 @@ extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_launch_ir
 extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_variant_geometry)(int *threads, int *blocks_per_cu) {
     *threads = SF_NT;
     *blocks_per_cu = SF_BLOCKS_PER_CU;
+#ifndef SF_CLUSTER
+    // what the runtime will really keep resident (registers, LDS granularity): never plan for more than that
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sf_frame_kernel, SF_NT, 0) == hipSuccess && n > 0 && n < *blocks_per_cu) *blocks_per_cu = n;
+#endif
 }

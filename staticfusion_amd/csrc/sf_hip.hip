@@ -33,6 +33,8 @@ struct FrameVariant {
 };
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_nt256(int, hipStream_t, const KArgs *, int, int);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_irls_pass_nt256(int, hipStream_t, const KArgs *, int, int, int, int);
+extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_nt256o5(int, hipStream_t, const KArgs *, int, int);
+extern "C" __attribute__((visibility("hidden"))) void sf_variant_geometry_nt256o5(int *, int *);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_nt1024(int, hipStream_t, const KArgs *, int, int);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_irls_pass_nt1024(int, hipStream_t, const KArgs *, int, int, int, int);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_debug_rows_nt256(int, hipStream_t, const KArgs *, int, float *);
@@ -83,6 +85,7 @@ struct sf_handle {
     KArgs k{};
     int device = 0;
     int max_blocks = 0;
+    int max_blocks_o5 = 0;  // throughput build: resident workgroups of the 5-per-CU kernel (0: not used)
     const FrameVariant *fv = &VARIANTS[0];
     std::vector<struct sf_map *> maps;  // live maps created from this handle: sf_destroy releases their memory and orphans them
     int cluster_grid = 0;  // SF_VARIANT_CLUSTER: blocks per launch (8 XCDs x streams per XCD x workgroups per stream)
@@ -197,7 +200,16 @@ static int launch(sf_handle *h, int mask, int im_count) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         h->args_dirty = false;
     }
-    const int grid = h->cluster_grid ? h->cluster_grid : std::min(h->k.batch, h->max_blocks);
+    int grid = h->cluster_grid ? h->cluster_grid : std::min(h->k.batch, h->max_blocks);
+    auto launch_frame = h->fv->launch_frame;
+    if (h->max_blocks_o5) {
+        bool five = h->k.p.segmentation_enabled != 0;
+        if (const char *v = std::getenv("SF_THROUGHPUT_WG_PER_CU")) five = (v[0] == '5');
+        if (five) {
+            launch_frame = sf_launch_frame_nt256o5;
+            grid = std::min(h->k.batch, h->max_blocks_o5);
+        }
+    }
     const bool timed = (mask & ST_SOLVE) != 0;
     if (timed) HIP_TRY(hipEventRecord(h->evk0, h->stream));
     if (h->cluster_grid && h->device < 64) {
@@ -205,11 +217,11 @@ static int launch(sf_handle *h, int mask, int im_count) {
         hipEvent_t &ev = g_cluster_done[h->device];
         if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         else HIP_TRY(hipStreamWaitEvent(h->stream, ev, 0));
-        h->fv->launch_frame(grid, h->stream, (const KArgs *)h->d_args, mask, im_count);
+        launch_frame(grid, h->stream, (const KArgs *)h->d_args, mask, im_count);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev, h->stream));
     } else {
-        h->fv->launch_frame(grid, h->stream, (const KArgs *)h->d_args, mask, im_count);
+        launch_frame(grid, h->stream, (const KArgs *)h->d_args, mask, im_count);
         HIP_TRY(hipGetLastError());
     }
     if (timed) {
@@ -387,6 +399,14 @@ int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, 
     int wg_threads = 0, wg_per_cu = 0;
     h->fv->geometry(&wg_threads, &wg_per_cu);
     h->max_blocks = prop.multiProcessorCount * wg_per_cu;
+    if (h->fv->id == SF_VARIANT_THROUGHPUT) {
+        // the full solver runs the same source at 5 workgroups per CU (Makefile: frame_nt256o5.o); SF_THROUGHPUT_WG_PER_CU=4|5
+        // pins one of the two for every configuration (A/B tooling)
+        int t5 = 0, per_cu5 = 0;
+        sf_variant_geometry_nt256o5(&t5, &per_cu5);
+        h->max_blocks_o5 = (per_cu5 > wg_per_cu) ? prop.multiProcessorCount * per_cu5 : 0;  // only if a fifth workgroup really fits
+        if (std::getenv("SF_DEBUG_GEOMETRY")) std::fprintf(stderr, "sf: throughput build: %d workgroups per CU, full-solver kernel %d\n", wg_per_cu, per_cu5);
+    }
     size_t slots = batch;  // record / accumulator slots of n0 pixels
     if (h->fv->id == SF_VARIANT_CLUSTER) {
         // G workgroups (CUs) per stream, all of a launch resident at once: 8 XCDs x (CUs / 8) CUs, the workgroups of a

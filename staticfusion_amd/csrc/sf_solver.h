@@ -54,9 +54,10 @@ struct LinTile {  // linearisation tile (with halo)
 };
 
 struct SolveShared {
-    union {            // the warp window and the linearisation tile are never live together
-        LinTile lt;
-        SplatWin win;
+    union {            // the warp window and the linearisation tile are never live together; the fp64 scratch of the
+        LinTile lt;    // one-lane algebra (4 x 4 inverse before a warp, motion filter after the IRLS, 3 x 3 inverse at the
+        SplatWin win;  // end of the solve) is used while neither is
+        double dwork[36 * 3 + 32];
     };
     // reductions
     double red[SF_NW][28];
@@ -87,7 +88,6 @@ struct SolveShared {
     float M24[SF_NC * (SF_NC + 1)], tmp24[SF_NC], y24[SF_NC], seg_diag[SF_NC], aver_res_label[SF_NC];
     int tr24[SF_NC];
     int seg_allzero;
-    double dwork[36 * 3 + 32];
     long long prof[SF_PROF_SLOTS], t_last;
 };
 

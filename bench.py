@@ -276,6 +276,7 @@ def run_pairs_workload(hx, args, workload, batch, with_parity):
     solver.process_frame(im)  # per-stage unit counts of ONE launch (for the algorithmic byte count): one more, un-timed step
     stats_last = [solver.stats(b) for b in range(min(B, args.distinct))]
     variant = solver.variant()
+    resident = solver.resident_workgroups()
     levels_n = [solver.level_shape(L)[0] * solver.level_shape(L)[1] for L in range(solver.levels)]
     levels = int(solver.levels)
     solver.close()
@@ -302,7 +303,7 @@ def run_pairs_workload(hx, args, workload, batch, with_parity):
             "workload": WORKLOAD_TEXT[workload],
             "streams_per_gpu": B, "distinct_pairs": len(pairs), "rows": rows, "cols": cols, "ctf_levels": levels,
             "max_iter_irls": int(params.max_iter_irls), "max_iter_per_level": int(params.max_iter_per_level),
-            "kernel_build": "%s (%d threads per workgroup, %d workgroup(s) per stream)" % variant,
+            "kernel_build": "%s (%d threads per workgroup, %d workgroup(s) per stream)" % variant + ", %d workgroups resident per CU (grid %d)" % resident,
             "parallelism": "independent streams, %d GPU(s)" % hx.world,
             "step": "sf_process_frame: pyramid(old)+runSolver(true)+residuals+segm image for every stream, one launch",
         },
@@ -386,6 +387,7 @@ def run_sequences_workload(hx, args):
         k = int((phase[b] + step - 1) % F)
         err.append(pose_delta(seqs[b % D]["T_gt"][k], T_all[b]))
     variant = solver.variant()
+    resident = solver.resident_workgroups()
     levels_n = [solver.level_shape(L)[0] * solver.level_shape(L)[1] for L in range(solver.levels)]
     levels = int(solver.levels)
     solver.close()
@@ -411,7 +413,7 @@ def run_sequences_workload(hx, args):
             "streams_per_gpu": B, "distinct_sequences_per_rank": D, "frames_per_sequence": F, "sequence_seeds": [1000 + hx.rank * D, 1000 + hx.rank * D + D - 1],
             "rows": rows, "cols": cols, "ctf_levels": levels,
             "max_iter_irls": int(params.max_iter_irls), "max_iter_per_level": int(params.max_iter_per_level),
-            "kernel_build": "%s (%d threads per workgroup, %d workgroup(s) per stream)" % variant,
+            "kernel_build": "%s (%d threads per workgroup, %d workgroup(s) per stream)" % variant + ", %d workgroups resident per CU (grid %d)" % resident,
             "parallelism": "independent sequences, %d GPU(s)" % hx.world,
             "step": "sf_advance_sequences_device (prediction := current, current := next frame from the HBM pool) + sf_process_frame",
         },

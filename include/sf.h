@@ -150,6 +150,11 @@ int SF_FN(create_ex)(const sf_params *p, int rows, int cols, int batch, int devi
 /* Which build the handle runs: *variant = SF_VARIANT_*, *threads = workgroup size, *workgroups_per_stream (1 except
  * for SF_VARIANT_CLUSTER). Any pointer may be NULL. */
 int SF_FN(get_variant)(const sf_handle *h, int *variant, int *threads, int *workgroups_per_stream);
+/* How many workgroups the next sf_process_frame / sf_run_solver launch keeps resident: per compute unit and in total
+ * (the launch grid). The throughput build carries its frame kernel twice -- 4 workgroups per CU at <= 128 registers for
+ * the pure-odometry configuration, 5 per CU at <= 96 registers for the full solver (segmentation_enabled) -- and picks per
+ * launch; everything else has one answer. The CPU oracle reports 1 / 1. Any pointer may be NULL. */
+int SF_FN(get_resident_workgroups)(const sf_handle *h, int *per_cu, int *total);
 void SF_FN(destroy)(sf_handle *h);
 int SF_FN(set_params)(sf_handle *h, const sf_params *p);
 int SF_FN(get_params)(const sf_handle *h, sf_params *p);

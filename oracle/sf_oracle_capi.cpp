@@ -137,6 +137,13 @@ int sfo_get_variant(const sf_handle *h, int *variant, int *threads, int *workgro
     return SF_OK;
 }
 
+int sfo_get_resident_workgroups(const sf_handle *h, int *per_cu, int *total) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    if (per_cu) *per_cu = 1;
+    if (total) *total = 1;
+    return SF_OK;
+}
+
 void sfo_destroy(sf_handle *h) { delete h; }
 
 int sfo_set_params(sf_handle *h, const sf_params *p) {

@@ -96,6 +96,7 @@ SIGNATURES = {
     "create": (C.c_int, [C.POINTER(SfParams), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
     "create_ex": (C.c_int, [C.POINTER(SfParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
     "get_variant": (C.c_int, [_H, _ip, _ip, _ip]),
+    "get_resident_workgroups": (C.c_int, [_H, _ip, _ip]),
     "destroy": (None, [_H]),
     "set_params": (C.c_int, [_H, C.POINTER(SfParams)]),
     "get_params": (C.c_int, [_H, C.POINTER(SfParams)]),
@@ -248,6 +249,12 @@ class Solver:
         v, t, g = C.c_int32(), C.c_int32(), C.c_int32()
         self.api.check(self.api.get_variant(self.h, C.byref(v), C.byref(t), C.byref(g)))
         return {n: k for k, n in VARIANT_NAMES.items()}[v.value], t.value, g.value
+
+    def resident_workgroups(self):
+        """(workgroups per CU, launch grid) of the next frame launch"""
+        p, t = C.c_int32(), C.c_int32()
+        self.api.check(self.api.get_resident_workgroups(self.h, C.byref(p), C.byref(t)))
+        return p.value, t.value
 
     def __del__(self):
         try:

@@ -85,6 +85,7 @@ struct sf_handle {
     KArgs k{};
     int device = 0;
     int max_blocks = 0;
+    int wg_per_cu = 0;
     int max_blocks_o5 = 0;  // throughput build: resident workgroups of the 5-per-CU kernel (0: not used)
     const FrameVariant *fv = &VARIANTS[0];
     std::vector<struct sf_map *> maps;  // live maps created from this handle: sf_destroy releases their memory and orphans them
@@ -192,6 +193,13 @@ static int dev_grow(sf_handle *h, T **p, size_t *capacity, size_t count) {
 static std::mutex g_cluster_mu;
 static hipEvent_t g_cluster_done[64] = {};
 
+// throughput build: the 5-workgroups-per-CU compilation of the frame kernel serves the full solver (Makefile: frame_nt256o5.o)
+static bool use_five_per_cu(const sf_handle *h) {
+    if (!h->max_blocks_o5) return false;
+    if (const char *v = std::getenv("SF_THROUGHPUT_WG_PER_CU")) return v[0] == '5';  // pins one of the two (A/B tooling)
+    return h->k.p.segmentation_enabled != 0;
+}
+
 static int launch(sf_handle *h, int mask, int im_count) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemsetAsync(h->k.queue, 0, sizeof(int), h->stream));
@@ -202,13 +210,9 @@ static int launch(sf_handle *h, int mask, int im_count) {
     }
     int grid = h->cluster_grid ? h->cluster_grid : std::min(h->k.batch, h->max_blocks);
     auto launch_frame = h->fv->launch_frame;
-    if (h->max_blocks_o5) {
-        bool five = h->k.p.segmentation_enabled != 0;
-        if (const char *v = std::getenv("SF_THROUGHPUT_WG_PER_CU")) five = (v[0] == '5');
-        if (five) {
-            launch_frame = sf_launch_frame_nt256o5;
-            grid = std::min(h->k.batch, h->max_blocks_o5);
-        }
+    if (use_five_per_cu(h)) {
+        launch_frame = sf_launch_frame_nt256o5;
+        grid = std::min(h->k.batch, h->max_blocks_o5);
     }
     const bool timed = (mask & ST_SOLVE) != 0;
     if (timed) HIP_TRY(hipEventRecord(h->evk0, h->stream));
@@ -323,6 +327,15 @@ int sf_get_variant(const sf_handle *h, int *variant, int *threads, int *workgrou
     return SF_OK;
 }
 
+int sf_get_resident_workgroups(const sf_handle *h, int *per_cu, int *total) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    const int cus = h->max_blocks / std::max(1, h->wg_per_cu);
+    const bool five = use_five_per_cu(h);
+    if (per_cu) *per_cu = five ? h->max_blocks_o5 / std::max(1, cus) : h->wg_per_cu;
+    if (total) *total = h->cluster_grid ? h->cluster_grid : std::min(h->k.batch, five ? h->max_blocks_o5 : h->max_blocks);
+    return SF_OK;
+}
+
 int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, int variant, sf_handle **out) {
     if (!p || !out || rows < 8 || cols < 8 || batch < 1) return fail(SF_ERR_ARG, "bad argument");
     if (variant < SF_VARIANT_AUTO || variant > SF_VARIANT_CLUSTER) return fail(SF_ERR_ARG, "unknown variant");
@@ -399,6 +412,7 @@ int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, 
     int wg_threads = 0, wg_per_cu = 0;
     h->fv->geometry(&wg_threads, &wg_per_cu);
     h->max_blocks = prop.multiProcessorCount * wg_per_cu;
+    h->wg_per_cu = wg_per_cu;
     if (h->fv->id == SF_VARIANT_THROUGHPUT) {
         // the full solver runs the same source at 5 workgroups per CU (Makefile: frame_nt256o5.o); SF_THROUGHPUT_WG_PER_CU=4|5
         // pins one of the two for every configuration (A/B tooling)

@@ -205,6 +205,33 @@ def test_warp_with_targets_outside_the_tile_windows(hip, ora, pair):
         assert sg.splat_replays() > 0, "the scene did not exercise the replay path"
 
 
+def test_throughput_build_picks_its_kernel_by_configuration(hip, pair):
+    """The throughput build launches the 4-per-CU compilation of the frame kernel for pure odometry and the 5-per-CU one
+    for the full solver (sf_get_resident_workgroups says which); both are covered by the parity tests above, which run with
+    and without segmentation. The same stream must give the same answer whichever of the two runs it."""
+    if hip.default_variant != "throughput":
+        pytest.skip("one compilation per build")
+    pr = pair(seed=5, sphere=True, rows=120, cols=160)
+    seg = make_solver(hip, 120, 160, driver_params(hip), pr, batch=2000)
+    odo = make_solver(hip, 120, 160, driver_params(hip, segmentation_enabled=0, ctf_levels=3), pr, batch=2000)
+    assert seg.resident_workgroups()[0] == 5 and odo.resident_workgroups()[0] == 4
+    assert seg.resident_workgroups()[1] == 5 * odo.resident_workgroups()[1] // 4  # 2000 streams exceed both grids
+    out = {}
+    for n in ("4", "5"):
+        os.environ["SF_THROUGHPUT_WG_PER_CU"] = n
+        try:
+            s = make_solver(hip, 120, 160, driver_params(hip), pr)
+            assert s.resident_workgroups()[0] == int(n)
+            s.build_pyramid(True)
+            s.run_solver(True)
+            s.build_segm_image()
+            out[n] = (s.T().copy(), s.b_image().copy(), s.labels(0).copy(), s.stats().n_irls)
+        finally:
+            del os.environ["SF_THROUGHPUT_WG_PER_CU"]
+    assert np.array_equal(out["4"][2], out["5"][2]) and out["4"][3] == out["5"][3]
+    assert np.array_equal(out["4"][0], out["5"][0]) and np.array_equal(out["4"][1], out["5"][1])
+
+
 def test_edge_cases(hip, ora, pair):
     z = np.zeros((60, 80), np.float32)
     for api in (hip, ora):

@@ -223,6 +223,29 @@ template <class T>
 __device__ __forceinline__ gptr<T> as_global(T *p) {  // every base pointer of a stage is workgroup-uniform
     return uniform_ptr((gptr<T>)p);
 }
+// Element idx >= 0 of an array whose base is workgroup-uniform, addressed as SGPR base + 32-bit unsigned BYTE offset:
+// the form the hardware takes directly (global_load ... v_off, s[base]). `p[idx]` with a signed int costs a sign extension
+// and a 64-bit shift-add in VALU per access -- about 7 % of all VALU instructions of a frame before this was used.
+template <class T>
+__device__ __forceinline__ T gld(gptr<const T> p, int idx) {
+    return *(gptr<const T>)((__attribute__((address_space(1))) const char *)p + (unsigned)idx * (unsigned)sizeof(T));
+}
+template <class T>
+__device__ __forceinline__ T gld(gptr<T> p, int idx) {
+    return *(gptr<const T>)((__attribute__((address_space(1))) const char *)p + (unsigned)idx * (unsigned)sizeof(T));
+}
+template <class T, class V>
+__device__ __forceinline__ void gst(gptr<T> p, int idx, V v) {
+    *(gptr<T>)((__attribute__((address_space(1))) char *)p + (unsigned)idx * (unsigned)sizeof(T)) = (T)v;
+}
+__device__ __forceinline__ void gatomic_add_at(gptr<long long> p, int idx, long long v) {
+    __hip_atomic_fetch_add((gptr<long long>)((__attribute__((address_space(1))) char *)p + (unsigned)idx * 8u), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class P>
+__device__ __forceinline__ long long gld_agent_i64(P p, int idx) {  // agent-scope (L1-bypassing) load of a 64-bit cell
+    return __hip_atomic_load((gptr<const long long>)((__attribute__((address_space(1))) const char *)p + (unsigned)idx * 8u), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void gatomic_add(gptr<long long> p, long long v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -427,8 +450,8 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
         if (replay) {
             if (it == n_tiles) {  // every tile flushed: zero what no window reached; the flags are complete
                 for (int idx = zcol * rows_i + tid; idx < cols_i * rows_i; idx += SF_NT) {
-                    acc_d[idx] = 0;
-                    acc_i[idx] = 0;
+                    gst(acc_d, idx, 0ll);
+                    gst(acc_i, idx, 0ll);
                 }
                 __syncthreads();
             }
@@ -494,8 +517,8 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
             const int need = min(cols_i, wu0 + WIN_U);
             if (need > zcol) {
                 for (int idx = zcol * rows_i + tid; idx < need * rows_i; idx += SF_NT) {
-                    acc_d[idx] = 0;
-                    acc_i[idx] = 0;
+                    gst(acc_d, idx, 0ll);
+                    gst(acc_i, idx, 0ll);
                 }
                 zcol = need;
             }
@@ -514,8 +537,8 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
                 outside = true;
             } else {
                 const int t = v + u * g.rows_i;
-                gatomic_add(acc_d + t, mul_i64_w(df, w));
-                gatomic_add(acc_i + t, mul_packed_w(jf, w));
+                gatomic_add_at(acc_d, t, mul_i64_w(df, w));
+                gatomic_add_at(acc_i, t, mul_packed_w(jf, w));
             }
         };
 #pragma unroll
@@ -559,8 +582,8 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
             if (packed == 0) continue;  // sum(w) >= 1 makes a touched cell non-zero
             const int du = q / WIN_V, dv = q - du * WIN_V;
             const int t = (wv0 + dv) + (wu0 + du) * g.rows_i;
-            gatomic_add(acc_d + t, win.d[q]);
-            gatomic_add(acc_i + t, packed);
+            gatomic_add_at(acc_d, t, win.d[q]);
+            gatomic_add_at(acc_i, t, packed);
         }
         __syncthreads();  // before the next tile clears the window
     }

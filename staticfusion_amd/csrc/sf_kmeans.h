@@ -183,13 +183,13 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
 #pragma unroll
             for (int k = 0; k < SF_LOAD_BATCH; k++) {
                 const int idx = min(base + k * SF_NT, n1 - 1);
-                dz[k] = depth[o1 + idx];
-                sl[k] = seed_lab[idx];
+                dz[k] = gld(depth, o1 + idx);
+                sl[k] = gld(seed_lab, idx);
             }
 #pragma unroll
             for (int k = 0; k < SF_LOAD_BATCH; k++) {
                 const int idx = base + k * SF_NT;
-                if (idx < n1) labels[o1 + idx] = (uint8_t)((dz[k] != 0.f) ? sl[k] : SF_NC);
+                if (idx < n1) gst(labels, o1 + idx, (uint8_t)((dz[k] != 0.f) ? sl[k] : SF_NC));
             }
         }
     }
@@ -204,8 +204,8 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
 #pragma unroll
             for (int k = 0; k < SF_LOAD_BATCH; k++) {
                 const int idx = min(base + k * SF_NT, n1 - 1);
-                lb[k] = labels[o1 + idx];
-                bits[k] = __float_as_uint(depth[o1 + idx]);
+                lb[k] = gld(labels, o1 + idx);
+                bits[k] = __float_as_uint(gld(depth, o1 + idx));
             }
 #pragma unroll
             for (int k = 0; k < SF_LOAD_BATCH; k++)
@@ -277,8 +277,8 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
 #pragma unroll
         for (int k = 0; k < SF_LOAD_BATCH; k++) {  // wave w owns pixels [256 w, 256 (w + 1)) of the chunk, k-major
             const int idx = min(wave * (64 * SF_LOAD_BATCH) + k * 64 + lane, n1 - 1);
-            nz[k] = depth[o1 + idx];
-            nold[k] = labels[o1 + idx];
+            nz[k] = gld(depth, o1 + idx);
+            nold[k] = gld(labels, o1 + idx);
         }
         for (int ch = 0; ch < n_chunks; ch++) {
             const int base = ch * KM_CHUNK + wave * (64 * SF_LOAD_BATCH);
@@ -294,8 +294,8 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
 #pragma unroll
                 for (int k = 0; k < SF_LOAD_BATCH; k++) {
                     const int idx = min(base + KM_CHUNK + k * 64 + lane, n1 - 1);
-                    nz[k] = depth[o1 + idx];
-                    nold[k] = labels[o1 + idx];
+                    nz[k] = gld(depth, o1 + idx);
+                    nold[k] = gld(labels, o1 + idx);
                 }
             }
 #pragma unroll
@@ -328,7 +328,7 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
             for (int k = 0; k < SF_LOAD_BATCH; k++) {
                 const int idx = base + k * 64 + lane;
                 rank[k] = 0;
-                if (valid[k]) labels[o1 + idx] = (uint8_t)best[k];
+                if (valid[k]) gst(labels, o1 + idx, (uint8_t)best[k]);
                 unsigned long long rem = __ballot(valid[k]);
                 while (rem) {
                     const int src = __ffsll((long long)rem) - 1;
@@ -476,10 +476,10 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
                 in[q] = (blk0 + q < n_blocks) && u < cols0 && v < rows0;
                 const int uc = min(u, cols0 - 1), vc = min(v, rows0 - 1);
                 pidx[q] = vc + uc * rows0;
-                pz[q] = depth[pidx[q]];
+                pz[q] = gld(depth, pidx[q]);
                 px[q] = coord_x(lc0, uc, pz[q]);
                 py[q] = coord_y(lc0, vc, pz[q]);
-                low[q] = labels[o1 + (vc / 2) + (uc / 2) * rows_km];
+                low[q] = gld(labels, o1 + (vc / 2) + (uc / 2) * rows_km);
             }
             bool act[SF_LOAD_BATCH];
             int start[SF_LOAD_BATCH], lab[SF_LOAD_BATCH];
@@ -491,7 +491,7 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
             km_search_n<SF_LOAD_BATCH>(s, start, pz, px, py, act, lab);
 #pragma unroll
             for (int q = 0; q < SF_LOAD_BATCH; q++)
-                if (in[q]) labels[pidx[q]] = (uint8_t)(act[q] ? lab[q] : SF_NC);
+                if (in[q]) gst(labels, pidx[q], (uint8_t)(act[q] ? lab[q] : SF_NC));
         }
     }
     if (tid < SF_NC) s.conn[tid] = 1u << tid;
@@ -512,12 +512,12 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
                 split_uv(lc0, idx, uu[q], vv[q]);
                 in[q] = (base + q * SF_NT < n0) && uu[q] < cols0 - 1 && vv[q] < rows0 - 1;
                 const int i1 = in[q] ? idx + 1 : idx, i2 = in[q] ? idx + rows0 : idx;  // the last row / column has no neighbour
-                dz[q] = depth[idx];
-                dzd[q] = depth[i1];
-                dzr[q] = depth[i2];
-                la[q] = labels[idx];
-                ld[q] = labels[i1];
-                lr[q] = labels[i2];
+                dz[q] = gld(depth, idx);
+                dzd[q] = gld(depth, i1);
+                dzr[q] = gld(depth, i2);
+                la[q] = gld(labels, idx);
+                ld[q] = gld(labels, i1);
+                lr[q] = gld(labels, i2);
             }
 #pragma unroll
             for (int q = 0; q < SF_LOAD_BATCH; q++) {
@@ -551,7 +551,7 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
         const int n = a.ln[L], o = a.loff[L];
         const LevelCoord lc = level_coord(a, L);
         for (int idx = tid; idx < n; idx += SF_NT) {
-            const float pz = depth[o + idx];
+            const float pz = gld(depth, o + idx);
             int lab = SF_NC;
             if (pz != 0.f) {
                 int u, v;
@@ -569,7 +569,7 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
                 }
                 lab = label;
             }
-            labels[o + idx] = (uint8_t)lab;
+            gst(labels, o + idx, (uint8_t)lab);
         }
     }
     __syncthreads();

@@ -52,8 +52,8 @@ __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, int which, int
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const int col = min(max(u2 - 1 + c, 0), 2 * cols_i - 1);  // clamped: a border pixel does not use what is outside
-                    const vfloat2 dd = *(gcf2 *)(d_prev + (v2 + col * rows_p));
-                    const vfloat2 ii = *(gcf2 *)(i_prev + (v2 + col * rows_p));
+                    const vfloat2 dd = *(gcf2 *)((__attribute__((address_space(1))) const char *)d_prev + (unsigned)(v2 + col * rows_p) * 4u);
+                    const vfloat2 ii = *(gcf2 *)((__attribute__((address_space(1))) const char *)i_prev + (unsigned)(v2 + col * rows_p) * 4u);
                     db[1 + 4 * c] = dd.x;
                     db[2 + 4 * c] = dd.y;
                     ib[1 + 4 * c] = ii.x;
@@ -119,8 +119,8 @@ __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, int which, int
                         }
                     dout = (cont != 0) ? new_d / float(cont) : 0.f;
                 }
-                d_here[idx] = dout;
-                i_here[idx] = iout;  // xx / yy (:385-386) are recomputed by their consumers: level_coord()
+                gst(d_here, idx, dout);
+                gst(i_here, idx, iout);  // xx / yy (:385-386) are recomputed by their consumers: level_coord()
             }
             }
         }  // level 0 is the input itself

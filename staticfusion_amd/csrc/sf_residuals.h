@@ -18,7 +18,7 @@ struct ResShared {
 
 __device__ __forceinline__ int level0_label(const KArgs &a, gptr<const uint8_t> labels0, int idx) {
     // without segmentation the reference's clusterAllocation[0] stays at its constructor value 0
-    return a.p.segmentation_enabled ? (int)labels0[idx] : 0;
+    return a.p.segmentation_enabled ? (int)gld(labels0, idx) : 0;
 }
 
 __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, bool push, LDS ResShared &s, LDS ClusterShared &cs, int tid) {
@@ -60,8 +60,8 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
             __hip_atomic_store(acc_d + idx, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(acc_i + idx, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            acc_d[idx] = 0;
-            acc_i[idx] = 0;
+            gst(acc_d, idx, 0ll);
+            gst(acc_i, idx, 0ll);
         }
     }
     cluster_rendezvous(cs, tid);
@@ -83,9 +83,9 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
         gptr<const float> dbuf, ibuf, dcur;
         float inv_f_i, disp_u_i, disp_v_i;
         __device__ __forceinline__ bool load(int v, int u, int idx, float &z, float &xr, float &yr, float &iw) const {
-            z = dbuf[idx];
-            iw = ibuf[idx];
-            const float dc = dcur[idx];
+            z = gld(dbuf, idx);
+            iw = gld(ibuf, idx);
+            const float dc = gld(dcur, idx);
             xr = (inv_f_i * (float(u) - disp_u_i)) * z;  // xxBuffer / yyBuffer (:922-926)
             yr = (inv_f_i * (float(v) - disp_v_i)) * z;
             return z != 0.f && dc != 0.f;
@@ -108,11 +108,11 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
 #pragma unroll
         for (int k = 0; k < SF_LOAD_BATCH; k++) {
             const int idx = min(base + k * SF_NT, px_end - 1);
-            sd[k] = __hip_atomic_load(acc_d + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            si[k] = __hip_atomic_load(acc_i + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            dc[k] = dcur[idx];
-            db[k] = dbuf[idx];
-            ic[k] = icur[idx];
+            sd[k] = gld_agent_i64(acc_d, idx);
+            si[k] = gld_agent_i64(acc_i, idx);
+            dc[k] = gld(dcur, idx);
+            db[k] = gld(dbuf, idx);
+            ic[k] = gld(icur, idx);
             lb[k] = level0_label(a, labels0, idx);
         }
         if (push) {
@@ -120,8 +120,8 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
             for (int k = 0; k < SF_LOAD_BATCH; k++) {
                 const int idx = base + k * SF_NT;
                 if (idx < px_end) {
-                    dpush[idx] = dc[k];
-                    ipush[idx] = ic[k];
+                    gst(dpush, idx, dc[k]);
+                    gst(ipush, idx, ic[k]);
                 }
             }
         }
@@ -190,7 +190,7 @@ __device__ __noinline__ void stage_segm_image(const KArgs &a, int b, int tid, LD
                 bb = std_max(0.f, std_min(1.f, st.b_segm[lab[k]]));
                 if ((double)st.cluster_res[lab[k]] < 0.017) bb = std_max(bb, 1.0f - bb);
             }
-            out[idx] = bb;
+            gst(out, idx, bb);
         }
     }
 }
@@ -209,17 +209,20 @@ __device__ __noinline__ void stage_push_history(const KArgs &a, int b, int im_co
         typedef __attribute__((address_space(1))) f4 gf4;
         const int i0 = base, i1 = base + SF_NT * 4;
         const bool in1 = i1 < n;
-        const f4 d0 = *(gcf4 *)(dcur + i0), c0 = *(gcf4 *)(icur + i0);
+        typedef __attribute__((address_space(1))) const char gcc;
+        typedef __attribute__((address_space(1))) char gc;
+        const unsigned o0 = (unsigned)i0 * 4u, o1 = (unsigned)i1 * 4u;  // SGPR base + 32-bit byte offset (gld, sf_device_common.h)
+        const f4 d0 = *(gcf4 *)((gcc *)dcur + o0), c0 = *(gcf4 *)((gcc *)icur + o0);
         f4 d1 = d0, c1 = c0;
         if (in1) {
-            d1 = *(gcf4 *)(dcur + i1);
-            c1 = *(gcf4 *)(icur + i1);
+            d1 = *(gcf4 *)((gcc *)dcur + o1);
+            c1 = *(gcf4 *)((gcc *)icur + o1);
         }
-        *(gf4 *)(dbuf + i0) = d0;
-        *(gf4 *)(ibuf + i0) = c0;
+        *(gf4 *)((gc *)dbuf + o0) = d0;
+        *(gf4 *)((gc *)ibuf + o0) = c0;
         if (in1) {
-            *(gf4 *)(dbuf + i1) = d1;
-            *(gf4 *)(ibuf + i1) = c1;
+            *(gf4 *)((gc *)dbuf + o1) = d1;
+            *(gf4 *)((gc *)ibuf + o1) = c1;
         }
     }
     if (tid < 16 && cl_writer(cs)) st.hist_T[slot][tid] = st.T[tid];

@@ -225,8 +225,8 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
             __hip_atomic_store(acc_d + idx, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(acc_i + idx, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            acc_d[idx] = 0;
-            acc_i[idx] = 0;
+            gst(acc_d, idx, 0ll);
+            gst(acc_i, idx, 0ll);
         }
     }
     cluster_rendezvous(cs, tid);  // the accumulators are zero everywhere before anybody splats into them (and s.Tinv is set)
@@ -247,8 +247,8 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
         gptr<const float> d, i;
         LevelCoord lc;
         __device__ __forceinline__ bool load(int v, int u, int idx, float &z, float &xr, float &yr, float &iw) const {
-            z = d[idx];
-            iw = i[idx];
+            z = gld(d, idx);
+            iw = gld(i, idx);
             xr = coord_x(lc, u, z);  // xxPrediction / yyPrediction of the pyramid (:385-386)
             yr = coord_y(lc, v, z);
             return z != 0.f;
@@ -313,20 +313,20 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
             const int v = ptv0 - 1 + lv, u = ptu0 - 1 + lu;                                                           \
             const bool inside = e < TILE_N && v >= 0 && v < rows_i && u >= 0 && u < cols_i;                           \
             const int idx = inside ? v + u * rows_i : 0;                                                              \
-            pf_dn[q] = dnew[idx];                                                                                     \
-            pf_in[q] = inew[idx];                                                                                     \
+            pf_dn[q] = gld(dnew, idx);                                                                                    \
+            pf_in[q] = gld(inew, idx);                                                                                    \
             if (first) { /* Warped := Pred (reference FrontEnd.cpp:1103-1110): carry the float bits in pf_ad */      \
-                const unsigned lo = __float_as_uint(dpred[idx]), hi = __float_as_uint(ipred[idx]);                    \
+                const unsigned lo = __float_as_uint(gld(dpred, idx)), hi = __float_as_uint(gld(ipred, idx));                    \
                 pf_ad[q] = (long long)(((unsigned long long)hi << 32) | lo);                                          \
             } else {                                                                                                  \
-                pf_ad[q] = __hip_atomic_load(acc_d + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                \
-                pf_ai[q] = __hip_atomic_load(acc_i + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                \
+                pf_ad[q] = gld_agent_i64(acc_d, idx);                \
+                pf_ai[q] = gld_agent_i64(acc_i, idx);                \
             }                                                                                                         \
         }                                                                                                             \
         if (seg) {                                                                                                    \
             _Pragma("unroll") for (int k = 0; k < TILE_CPX; k++) {                                                   \
                 const int v = ptv0 + lane, u = ptu0 + wave + k * SF_NW;                                               \
-                pf_lab[k] = (int)labels[(v < rows_i && u < cols_i) ? v + u * rows_i : 0];                             \
+                pf_lab[k] = (int)gld(labels, (v < rows_i && u < cols_i) ? v + u * rows_i : 0);                             \
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
@@ -420,13 +420,13 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                 // (a point behind the camera that still projects into the image: a diverged pose) stays negative = not valid;
                 // the segmentation prior then sees its magnitude (solve_seg_prior), the one place where this differs from the
                 // reference, which carries such a pixel through with its sign
-                rec[R_DW][idx] = valid ? dw : -fabsf(dw);
-                rec[R_DCU][idx] = dcu_;
-                rec[R_DCV][idx] = dcv_;
-                rec[R_DCT][idx] = (valid || dbg) ? dct_ : 0.f;  // 0 outside validPixels: the passes run branch-free over every pixel
-                rec[R_DDU][idx] = ddu_;
-                rec[R_DDV][idx] = ddv_;
-                if (seg || dbg) rec_lab[idx] = valid ? (uint8_t)(seg ? lab : 0) : (uint8_t)SF_INVALID_LABEL;
+                gst(rec[R_DW], idx, valid ? dw : -fabsf(dw));
+                gst(rec[R_DCU], idx, dcu_);
+                gst(rec[R_DCV], idx, dcv_);
+                gst(rec[R_DCT], idx, (valid || dbg) ? dct_ : 0.f);  // 0 outside validPixels: the passes run branch-free over every pixel
+                gst(rec[R_DDU], idx, ddu_);
+                gst(rec[R_DDV], idx, ddv_);
+                if (seg || dbg) gst(rec_lab, idx, valid ? (uint8_t)(seg ? lab : 0) : (uint8_t)SF_INVALID_LABEL);
                 if (dbg) {
                     float d_i = 0.f, x_i = 0.f, y_i = 0.f, xw = 0.f, yw = 0.f;
                     const LevelCoord lcd = level_coord(a, L);

@@ -226,24 +226,31 @@ __device__ __forceinline__ gptr<T> as_global(T *p) {  // every base pointer of a
 // Element idx >= 0 of an array whose base is workgroup-uniform, addressed as SGPR base + 32-bit unsigned BYTE offset:
 // the form the hardware takes directly (global_load ... v_off, s[base]). `p[idx]` with a signed int costs a sign extension
 // and a 64-bit shift-add in VALU per access -- about 7 % of all VALU instructions of a frame before this was used.
+// (The offset passes through an empty asm so that two accesses with the same index do not share one zero-extension node:
+// instruction selection folds the extension into the addressing mode only when the access is its single user.)
+__device__ __forceinline__ unsigned gbyte_off(int idx, unsigned elem) {
+    unsigned off = (unsigned)idx * elem;
+    asm("" : "+v"(off));
+    return off;
+}
 template <class T>
 __device__ __forceinline__ T gld(gptr<const T> p, int idx) {
-    return *(gptr<const T>)((__attribute__((address_space(1))) const char *)p + (unsigned)idx * (unsigned)sizeof(T));
+    return *(gptr<const T>)((__attribute__((address_space(1))) const char *)p + gbyte_off(idx, (unsigned)sizeof(T)));
 }
 template <class T>
 __device__ __forceinline__ T gld(gptr<T> p, int idx) {
-    return *(gptr<const T>)((__attribute__((address_space(1))) const char *)p + (unsigned)idx * (unsigned)sizeof(T));
+    return *(gptr<const T>)((__attribute__((address_space(1))) const char *)p + gbyte_off(idx, (unsigned)sizeof(T)));
 }
 template <class T, class V>
 __device__ __forceinline__ void gst(gptr<T> p, int idx, V v) {
-    *(gptr<T>)((__attribute__((address_space(1))) char *)p + (unsigned)idx * (unsigned)sizeof(T)) = (T)v;
+    *(gptr<T>)((__attribute__((address_space(1))) char *)p + gbyte_off(idx, (unsigned)sizeof(T))) = (T)v;
 }
 __device__ __forceinline__ void gatomic_add_at(gptr<long long> p, int idx, long long v) {
-    __hip_atomic_fetch_add((gptr<long long>)((__attribute__((address_space(1))) char *)p + (unsigned)idx * 8u), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add((gptr<long long>)((__attribute__((address_space(1))) char *)p + gbyte_off(idx, 8u)), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <class P>
 __device__ __forceinline__ long long gld_agent_i64(P p, int idx) {  // agent-scope (L1-bypassing) load of a 64-bit cell
-    return __hip_atomic_load((gptr<const long long>)((__attribute__((address_space(1))) const char *)p + (unsigned)idx * 8u), __ATOMIC_RELAXED,
+    return __hip_atomic_load((gptr<const long long>)((__attribute__((address_space(1))) const char *)p + gbyte_off(idx, 8u)), __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void gatomic_add(gptr<long long> p, long long v) {

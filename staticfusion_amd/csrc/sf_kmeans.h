@@ -265,6 +265,9 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
     // sums front to back (KMeans.cpp:215-221: centers_b.col(best_label) += p in pixel order; strictly sequential
     // per sum, parallel across sums). Nothing but the labels goes back to memory.
     const int n_chunks = (n1 + KM_CHUNK - 1) / KM_CHUNK;
+    // pixel index steps as (column, row) steps: + 64 between a lane's pixels, + KM_CHUNK - 64 SF_LOAD_BATCH to the next chunk
+    const int step64_u = 64 / rows_km, step64_v = 64 - step64_u * rows_km;
+    const int stepc = KM_CHUNK - 64 * SF_LOAD_BATCH, stepc_u = stepc / rows_km, stepc_v = stepc - stepc_u * rows_km;
     int iters = 0;
     for (int it = 0; it < 9; it++) {
         iters++;
@@ -280,6 +283,8 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
             nz[k] = gld(depth, o1 + idx);
             nold[k] = gld(labels, o1 + idx);
         }
+        int cu, cv;  // column / row of the lane's next pixel (beyond the level at the end: such pixels are not valid)
+        split_uv(lc1, wave * (64 * SF_LOAD_BATCH) + lane, cu, cv);
         for (int ch = 0; ch < n_chunks; ch++) {
             const int base = ch * KM_CHUNK + wave * (64 * SF_LOAD_BATCH);
             float px[SF_LOAD_BATCH], py[SF_LOAD_BATCH];
@@ -301,12 +306,22 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
 #pragma unroll
             for (int k = 0; k < SF_LOAD_BATCH; k++) {
                 const int idx = base + k * 64 + lane;
-                int u, v;
-                split_uv(lc1, min(idx, n1 - 1), u, v);
-                px[k] = coord_x(lc1, u, pz[k]);
-                py[k] = coord_y(lc1, v, pz[k]);
+                px[k] = coord_x(lc1, cu, pz[k]);  // (cu, cv) = column / row of pixel idx, stepped instead of divided
+                py[k] = coord_y(lc1, cv, pz[k]);
                 valid[k] = (idx < n1) && pz[k] != 0.f;
                 old[k] = valid[k] ? old[k] : 0;  // a safe table row for pixels that are not searched
+                cv += step64_v;
+                cu += step64_u;
+                if (cv >= rows_km) {
+                    cv -= rows_km;
+                    cu++;
+                }
+            }
+            cv += stepc_v;  // from idx + 4 * 64 on to the lane's first pixel of the next chunk
+            cu += stepc_u;
+            if (cv >= rows_km) {
+                cv -= rows_km;
+                cu++;
             }
 #ifdef SF_KM_FINE_PROFILE
             int trips = 0;

@@ -23,6 +23,7 @@ __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, int which, int
 
     for (int L = 0; L < a.levels; L++) {
         const int rows_i = a.lrows[L], cols_i = a.lcols[L], n = a.ln[L];
+        const LevelCoord lcL = level_coord(a, L);
         if (L > 0) cluster_barrier(cs, tid);  // level L-1 complete (written by this workgroup / by the cluster's workgroups)
         for (int si = 0; si < 2; si++) {
             if (L == 0 || !((which >> si) & 1)) continue;
@@ -45,7 +46,8 @@ __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, int which, int
                 const int idx = chunk * 62 + lane - 1;
                 const bool produce = lane >= 1 && lane <= 62 && idx < n;
                 const int idc = min(max(idx, 0), n - 1);
-                const int u = idc / rows_i, v = idc - u * rows_i;
+                int u, v;
+                split_uv(lcL, idc, u, v);  // reciprocal multiply + correction instead of an integer division
                 const int u2 = 2 * u, v2 = 2 * v;
                 float dout, iout;
                 float db[16], ib[16];

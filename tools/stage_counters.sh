@@ -17,4 +17,9 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $set -d $OUT/pmc$i -o pmc -- $CMD > $OUT/pmc$i.log 2>&1
 done
-python tools/stage_counters_sum.py $OUT 3
+python tools/stage_counters_sum.py $OUT 3 > /dev/null
+python - <<PY
+import json
+r = json.load(open("$OUT/counters.json")); r["batch"] = $B; r["workload"] = "$WL"; r["variant"] = "$VAR"
+json.dump(r, open("$OUT/counters.json", "w"), indent=1); print(json.dumps(r, indent=1))
+PY

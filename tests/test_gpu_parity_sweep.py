@@ -13,7 +13,16 @@ from test_gpu_parity import POSE_TOL, assert_traces_match, solve_both
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", range(10))
+def _sweep_cases():
+    """10 cases in the suite; SF_SWEEP_CASES=first:last runs another range of the generator (one-off hunts)"""
+    spec = os.environ.get("SF_SWEEP_CASES")
+    if not spec:
+        return range(10)
+    first, last = (int(x) for x in spec.split(":"))
+    return range(first, last)
+
+
+@pytest.mark.parametrize("case", _sweep_cases())
 def test_random_parameter_sweep(hip, ora, pair, case):
     """parameters drawn from the ranges the drivers / constructor use (StaticFusion-datasets.cpp:79-94, FrontEnd.cpp:57-76)"""
     g = LCG64(9000 + case)

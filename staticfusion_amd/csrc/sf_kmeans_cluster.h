@@ -5,9 +5,11 @@
 //   assignment     (seed labels, every Lloyd iteration, the level-0 labels) is split by PIXELS: workgroup r labels the
 //                  r-th share of the level, four consecutive pixels per thread, one 32-bit label word per thread.
 //   ordered sums   KMeans.cpp:215-221 adds the members of a cluster in pixel order in float32: a sum cannot be split.
-//                  They are split by CLUSTER instead: workgroup r owns the clusters c with c % G == r, walks ALL labels of
+//                  They are split by CLUSTER instead: workgroup r owns the clusters c with c % G == r, walks the labels of
 //                  the level in pixel order (chunks of 4096 pixels, a quad per thread), compacts the members of its
-//                  clusters into LDS in that order and continues its 3 x (24 / G) running sums front to back.
+//                  clusters into LDS in that order and continues its 3 x (24 / G) running sums front to back. It walks only
+//                  the shares that hold members of its clusters: the rendezvous after the assignment carries a 24-bit mask
+//                  per workgroup ("labels that occur in my share"); a compact cluster spans 4-5 of 24 shares.
 //   medians        of the seeds (radix select) likewise by seed ownership.
 // Label words that another workgroup reads within the launch are written and read with agent-scope (sc1) accesses and
 // handed over through a cluster_gather rendezvous after the writing waves have drained: no fence needed
@@ -25,6 +27,7 @@
 struct KmClShared {
     alignas(16) float run[3][KMC_CHUNK];  // (z, x, y) of the members of this workgroup's clusters in the chunk: cluster by cluster, pixel order
     int wcnt[KMC_R][SF_NW][KMC_MAX_OWN];
+    unsigned present;  // labels that occur in this workgroup's share of level 1 after an assignment (bit l = label l)
 };
 struct KmClusterShared {
     KmShared km;
@@ -41,11 +44,22 @@ __device__ __forceinline__ unsigned ld_byte_agent(gcu8b *p) {
 
 // the label words this workgroup wrote have left; everybody has written theirs
 __device__ __forceinline__ void labels_rendezvous(LDS ClusterShared &cs, int tid) { cluster_rendezvous(cs, tid); }
+// The same hand-over after a Lloyd assignment, with a payload: which labels occur in this workgroup's share of the level.
+// Afterwards cs.all[p] holds the mask of workgroup p's share: the owner of a cluster collects its members from the shares
+// that contain any (a compact cluster spans 4-5 of 24 shares) instead of walking the whole level.
+__device__ __forceinline__ void labels_rendezvous_with_mask(LDS ClusterShared &cs, LDS unsigned &present, int tid) {
+    if (cl_G(cs) > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // present complete
+    if (tid == 0) cs.in[0] = present;
+    cluster_gather(cs, 1, tid);
+}
 
 // One Lloyd iteration's ordered sums of the clusters this workgroup owns (KMeans.cpp:215-221), in pixel order, and the new
 // centres of those clusters -> cs.in[4 q + r] (r < 3: coordinate, 3: member count). Its own function: its own registers.
+// R = chunks loaded and ranked together; [qlo, qhi) = the quads to walk (the shares that hold members of the owned clusters)
+template <int R>
 __device__ __noinline__ void kmc_collect_and_sum(LDS KmClShared &kc, LDS ClusterShared &cs, gu32w *lab1w_, const __attribute__((address_space(1))) void *depth1q_,
-                                                 const LevelCoord lc1, int nq1, int n_chunks, int G, int rank, int nown, int tid,
+                                                 const LevelCoord lc1, int qlo, int qhi, int G, int rank, int nown, int tid,
                                                  long long *prof_out) {
     typedef __attribute__((address_space(1))) const vfloat4 gcf4;
     gu32w *lab1w = uniform_ptr(lab1w_);
@@ -54,8 +68,9 @@ __device__ __noinline__ void kmc_collect_and_sum(LDS KmClShared &kc, LDS Cluster
     G = uniform_i(G);
     rank = uniform_i(rank);
     nown = uniform_i(nown);
-    nq1 = uniform_i(nq1);
-    n_chunks = uniform_i(n_chunks);
+    qlo = uniform_i(qlo);
+    qhi = uniform_i(qhi);
+    const int n_chunks = (qhi - qlo + SF_NT - 1) / SF_NT;
 #ifdef SF_KMC_FINE
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tph = clock64();
 #define PH(i) do { if (tid == 0) { const long long n_ = clock64(); ph[i] += n_ - tph; tph = n_; } } while (0)
@@ -63,21 +78,21 @@ __device__ __noinline__ void kmc_collect_and_sum(LDS KmClShared &kc, LDS Cluster
 #define PH(i) do {} while (0)
 #endif
         // ---- ordered sums of the clusters this workgroup owns (KMeans.cpp:215-221), in pixel order.
-        // KMC_R chunks (a quad of consecutive pixels per thread and chunk) are loaded and ranked together; the members of the
+        // R chunks (a quad of consecutive pixels per thread and chunk) are loaded and ranked together; the members of the
         // owned clusters are then compacted into LDS and added GROUP by group, a group being as many consecutive chunks as fit
         // the LDS runs (at QVGA the whole level in one go unless this workgroup's clusters hold more than KMC_CHUNK pixels):
         // two barriers and one long front-to-back pass per group instead of per chunk.
         float acc = 0.f;  // thread (q, r) = tid < 3 nown: running sum of coordinate r over the members of cluster rank + q G
         int total = 0;    // ... and the member count (all three threads of a cluster count)
-        for (int ch0 = 0; ch0 < n_chunks; ch0 += KMC_R) {
+        for (int ch0 = 0; ch0 < n_chunks; ch0 += R) {
             // per chunk only the quad's label word stays in a register; which pixels are members of an owned cluster is
             // re-derived from it where needed and the depth of a member is loaded when it is scattered (registers: the
             // function must not spill)
-            unsigned word[KMC_R];
+            unsigned word[R];
 #pragma unroll
-            for (int c5 = 0; c5 < KMC_R; c5++) {
-                const int q = (ch0 + c5) * SF_NT + tid;
-                word[c5] = (q < nq1) ? ld_word_agent(lab1w + q) : 0xffffffffu;  // label 255: nobody's
+            for (int c5 = 0; c5 < R; c5++) {
+                const int q = qlo + (ch0 + c5) * SF_NT + tid;
+                word[c5] = (q < qhi) ? ld_word_agent(lab1w + q) : 0xffffffffu;  // label 255: nobody's
             }
             // own index (0 .. nown-1) of pixel k of a quad, or -1. A label < 24 implies a valid depth (invalid pixels carry 24).
             auto own_index = [&](unsigned w, int k) -> int {
@@ -87,7 +102,7 @@ __device__ __noinline__ void kmc_collect_and_sum(LDS KmClShared &kc, LDS Cluster
             const unsigned long long lt = (1ull << lane) - 1ull;
             // the wave's member counts per chunk and owned cluster (lane c < nown holds cluster c's)
 #pragma unroll
-            for (int c5 = 0; c5 < KMC_R; c5++) {
+            for (int c5 = 0; c5 < R; c5++) {
                 int cnt_lane = 0;
                 for (int c = 0; c < nown; c++) {
                     int tot = 0;
@@ -101,18 +116,18 @@ __device__ __noinline__ void kmc_collect_and_sum(LDS KmClShared &kc, LDS Cluster
             __syncthreads();  // also: the previous group's sums have consumed kc.run
             PH(1);
             // the depths of the quads: issued now, in flight during the offset arithmetic, consumed by the scatter
-            vfloat4 dz4[KMC_R];
+            vfloat4 dz4[R];
 #pragma unroll
-            for (int c5 = 0; c5 < KMC_R; c5++) {
-                const int q = (ch0 + c5) * SF_NT + tid;
-                dz4[c5] = depth1q[(q < nq1) ? q : 0];
+            for (int c5 = 0; c5 < R; c5++) {
+                const int q = qlo + (ch0 + c5) * SF_NT + tid;
+                dz4[c5] = depth1q[(q < qhi) ? q : 0];
             }
             // members of cluster c per chunk in earlier waves / in the whole chunk: lane w reads wave w's count, a DPP scan
             // over the first 16 lanes gives every wave's prefix (one LDS read per (chunk, cluster) instead of one per wave);
             // the results go back to the layout "lane c holds cluster c's numbers"
-            int before[KMC_R], members[KMC_R], chunk_all[KMC_R];
+            int before[R], members[R], chunk_all[R];
 #pragma unroll
-            for (int c5 = 0; c5 < KMC_R; c5++) {
+            for (int c5 = 0; c5 < R; c5++) {
                 before[c5] = 0;
                 members[c5] = 0;
                 chunk_all[c5] = 0;
@@ -135,10 +150,10 @@ __device__ __noinline__ void kmc_collect_and_sum(LDS KmClShared &kc, LDS Cluster
             PH(2);
             // groups of consecutive chunks whose members (all owned clusters together) fit the LDS runs
             int g0 = 0;
-            while (g0 < KMC_R) {  // uniform: every lane derives the same group bounds from the same counts
+            while (g0 < R) {  // uniform: every lane derives the same group bounds from the same counts
                 int g1 = g0, fill = 0;
 #pragma unroll
-                for (int c5 = 0; c5 < KMC_R; c5++) {
+                for (int c5 = 0; c5 < R; c5++) {
                     if (c5 >= g0 && c5 == g1 && (fill + chunk_all[c5] <= KMC_CHUNK || g1 == g0)) {
                         fill += chunk_all[c5];
                         g1 = c5 + 1;
@@ -147,7 +162,7 @@ __device__ __noinline__ void kmc_collect_and_sum(LDS KmClShared &kc, LDS Cluster
                 // within the group: cluster c's run = its members of chunk g0, then of chunk g0 + 1, ...
                 int grp_members = 0;
 #pragma unroll
-                for (int c5 = 0; c5 < KMC_R; c5++) grp_members += (c5 >= g0 && c5 < g1) ? members[c5] : 0;
+                for (int c5 = 0; c5 < R; c5++) grp_members += (c5 >= g0 && c5 < g1) ? members[c5] : 0;
                 int incl = grp_members;  // inclusive scan over the owned clusters (nown <= 12: one DPP row)
                 incl += dpp_i32<0x111, 0xf>(incl);
                 incl += dpp_i32<0x112, 0xf>(incl);
@@ -161,14 +176,14 @@ __device__ __noinline__ void kmc_collect_and_sum(LDS KmClShared &kc, LDS Cluster
                     int bef5 = before[0], mem5 = members[0];
                     vfloat4 d5 = dz4[0];
 #pragma unroll
-                    for (int e = 1; e < KMC_R; e++) {
+                    for (int e = 1; e < R; e++) {
                         w5 = (c5 == e) ? word[e] : w5;
                         bef5 = (c5 == e) ? before[e] : bef5;
                         mem5 = (c5 == e) ? members[e] : mem5;
                         d5 = (c5 == e) ? dz4[e] : d5;
                     }
                     const int my_base = run_start + earlier + bef5;  // lane c: where this wave's members of cluster c go
-                    const int q = (ch0 + c5) * SF_NT + tid;
+                    const int q = qlo + (ch0 + c5) * SF_NT + tid;
                     int qk[4], rk[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -262,7 +277,7 @@ __device__ __noinline__ void kmc_collect_and_sum(LDS KmClShared &kc, LDS Cluster
                 }
                 PH(5);
                 g0 = g1;
-                if (g0 < KMC_R) __syncthreads();  // the next group's scatter may overwrite the runs
+                if (g0 < R) __syncthreads();  // the next group's scatter may overwrite the runs
             }
         }
         // ---- the owned centres -> cs.in (KMeans.cpp:219-226)
@@ -406,10 +421,10 @@ __device__ __noinline__ void stage_kmeans_cluster(const KArgs &a, int b, LDS KmC
     KMC_MARK(PF_KM_INIT);
 
     // ------------------------------------------------------------------ Lloyd iterations (K2)
-    const int n_chunks = (n1 + KMC_CHUNK - 1) / KMC_CHUNK;
     int iters = 0;
     for (int it = 0; it < 9; it++) {
         iters++;
+        if (tid == 0) kc.present = 0;  // ordered before the assignment loop by the barriers of km_sort_centres
         km_sort_centres(s, tid);
         KMC_MARK(PF_KM_SORT);
         // ---- assignment of this workgroup's share (KMeans.cpp:187-213)
@@ -432,15 +447,39 @@ __device__ __noinline__ void stage_kmeans_cluster(const KArgs &a, int b, LDS KmC
                 old[k] = valid[k] ? (int)((word >> (8 * k)) & 255u) : 0;
             }
             km_search_n<4>(s, old, pz, px, py, valid, best);
-            unsigned out = 0;
+            unsigned out = 0, mask = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) out |= (valid[k] ? (unsigned)best[k] : ((word >> (8 * k)) & 255u)) << (8 * k);
-            if (in) st_word_agent(lab1w + q, out);
+            for (int k = 0; k < 4; k++) {
+                const unsigned lb = valid[k] ? (unsigned)best[k] : ((word >> (8 * k)) & 255u);
+                out |= lb << (8 * k);
+                mask |= (lb < SF_NC) ? (1u << lb) : 0u;
+            }
+            if (in) {
+                st_word_agent(lab1w + q, out);
+                if (mask) lds_or(&kc.present, mask);
+            }
         }
-        labels_rendezvous(cs, tid);
+        labels_rendezvous_with_mask(cs, kc.present, tid);
         KMC_MARK(PF_KM_ASSIGN);
         // ---- ordered sums of the clusters this workgroup owns (KMeans.cpp:215-221) -> cs.in
-        kmc_collect_and_sum(kc, cs, lab1w, depth1q, lc1, nq1, n_chunks, G, rank, nown, tid, writer ? &st.prof[16] : nullptr);
+        {
+            // the shares (workgroup p labelled quads [p per, (p + 1) per)) that hold members of an owned cluster
+            unsigned own_mask = 0;
+            for (int c = 0; c < nown; c++) own_mask |= 1u << (rank + c * G);
+            int first_p = G, last_p = -1;
+            for (int p = 0; p < G; p++)
+                if (cs.all[p] & own_mask) {
+                    first_p = min(first_p, p);
+                    last_p = p;
+                }
+            const int per = (nq1 + G - 1) / G;  // cluster_range(cs, nq1, 1, ...)
+            const int qlo = (last_p < 0) ? 0 : min(nq1, first_p * per), qhi = (last_p < 0) ? 0 : min(nq1, (last_p + 1) * per);
+            const int n_walk = (uniform_i(qhi) - uniform_i(qlo) + SF_NT - 1) / SF_NT;
+            long long *pr = writer ? &st.prof[16] : nullptr;
+            if (n_walk <= 1) kmc_collect_and_sum<1>(kc, cs, lab1w, depth1q, lc1, qlo, qhi, G, rank, nown, tid, pr);
+            else if (n_walk <= 2) kmc_collect_and_sum<2>(kc, cs, lab1w, depth1q, lc1, qlo, qhi, G, rank, nown, tid, pr);
+            else kmc_collect_and_sum<KMC_R>(kc, cs, lab1w, depth1q, lc1, qlo, qhi, G, rank, nown, tid, pr);
+        }
         cluster_gather(cs, 4 * KMC_MAX_OWN, tid);
         if (tid < 3 * SF_NC) {
             const int c = tid / 3, r = tid - 3 * c;

@@ -153,6 +153,7 @@ __device__ __forceinline__ long long dpp_i64(long long b) {
 template <class T>
 __device__ __forceinline__ T sf_op_add(T a, T b) { return a + b; }
 __device__ __forceinline__ int sf_op_maxi(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int sf_op_ori(int a, int b) { return a | b; }
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
     SF_DPP_REDUCE(v, dpp_f64, sf_op_add)

@@ -428,6 +428,7 @@ __device__ __noinline__ void stage_kmeans_cluster(const KArgs &a, int b, LDS KmC
         km_sort_centres(s, tid);
         KMC_MARK(PF_KM_SORT);
         // ---- assignment of this workgroup's share (KMeans.cpp:187-213)
+        unsigned present = 0;  // labels this thread has seen in its quads
         for (int base = qb1; base < qe1; base += SF_NT) {
             const int q = base + tid;
             const bool in = q < qe1;
@@ -447,17 +448,19 @@ __device__ __noinline__ void stage_kmeans_cluster(const KArgs &a, int b, LDS KmC
                 old[k] = valid[k] ? (int)((word >> (8 * k)) & 255u) : 0;
             }
             km_search_n<4>(s, old, pz, px, py, valid, best);
-            unsigned out = 0, mask = 0;
+            unsigned out = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const unsigned lb = valid[k] ? (unsigned)best[k] : ((word >> (8 * k)) & 255u);
                 out |= lb << (8 * k);
-                mask |= (lb < SF_NC) ? (1u << lb) : 0u;
+                if (in && lb < SF_NC) present |= 1u << lb;
             }
-            if (in) {
-                st_word_agent(lab1w + q, out);
-                if (mask) lds_or(&kc.present, mask);
-            }
+            if (in) st_word_agent(lab1w + q, out);
+        }
+        {   // the wave's labels in one LDS atomic (an OR over the lanes on the DPP network: 0 shifts in at the row edges)
+            int m = (int)present;
+            SF_DPP_REDUCE(m, dpp_i32, sf_op_ori)
+            if (lane == 63 && m) lds_or(&kc.present, (unsigned)m);
         }
         labels_rendezvous_with_mask(cs, kc.present, tid);
         KMC_MARK(PF_KM_ASSIGN);

@@ -1,6 +1,6 @@
 """One-off hunt: N random 8-frame sequences (carried state, 5-frame residuals from frame 5 on) at 160 x 120 through
 sf_process_frame on every build of the frame kernel against the oracle. Prints the worst deviations and every mismatch.
-usage (GPU box): python tools/diag/sequence_hunt.py [first_seed] [count]"""
+usage (GPU box): python tools/diag/sequence_hunt.py [first_seed] [count] [render_width render_height]"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,6 +11,7 @@ from staticfusion_amd.synth import DEFAULT_XI, LCG64, Scene, pose_delta, quantis
 from conftest import driver_params, make_solver
 
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 5000), (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
+W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (320, 240)  # rendered size; the solver sees half of it
 binding.build()
 ora = binding.load()
 worst = {"rot": 0.0, "trans": 0.0, "b": 0.0}
@@ -26,7 +27,7 @@ for seed in range(first, first + count):
     step = (g.uniform(-0.03, 0.03), g.uniform(-0.01, 0.01), g.uniform(-0.01, 0.01))
     frames, T = [], np.eye(4)
     for k in range(9):
-        d, i = scene.render(T, 320, 240, sphere_offset=tuple(k * s for s in step))
+        d, i = scene.render(T, W, H, sphere_offset=tuple(k * s for s in step))
         frames.append(quantise_and_decimate(d, i))
         T = T @ se3_exp(xi)
     rows, cols = frames[0][0].shape

@@ -32,14 +32,15 @@ for seed in range(first, first + count):
         T = T @ se3_exp(xi)
     rows, cols = frames[0][0].shape
     kb = g.uniform(1.0, 1.6)
-    so = make_solver(ora, rows, cols, driver_params(ora, kb=kb))
+    over = dict(segmentation_enabled=0, ctf_levels=3) if os.environ.get("SF_HUNT_SEG") == "0" else {}  # pure odometry (configs[1])
+    so = make_solver(ora, rows, cols, driver_params(ora, kb=kb, **over))
     ref = []
     so.set_current(0, *frames[0]); so.current_to_prediction(); so.push_history(0)
     for k in range(1, 9):
         so.set_prediction(0, *frames[k - 1]); so.set_current(0, *frames[k]); so.process_frame(k)
         ref.append((so.T().copy(), so.labels(0).copy(), so.b_image().copy(), (so.stats().n_outer, so.stats().n_irls)))
     for variant in ("throughput", "latency", "cluster"):
-        sg = make_solver(sf.load().with_variant(variant), rows, cols, driver_params(sf.load(), kb=kb))
+        sg = make_solver(sf.load().with_variant(variant), rows, cols, driver_params(sf.load(), kb=kb, **over))
         sg.set_current(0, *frames[0]); sg.current_to_prediction(); sg.push_history(0)
         for k in range(1, 9):
             sg.set_prediction(0, *frames[k - 1]); sg.set_current(0, *frames[k]); sg.process_frame(k)

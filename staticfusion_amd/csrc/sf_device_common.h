@@ -114,6 +114,7 @@ struct KArgs {
     StreamState *state;      // [batch]
     sf_frame_stats *stats;   // [batch]
     int *queue;              // work-queue counter (zeroed before every launch)
+    const int *order;        // null, or the order in which the queue hands out the streams (longest expected first)
     // cluster build (sf_cluster.h): workgroups per stream; granules [batch][2][cluster_g][SF_SYNC_WORDS]. The record /
     // accumulator arrays then hold batch * (1 + cluster_g) slots of n0 pixels: slot b is stream b's shared one, slot
     // batch + b * cluster_g + r the private one of its workgroup r (coarse levels run redundantly per workgroup)

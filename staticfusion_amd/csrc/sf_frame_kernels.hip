@@ -104,7 +104,12 @@ __global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__
     const KArgs &a = *ka;
     const int tid = threadIdx.x;
     for (;;) {
-        if (tid == 0) s_next = atomicAdd(a.queue, 1);
+        if (tid == 0) {
+            const int ticket = atomicAdd(a.queue, 1);
+            // longest-expected-first when the host supplied an order (sf_hip.hip: streams sorted by the IRLS iterations of their
+            // previous frame): the heavy streams of a launch do not end up alone in its tail
+            s_next = (ticket < a.batch && a.order) ? a.order[ticket] : ticket;
+        }
         __syncthreads();
         const int b = __builtin_amdgcn_readfirstlane(s_next);  // provably wave-uniform: scalar branches around the barriers
         __syncthreads();

@@ -53,6 +53,28 @@ static const FrameVariant VARIANTS[3] = {
 
 // prediction := current; current := pool[frame_index[stream]] for every stream, 16 bytes per lane and plane
 // (sf_advance_sequences_device). grid = (slices, batch).
+// Longest-expected-first order of the streams of a launch (KArgs::order): a counting sort by the IRLS iterations each
+// stream needed for its previous frame, descending. One workgroup; the order inside a bucket is whatever the atomics give
+// (it only decides who runs when, never what is computed).
+__global__ __launch_bounds__(1024) void sf_order_kernel(const sf_frame_stats *stats, int batch, int *order) {
+    __shared__ int bins[256];
+    const int tid = threadIdx.x;
+    if (tid < 256) bins[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < batch; i += 1024) atomicAdd(&bins[255 - min(max(stats[i].n_irls, 0), 255)], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int q = 0; q < 256; q++) {
+            const int n = bins[q];
+            bins[q] = run;
+            run += n;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < batch; i += 1024) order[atomicAdd(&bins[255 - min(max(stats[i].n_irls, 0), 255)], 1)] = i;
+}
+
 // the nearest K-means seed of every level-1 pixel (KArgs::km_seed_lab): once per handle, with the device arithmetic
 __global__ __launch_bounds__(256) void sf_seed_label_kernel(uint8_t *out, int rows_km, int cols_km) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -86,6 +108,7 @@ struct sf_handle {
     int device = 0;
     int max_blocks = 0;
     int wg_per_cu = 0;
+    int *d_order = nullptr;   // KArgs::order storage (more streams than resident workgroups: a launch has a tail)
     int max_blocks_o5 = 0;  // throughput build: resident workgroups of the 5-per-CU kernel (0: not used)
     const FrameVariant *fv = &VARIANTS[0];
     std::vector<struct sf_map *> maps;  // live maps created from this handle: sf_destroy releases their memory and orphans them
@@ -215,6 +238,12 @@ static int launch(sf_handle *h, int mask, int im_count) {
         grid = std::min(h->k.batch, h->max_blocks_o5);
     }
     const bool timed = (mask & ST_SOLVE) != 0;
+    if (h->k.order && (mask & ST_SOLVE) && !std::getenv("SF_NO_STREAM_ORDER")) {
+        // more streams than resident workgroups: hand the streams out longest-expected-first (their previous frame's IRLS
+        // iterations; identical results, a shorter tail when the streams differ)
+        hipLaunchKernelGGL(sf_order_kernel, dim3(1), dim3(1024), 0, h->stream, (const sf_frame_stats *)h->k.stats, h->k.batch, h->d_order);
+        HIP_TRY(hipGetLastError());
+    }
     if (timed) HIP_TRY(hipEventRecord(h->evk0, h->stream));
     if (h->cluster_grid && h->device < 64) {
         std::lock_guard<std::mutex> lock(g_cluster_mu);
@@ -492,6 +521,13 @@ int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, 
     }
     for (size_t b = 0; b < B; b++) st[b].last_slot = (int32_t)b;
     HIP_OR_FREE(hipMemcpy(k.state, st.data(), B * sizeof(StreamState), hipMemcpyHostToDevice));
+    if (!k.cluster_g && (int)B > std::max(h->max_blocks, h->max_blocks_o5)) {
+        TRY_OR_FREE(dev_alloc(h, &h->d_order, B));
+        std::vector<int> iota(B);
+        for (size_t i = 0; i < B; i++) iota[i] = (int)i;
+        HIP_OR_FREE(hipMemcpy(h->d_order, iota.data(), B * sizeof(int), hipMemcpyHostToDevice));
+        k.order = h->d_order;
+    }
     if (k.levels >= 2) {
         const int n1 = k.ln[1];
         hipLaunchKernelGGL(sf_seed_label_kernel, dim3((n1 + 255) / 256), dim3(256), 0, 0, const_cast<uint8_t *>(k.km_seed_lab), k.lrows[1], k.lcols[1]);

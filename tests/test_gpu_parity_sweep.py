@@ -99,6 +99,36 @@ def test_bench_size_batch_duplicates_identical(hip, pair):
     assert len({tuple(T[i].ravel()) for i in range(8)}) == 8  # and the distinct pairs give distinct poses
 
 
+def test_stream_order_changes_nothing_but_the_schedule(hip, pair):
+    """With more streams than resident workgroups a launch hands the streams out longest-expected-first (a device-side
+    counting sort by the IRLS iterations of each stream's previous frame, sf_hip.hip). Streams of very different cost, two
+    frames each: every result equals the run with the plain queue order (SF_NO_STREAM_ORDER)."""
+    if hip.default_variant == "cluster":
+        pytest.skip("every workgroup of a cluster launch is resident: no queue")
+    B = 1600  # more than 5 x 256 resident workgroups
+    easy = pair(seed=61, rows=60, cols=80, sphere=True)
+    hard = pair(seed=62, rows=60, cols=80, sphere=True, xi=tuple(3.0 * np.array(DEFAULT_XI)))
+    out = []
+    for no_order in ("", "1"):
+        if no_order:
+            os.environ["SF_NO_STREAM_ORDER"] = "1"
+        try:
+            s = make_solver(hip, 60, 80, driver_params(hip), batch=B)
+            for b in range(B):
+                pr = hard if b % 7 == 3 else easy
+                s.set_current(b, *pr["new"])
+                s.set_prediction(b, *pr["old"])
+            s.process_frame(0)
+            s.process_frame(1)  # ordered by the counts of frame 0
+            T, n_irls, n_outer, pix = s.batch_results()
+            out.append((T.copy(), n_irls.copy(), pix.copy(), s.b_image(3).copy(), s.b_image(0).copy()))
+        finally:
+            os.environ.pop("SF_NO_STREAM_ORDER", None)
+    assert len(set(out[0][1].tolist())) > 1, "the streams should differ in cost"
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+
+
 def test_overlapped_upload_equals_direct_upload(hip, pair):
     """sf_upload_current_async + sf_commit_upload (second HIP stream, page-locked host buffers) hands the solver the
     same frames as sf_set_current, also when the next upload is in flight during a solve."""

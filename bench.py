@@ -50,7 +50,20 @@ WORKLOAD_TEXT = {
                "K-means(24) + b-field, driver parameters, 5 levels"),
     "sequences": ("SURVEY 8(d) config 5: independent synthetic QVGA sequences per rank (seeds 1000 + rank ..., smooth random-walk "
                   "camera, swinging sphere), frame-to-frame prediction, full solver, K-means(24) + b-field, driver parameters"),
+    "tum": ("BASELINE.json configs[0] / configs[3] in frame-to-frame mode (SURVEY 8(d) config 1 substitute): a TUM-format directory "
+            "(rgb/ depth/ rgbd_assoc.txt, reference README.md:67-89) through the loader + bilateral depth filter of the input stage, "
+            "every stream plays the sequence from its own start frame, full solver, driver parameters"),
 }
+
+# BASELINE.json configs this environment cannot exercise, and why; `--workload tum --dataset DIR` runs [0] / [3] in
+# frame-to-frame mode the moment a dataset is mounted (tests/test_gpu_parity_hunt.py::test_tum_dataset_bench skips likewise)
+CONFIGS_UNAVAILABLE = [
+    "configs[0] TUM fr1/360 rawlog: dataset absent (no network); the rawlog container itself needs MRPT -- the PNG + rgbd_assoc.txt "
+    "form of the sequence runs with --workload tum --dataset DIR",
+    "configs[3] TUM fr3/walking_xyz feeding the OpenGL surfel model: dataset absent, no OpenGL / Pangolin in the image -- frame-to-frame "
+    "with --workload tum --dataset DIR, headless fusion with tools/run_sequence.py --mode fusion",
+    "configs[4] 8 sequences on 8 GPUs: this process sees the GPUs the driver gives it (python -m torch.distributed.run ... bench.py --gpus N)",
+]
 
 
 def parse():
@@ -59,12 +72,16 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16384, help="independent streams per GPU (8.3 MB of HBM each: 136 GB); 16 rounds of the 1024 resident workgroups")
-    ap.add_argument("--workload", choices=["static", "sphere", "sequences"], default="static")
+    ap.add_argument("--workload", choices=["static", "sphere", "sequences", "tum"], default="static")
+    ap.add_argument("--dataset", default=os.environ.get("SF_TUM_DATASET"), help="tum workload: directory with rgb/ depth/ rgbd_assoc.txt")
     ap.add_argument("--variant", choices=["auto", "throughput", "latency", "cluster"], default="auto", help="frame-kernel build (sf_create_ex)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pairs (tiled over the batch)")
     ap.add_argument("--seq-distinct", type=int, default=4, help="sequences workload: distinct sequences per rank")
     ap.add_argument("--seq-frames", type=int, default=200, help="sequences workload: frames per sequence")
     ap.add_argument("--no-full-solver", action="store_true", help="static workload: skip the configs[2] block")
+    ap.add_argument("--no-sequences", action="store_true", help="static workload: skip the sequences blocks")
+    ap.add_argument("--seq-batches", default="16384,4096", help="static workload: stream counts of the sequences blocks")
+    ap.add_argument("--pass-reps", type=int, default=4, help="repetitions of each isolated IRLS pass (roofline.irls_passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
@@ -275,7 +292,12 @@ def run_pairs_workload(hx, args, workload, batch, with_parity):
     k_ms = region_ms / args.steps
     solver.process_frame(im)  # per-stage unit counts of ONE launch (for the algorithmic byte count): one more, un-timed step
     stats_last = [solver.stats(b) for b in range(min(B, args.distinct))]
+    status_or = 0
+    for st in stats_last:
+        status_or |= int(st.status)
+    assert status_or & sf.STATUS_SYNC_TIMEOUT == 0, "a cluster rendezvous timed out: the frames of this run are not valid"
     variant = solver.variant()
+    irls_passes = isolated_passes(solver, B, rows * cols, args.pass_reps) if variant[0] != "cluster" else None
     resident = solver.resident_workgroups()
     levels_n = [solver.level_shape(L)[0] * solver.level_shape(L)[1] for L in range(solver.levels)]
     levels = int(solver.levels)
@@ -316,30 +338,92 @@ def run_pairs_workload(hx, args, workload, batch, with_parity):
             "algorithmic_bytes_per_launch": alg_bytes_launch,
             "algorithmic_bytes_breakdown_per_stream": {k: v / float(len(stats_last)) for k, v in per_stream.items()},
             "kernel_ms_avg": k_ms,
+            # the north star's "residual / Jacobian kernel" on its own: the two streaming passes of one IRLS iteration
+            # launched alone (sf_irls_pass_kernel) over the level-0 records of every stream of THIS handle
+            "irls_passes": irls_passes,
         },
         "pairs": pairs,
     }
 
 
-def run_sequences_workload(hx, args):
-    """Independent sequences per rank, resident in HBM, frame-to-frame prediction (see the module docstring)."""
+def isolated_passes(solver, B, n0, reps):
+    """Each IRLS pass alone over level 0 of all B streams: ms per repetition, GB/s against the algorithmic 30 B per pixel and
+    pass (60 B per pixel and IRLS iteration), fraction of the 8 TB/s peak; `iteration` = both passes."""
+    out = {}
+    px = float(B) * n0
+    for which, name in ((1, "pass1_weights_normal_equations"), (2, "pass2_residuals_label_sums")):
+        solver.microbench_pass(which, 0, 1)
+        ms = solver.microbench_pass(which, 0, reps) / reps
+        out[name] = {"ms": ms, "gpx_per_s": px / ms / 1e6, "bytes": 30.0 * px, "achieved": 30.0 * px / ms / 1e6, "frac": 30.0 * px / ms / 1e6 / HBM_PEAK_GBS}
+    ms = sum(v["ms"] for v in out.values())
+    out["iteration"] = {"ms": ms, "bytes": 60.0 * px, "achieved": 60.0 * px / ms / 1e6, "unit": "GB/s", "frac": 60.0 * px / ms / 1e6 / HBM_PEAK_GBS,
+                        "pixels": px, "repetitions": reps, "kernel": "sf_irls_pass_kernel (level 0 of every stream, one pass per launch)"}
+    return out
+
+
+def synthetic_sequence_pool(hx, args):
+    """The frames of D synthetic sequences per rank as two HBM-resident [D * F][n0] arrays (column-major images)."""
     import multiprocessing as mp
 
-    import staticfusion_amd as sf
-    from staticfusion_amd.synth import make_sequence, pose_delta
+    from staticfusion_amd.synth import make_sequence
 
-    torch = hx.torch
-    api = sf.load()
-    params = make_params(api, "sequences")
-    rows, cols, B = 240, 320, args.batch
     D, F = args.seq_distinct, args.seq_frames
-    assert args.warmup + args.steps + 2 <= F, "sequence too short for the requested steps"
     with mp.get_context("spawn").Pool(min(len(os.sched_getaffinity(0)), 16)) as pool:
         seqs = [make_sequence(1000 + hx.rank * D + q, F, sphere=True, pool=pool) for q in range(D)]
-    n0 = rows * cols
     col = lambda a: np.ascontiguousarray(np.asarray(a, np.float32).T).ravel()
-    pool_d = torch.from_numpy(np.stack([col(f[0]) for s in seqs for f in s["frames"]])).to("cuda:%d" % hx.dev_index)
-    pool_i = torch.from_numpy(np.stack([col(f[1]) for s in seqs for f in s["frames"]])).to("cuda:%d" % hx.dev_index)
+    dev = "cuda:%d" % hx.dev_index
+    return {
+        "d": hx.torch.from_numpy(np.stack([col(f[0]) for s in seqs for f in s["frames"]])).to(dev),
+        "i": hx.torch.from_numpy(np.stack([col(f[1]) for s in seqs for f in s["frames"]])).to(dev),
+        "D": D, "F": F, "T_gt": [s["T_gt"] for s in seqs], "rows": 240, "cols": 320, "workload": "sequences",
+        "what": {"distinct_sequences_per_rank": D, "frames_per_sequence": F, "sequence_seeds": [1000 + hx.rank * D, 1000 + hx.rank * D + D - 1]},
+    }
+
+
+def tum_sequence_pool(hx, args):
+    """A TUM-format directory through the input stage (loader decimation / flip / RGB -> intensity, bilateral depth filter +
+    metricise: reference FrontEnd.cpp:216-254, Reconstruction.cpp:722-732) into the same kind of pool: one sequence."""
+    import staticfusion_amd as sf
+    from staticfusion_amd import io as sfio
+
+    if not args.dataset or not os.path.isdir(args.dataset):
+        raise SystemExit("dataset absent: %r (no dataset ships with this repository; --dataset DIR or SF_TUM_DATASET)" % (args.dataset,))
+    io = sfio.Io()
+    directory = args.dataset if args.dataset.endswith("/") else args.dataset + "/"
+    ts, files_depth, files_color = io.load_assoc(directory)
+    F = min(len(ts), args.seq_frames)
+    assert F >= args.warmup + args.steps + 12, "the sequence is too short for the requested steps (%d frames)" % F
+    first = io.imread_depth16(files_depth[0])
+    rows, cols = first.shape[0] // 2, first.shape[1] // 2
+    api = sf.load()
+    conv = sf.Solver(api, rows, cols, 1, make_params(api, "tum"), device=hx.dev_index)
+    frames_d, frames_i = [], []
+    col = lambda a: np.ascontiguousarray(np.asarray(a, np.float32).T).ravel()
+    for k in range(F):
+        conv.load_frame(0, io.imread_color(files_color[k]), io.imread_depth16(files_depth[k]), 2)
+        if k:
+            conv.filter_depth()  # the bootstrap frame is used unfiltered (StaticFusion-imagesequenceassoc.cpp:117-123)
+        d, i = conv.current(0)
+        frames_d.append(col(d))
+        frames_i.append(col(i))
+    conv.close()
+    dev = "cuda:%d" % hx.dev_index
+    return {"d": hx.torch.from_numpy(np.stack(frames_d)).to(dev), "i": hx.torch.from_numpy(np.stack(frames_i)).to(dev), "D": 1, "F": F,
+            "T_gt": None, "rows": rows, "cols": cols, "workload": "tum", "what": {"dataset": os.path.abspath(args.dataset), "frames": F}}
+
+
+def run_sequences_workload(hx, args, B, pool):
+    """Independent sequences per rank, resident in HBM, frame-to-frame prediction (see the module docstring)."""
+    import staticfusion_amd as sf
+    from staticfusion_amd.synth import pose_delta
+
+    api = sf.load()
+    params = make_params(api, pool["workload"])
+    rows, cols = pool["rows"], pool["cols"]
+    D, F = pool["D"], pool["F"]
+    assert args.warmup + args.steps + 10 <= F, "sequence too short for the requested steps"
+    n0 = rows * cols
+    pool_d, pool_i = pool["d"], pool["i"]
     assert pool_d.shape == (D * F, n0)
     solver = sf.Solver(api, rows, cols, B, params, device=hx.dev_index, variant=args.variant)
     # stream b plays sequence b % D starting at frame phase[b]; frames wrap to 1 (never to 0) so that a wrap is a large
@@ -350,11 +434,11 @@ def run_sequences_workload(hx, args):
     def index_at(step):
         return (seq_of * F + (phase + step) % F).astype(np.int32)
 
-    solver.advance_sequences_device(pool_d.data_ptr(), pool_i.data_ptr(), index_at(0))
+    solver.advance_sequences_device(pool_d.data_ptr(), pool_i.data_ptr(), index_at(0), D * F)
     solver.push_history(0)
     step = 1
     for _ in range(5 + args.warmup):  # bootstrap + the 5-frame ring + warm-up
-        solver.advance_sequences_device(pool_d.data_ptr(), pool_i.data_ptr(), index_at(step))
+        solver.advance_sequences_device(pool_d.data_ptr(), pool_i.data_ptr(), index_at(step), D * F)
         solver.process_frame(step)
         step += 1
     solver.synchronize()
@@ -362,7 +446,7 @@ def run_sequences_workload(hx, args):
     hx.barrier(solver)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        solver.advance_sequences_device(pool_d.data_ptr(), pool_i.data_ptr(), index_at(step))
+        solver.advance_sequences_device(pool_d.data_ptr(), pool_i.data_ptr(), index_at(step), D * F)
         solver.process_frame(step)
         step += 1
     hx.barrier(solver)
@@ -373,7 +457,7 @@ def run_sequences_workload(hx, args):
     # kernel duration + unit counts from three more, un-timed launches
     k_ms, stats_last = [], None
     for _ in range(3):
-        solver.advance_sequences_device(pool_d.data_ptr(), pool_i.data_ptr(), index_at(step))
+        solver.advance_sequences_device(pool_d.data_ptr(), pool_i.data_ptr(), index_at(step), D * F)
         solver.process_frame(step)
         solver.synchronize()
         k_ms.append(solver.last_solver_kernel_ms())
@@ -382,16 +466,20 @@ def run_sequences_workload(hx, args):
     stats_last = [solver.stats(b) for b in range(ncheck)]
     # tracking check against the ground truth of the generator for the last frame (streams 0 .. D-1 did not wrap)
     T_all, n_irls, _, _ = solver.batch_results()
+    status_or = 0
+    for st in stats_last:
+        status_or |= int(st.status)
+    assert status_or & sf.STATUS_SYNC_TIMEOUT == 0, "a cluster rendezvous timed out: the frames of this run are not valid"
     err = []
-    for b in range(min(B, D)):
-        k = int((phase[b] + step - 1) % F)
-        err.append(pose_delta(seqs[b % D]["T_gt"][k], T_all[b]))
+    if pool["T_gt"] is not None:
+        for b in range(min(B, D)):
+            k = int((phase[b] + step - 1) % F)
+            err.append(pose_delta(pool["T_gt"][b % D][k], T_all[b]))
     variant = solver.variant()
     resident = solver.resident_workgroups()
     levels_n = [solver.level_shape(L)[0] * solver.level_shape(L)[1] for L in range(solver.levels)]
     levels = int(solver.levels)
     solver.close()
-    del pool_d, pool_i
 
     t_max, iters_all, frames_all = reduce_over_ranks(hx.dist, hx.reduce_device, elapsed, iters_total, B * args.steps)
     per_rank = gather_per_rank(hx.dist, hx.reduce_device, elapsed, iters_total, B * args.steps)
@@ -399,28 +487,32 @@ def run_sequences_workload(hx, args):
     alg_bytes_launch = sum(per_stream.values()) * B / float(len(stats_last))
     kms = float(np.mean(k_ms))
     achieved = alg_bytes_launch / (kms * 1e-3) / 1e9
+    traffic, why = measured_traffic(pool["workload"], B, variant[0])
+    if traffic:
+        traffic["ratio_to_algorithmic"] = traffic["hbm_bytes_per_launch"] / alg_bytes_launch
+    cfg = {"workload": WORKLOAD_TEXT[pool["workload"]], "streams_per_gpu": B}
+    cfg.update(pool["what"])
     return {
-        "workload": "sequences",
+        "workload": pool["workload"],
         "value": iters_all / t_max,
         "frames_per_s": frames_all / t_max,
         "ms_per_step": 1e3 * t_max / args.steps,
         "iterations_per_frame": iters_total / float(B * args.steps),
         "iterations_per_frame_spread": [int(n_irls.min()), int(n_irls.max())],
-        "parity": {"tracking_error_vs_ground_truth": {"rot_rad_max": max(e[0] for e in err), "trans_m_max": max(e[1] for e in err), "streams": len(err)}},
+        "parity": ({"tracking_error_vs_ground_truth": {"rot_rad_max": max(e[0] for e in err), "trans_m_max": max(e[1] for e in err), "streams": len(err)}}
+                   if err else None),
         "per_rank": [{"rank": r, "elapsed_s": e, "iterations_per_s": i / e, "frames_per_s": f / e} for r, (e, i, f) in enumerate(per_rank)],
-        "config": {
-            "workload": WORKLOAD_TEXT["sequences"],
-            "streams_per_gpu": B, "distinct_sequences_per_rank": D, "frames_per_sequence": F, "sequence_seeds": [1000 + hx.rank * D, 1000 + hx.rank * D + D - 1],
+        "config": dict(cfg, **{
             "rows": rows, "cols": cols, "ctf_levels": levels,
             "max_iter_irls": int(params.max_iter_irls), "max_iter_per_level": int(params.max_iter_per_level),
             "kernel_build": "%s (%d threads per workgroup, %d workgroup(s) per stream)" % variant + ", %d workgroups resident per CU (grid %d)" % resident,
             "parallelism": "independent sequences, %d GPU(s)" % hx.world,
             "step": "sf_advance_sequences_device (prediction := current, current := next frame from the HBM pool) + sf_process_frame",
-        },
+        }),
         "roofline": {
             "kernel": "sf_frame_kernel (%s build)" % variant[0],
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "traffic_provenance": None, "traffic_note": "not measured for this workload",
+            "traffic": traffic["hbm_bytes_per_launch"] if traffic else None, "traffic_provenance": traffic, "traffic_note": why,
             "algorithmic_bytes_per_launch": alg_bytes_launch,
             "algorithmic_bytes_breakdown_per_stream": {k: v / float(len(stats_last)) for k, v in per_stream.items()},
             "kernel_ms_avg": kms,
@@ -433,13 +525,23 @@ def main():
     args = parse()
     hx = Harness(args)
     want_parity = not args.no_cpu_baseline
-    if args.workload == "sequences":
-        blk = run_sequences_workload(hx, args)
+    seq_blocks = []
+    if args.workload in ("sequences", "tum"):
+        pool = synthetic_sequence_pool(hx, args) if args.workload == "sequences" else tum_sequence_pool(hx, args)
+        blk = run_sequences_workload(hx, args, args.batch, pool)
+        del pool
     else:
         blk = run_pairs_workload(hx, args, args.workload, args.batch, want_parity)
     full = None
     if args.workload == "static" and not args.no_full_solver:
         full = run_pairs_workload(hx, args, "sphere", args.batch, want_parity)
+    if args.workload == "static" and not args.no_sequences:
+        # the realistic shape of the many-streams use: unequal streams (8 ... 66 IRLS iterations per frame), at a batch
+        # that is many rounds of the resident workgroups and at one that is only three (the tail of a launch shows)
+        pool = synthetic_sequence_pool(hx, args)
+        for nb in [int(x) for x in args.seq_batches.split(",") if x]:
+            seq_blocks.append(run_sequences_workload(hx, args, min(nb, args.batch), pool))
+        del pool
 
     if hx.rank == 0:
         out = {
@@ -465,8 +567,17 @@ def main():
             "roofline": blk["roofline"],
             "build": {"head": git_head(), "src_sha": source_sha()},
         }
+        out["configs_unavailable"] = CONFIGS_UNAVAILABLE
         if "iterations_per_frame_spread" in blk:
             out["iterations_per_frame_spread"] = blk["iterations_per_frame_spread"]
+        if seq_blocks:
+            out["sequences"] = [{
+                "workload": q["config"]["workload"], "streams_per_gpu": q["config"]["streams_per_gpu"],
+                "value": q["value"], "unit": "iterations/s", "frames_per_s": q["frames_per_s"], "ms_per_step": q["ms_per_step"],
+                "steps": args.steps, "warmup": args.warmup, "iterations_per_frame": q["iterations_per_frame"],
+                "iterations_per_frame_spread": q["iterations_per_frame_spread"], "tracking": q["parity"],
+                "config": q["config"], "roofline": q["roofline"], "per_rank": q["per_rank"],
+            } for q in seq_blocks]
         if full is not None:
             out["full_solver"] = {
                 "workload": full["config"]["workload"],
@@ -475,7 +586,7 @@ def main():
                 "iterations_per_frame": full["iterations_per_frame"], "pose_delta_vs_cpu": full["parity"],
                 "config": full["config"], "roofline": full["roofline"], "per_rank": full["per_rank"],
             }
-        if not args.no_cpu_baseline and hx.world == 1 and args.workload != "sequences":  # rank 0 at N = 1 only
+        if not args.no_cpu_baseline and hx.world == 1 and args.workload in ("static", "sphere"):  # rank 0 at N = 1 only
             lib = native_oracle()
             out["cpu_baseline"] = cpu_baseline(args.workload, blk["pairs"], args.cpu_seconds, lib)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.workload, min(args.cpu_seconds, 8.0), lib)

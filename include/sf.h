@@ -104,6 +104,8 @@ typedef struct sf_outer_trace {
     float lambda_t_w[SF_NUM_CLUSTERS];
     float AtA[36];      /* normal equations of the LAST IRLS iteration (FrontEnd.cpp:640-641), row-major 6x6 */
     float AtB[6];
+    float delta_sol_max; /* |Var - previous Var|_inf of the LAST IRLS iteration: what the stopping test compared with
+                            irls_delta_threshold (FrontEnd.cpp:676-679) */
 } sf_outer_trace;
 
 typedef struct sf_frame_stats {
@@ -182,9 +184,12 @@ int SF_FN(set_prediction_device)(sf_handle *h, const void *d_depth, const void *
  *   depthPrediction / intensityPrediction := depthCurrent / intensityCurrent
  *   depthCurrent / intensityCurrent       := frame frame_index[b] of the pools
  * in ONE pass over the images. pool_depth / pool_intensity are DEVICE buffers of frames laid out [frame][cols][rows]
- * (column-major float32, rows*cols each); frame_index is a HOST array of `batch` frame numbers, a negative entry leaves
- * that stream untouched. Asynchronous on the handle's stream (the index array is copied before the call returns). */
-int SF_FN(advance_sequences_device)(sf_handle *h, const void *pool_depth, const void *pool_intensity, const int32_t *frame_index);
+ * (column-major float32, rows*cols each) holding pool_frames frames each, 16-byte aligned; frame_index is a HOST array
+ * of `batch` frame numbers in [0, pool_frames), a negative entry leaves that stream untouched (any other value outside
+ * the pool: SF_ERR_ARG, nothing is launched). Asynchronous on the handle's stream (the index array is copied before the
+ * call returns). */
+int SF_FN(advance_sequences_device)(sf_handle *h, const void *pool_depth, const void *pool_intensity, const int32_t *frame_index,
+                                    int pool_frames);
 /* Overlapped upload for PCIe-fed deployments: sf_upload_current_async starts copying depthCurrent / intensityCurrent
  * of the WHOLE batch (host buffers laid out [batch][cols][rows]; page-locked memory from sf_alloc_pinned makes the
  * copy truly asynchronous) into a staging block on a second HIP stream and returns at once -- the solver launches

@@ -9,7 +9,8 @@ import subprocess
 from staticfusion_amd._capi import Api
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(_HERE, "liboracle.so")
+# SF_ORACLE_LIB: another build of the same sources (tests/test_oracle_sanitizers.py points it at liboracle_asan.so)
+LIB = os.environ.get("SF_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
 
 
 def build(force=False):

@@ -532,8 +532,11 @@ void StaticFusion::calculateCoord() {
                 depth_inter_ref(v, u) = 0.5f * (depth_ref(v, u) + depth_warped_ref(v, u));
                 xx_inter_ref(v, u) = 0.5f * (xxPyr[image_level](v, u) + xxWarpedPyr[image_level](v, u));
                 yy_inter_ref(v, u) = 0.5f * (yyPyr[image_level](v, u) + yyWarpedPyr[image_level](v, u));
-                if ((u != 0) && (v != 0) && (u != cols_i - 1) && (v != rows_i - 1))
-                    validPixels.push_back(std::make_pair(int(v), int(u)));
+                if ((u != 0) && (v != 0) && (u != cols_i - 1) && (v != rows_i - 1)) {
+                    const bool behind = depth_warped_ref(v, u) < 0.f;  // not in the reference: see hip_behind_camera_rule
+                    if (behind && !hip_behind_camera_rule) behind_camera_valid++;
+                    if (!(behind && hip_behind_camera_rule)) validPixels.push_back(std::make_pair(int(v), int(u)));
+                }
             } else {
                 Null(v, u) = 1;
                 depth_inter_ref(v, u) = 0.f;
@@ -663,8 +666,11 @@ void StaticFusion::computeSegPrior() {
             if (l != NUM_CLUSTERS) {
                 if (Null(v, u) == 0) {
                     cluster_nonnull[l]++;
-                    b_prior[l] += 1.f - kz * std::abs(ddt(v, u));
-                    exact[l] += double(1.f - kz * std::abs(ddt(v, u)));
+                    float ddt_here = ddt(v, u);
+                    if (hip_behind_camera_rule)  // the HIP build keeps |depthWarped| for a pixel outside validPixels
+                        ddt_here = depthPyr[image_level](v, u) - std::abs(depthWarpedPyr[image_level](v, u));
+                    b_prior[l] += 1.f - kz * std::abs(ddt_here);
+                    exact[l] += double(1.f - kz * std::abs(ddt_here));
                 }
                 cluster_size[labels_ref(v, u)]++;
             }
@@ -832,6 +838,7 @@ void StaticFusion::solveOdometryAndSegmJoint() {
             t0.n_valid = 0;
             t0.irls_iters = 0;
             t0.aver_res = 0.f;
+            t0.delta_sol_max = 0.f;
             for (int c = 0; c < 6; c++) t0.var[c] = t0.twist_level[c] = 0.f;
             for (int l = 0; l < NUM_CLUSTERS; l++) t0.b_segm[l] = b_segm[l];
             std::memcpy(t0.T, T_odometry.m, sizeof(t0.T));
@@ -846,6 +853,7 @@ void StaticFusion::solveOdometryAndSegmJoint() {
     }
 
     unsigned int iters_done = 0;
+    float last_delta = 0.f;
     for (unsigned int k = 1; k <= max_iter_irls; k++) {
         iters_done = k;
         const float inv_c_Cauchy = 1.f / (kc_Cauchy * aver_res);  // :615
@@ -872,11 +880,27 @@ void StaticFusion::solveOdometryAndSegmJoint() {
         {
             double acc[27];
             for (auto &a : acc) a = 0.0;
-            for (size_t r = 0; r < M; r++) {
-                int q = 0;
-                for (int i = 0; i < 6; i++)
-                    for (int j = i; j < 6; j++) acc[q++] += double(Aw_(r, i)) * double(Aw_(r, j));
-                for (int i = 0; i < 6; i++) acc[21 + i] += double(Aw_(r, i)) * double(Bw[r]);
+            if (gemm_mode == 0 || gemm_mode == 3) {
+                for (size_t rr = 0; rr < M; rr++) {
+                    const size_t r = (gemm_mode == 3) ? M - 1 - rr : rr;
+                    int q = 0;
+                    for (int i = 0; i < 6; i++)
+                        for (int j = i; j < 6; j++) acc[q++] += double(Aw_(r, i)) * double(Aw_(r, j));
+                    for (int i = 0; i < 6; i++) acc[21 + i] += double(Aw_(r, i)) * double(Bw[r]);
+                }
+            } else {  // test hook: float accumulators (see gemm_mode in sf_oracle.hpp)
+                const int P = (gemm_mode == 2) ? 4 : 1;
+                float part[4][27];
+                for (auto &pp : part)
+                    for (auto &a : pp) a = 0.f;
+                for (size_t r = 0; r < M; r++) {
+                    float *pa = part[r % size_t(P)];
+                    int q = 0;
+                    for (int i = 0; i < 6; i++)
+                        for (int j = i; j < 6; j++) pa[q++] += Aw_(r, i) * Aw_(r, j);
+                    for (int i = 0; i < 6; i++) pa[21 + i] += Aw_(r, i) * Bw[r];
+                }
+                for (int q = 0; q < 27; q++) acc[q] = double((part[0][q] + part[1][q]) + (part[2][q] + part[3][q]));
             }
             int q = 0;
             for (int i = 0; i < 6; i++)
@@ -929,6 +953,7 @@ void StaticFusion::solveOdometryAndSegmJoint() {
         float delta_sol_max = 0.f;
         for (int c = 0; c < 6; c++) delta_sol_max = std::max(delta_sol_max, std::fabs(prev_sol[c] - Var[c]));
         for (int c = 0; c < 6; c++) prev_sol[c] = Var[c];
+        last_delta = delta_sol_max;
         if ((delta_sol_max < irls_delta_threshold) || (k == max_iter_irls)) break;
     }
 
@@ -949,6 +974,7 @@ void StaticFusion::solveOdometryAndSegmJoint() {
         tr->n_valid = int(N);
         tr->irls_iters = int(iters_done);
         tr->aver_res = aver_res;
+        tr->delta_sol_max = last_delta;
         for (int c = 0; c < 6; c++) tr->var[c] = Var[c];
         for (int l = 0; l < NUM_CLUSTERS; l++) {
             tr->b_prior[l] = b_prior[l];
@@ -1063,6 +1089,16 @@ void StaticFusion::warpImagesAccurateInverse() {
     MatF wacu;
     wacu.resize(rows_i, cols_i);
     wacu.assign(0.f);
+    std::vector<double> ex_d, ex_i;  // exact_warp (test hook): fp64 sums of the exact products
+    if (exact_warp) {
+        ex_d.assign(size_t(rows_i) * cols_i, 0.0);
+        ex_i.assign(size_t(rows_i) * cols_i, 0.0);
+    }
+    auto ex_add = [&](int v, int u, int w, float dw, float iw) {
+        if (!exact_warp) return;
+        ex_d[size_t(v) + size_t(u) * rows_i] += double(w) * double(dw);
+        ex_i[size_t(v) + size_t(u) * rows_i] += double(w) * double(iw);
+    };
     const int cols_lim = 100 * (cols_i - 1);
     const int rows_lim = 100 * (rows_i - 1);
 
@@ -1096,6 +1132,7 @@ void StaticFusion::warpImagesAccurateInverse() {
                         depth_warped_ref(ind_v, ind_u) += 200.f * depth_w;
                         intensity_warped_ref(ind_v, ind_u) += 200.f * intensity_w;
                         wacu(ind_v, ind_u) += 200;
+                        ex_add(ind_v, ind_u, 200, depth_w, intensity_w);
                     } else {
                         const int v_d = vwarp_d / 100, u_l = uwarp_l / 100;
                         const int v_u = v_d + 1, u_r = u_l + 1;
@@ -1104,21 +1141,25 @@ void StaticFusion::warpImagesAccurateInverse() {
                         depth_warped_ref(v_u, u_r) += w_ur * depth_w;
                         intensity_warped_ref(v_u, u_r) += w_ur * intensity_w;
                         wacu(v_u, u_r) += w_ur;
+                        ex_add(v_u, u_r, w_ur, depth_w, intensity_w);
 
                         const int w_ul = delta_r + delta_d;
                         depth_warped_ref(v_u, u_l) += w_ul * depth_w;
                         intensity_warped_ref(v_u, u_l) += w_ul * intensity_w;
                         wacu(v_u, u_l) += w_ul;
+                        ex_add(v_u, u_l, w_ul, depth_w, intensity_w);
 
                         const int w_dr = delta_l + delta_u;
                         depth_warped_ref(v_d, u_r) += w_dr * depth_w;
                         intensity_warped_ref(v_d, u_r) += w_dr * intensity_w;
                         wacu(v_d, u_r) += w_dr;
+                        ex_add(v_d, u_r, w_dr, depth_w, intensity_w);
 
                         const int w_dl = delta_r + delta_u;
                         depth_warped_ref(v_d, u_l) += w_dl * depth_w;
                         intensity_warped_ref(v_d, u_l) += w_dl * intensity_w;
                         wacu(v_d, u_l) += w_dl;
+                        ex_add(v_d, u_l, w_dl, depth_w, intensity_w);
                     }
                 }
             }
@@ -1130,6 +1171,10 @@ void StaticFusion::warpImagesAccurateInverse() {
             if (wacu(v, u) != 0) {
                 intensity_warped_ref(v, u) /= float(wacu(v, u));
                 depth_warped_ref(v, u) /= float(wacu(v, u));
+                if (exact_warp) {
+                    intensity_warped_ref(v, u) = float(ex_i[size_t(v) + size_t(u) * rows_i] / double(wacu(v, u)));
+                    depth_warped_ref(v, u) = float(ex_d[size_t(v) + size_t(u) * rows_i] / double(wacu(v, u)));
+                }
                 xx_warped_ref(v, u) = (u - disp_u_i) * depth_warped_ref(v, u) * inv_f_i;
                 yy_warped_ref(v, u) = (v - disp_v_i) * depth_warped_ref(v, u) * inv_f_i;
             } else {
@@ -1285,6 +1330,7 @@ void StaticFusion::runSolver(bool create_image_pyr) {
     stats.pixel_iters = 0;
     stats.kmeans_iters = 0;
     stats.status = 0;
+    behind_camera_valid = 0;
 
     if (create_image_pyr) createImagePyramid(false);
 

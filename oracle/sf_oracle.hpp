@@ -98,6 +98,7 @@ struct OuterTrace {
     float T[16];
     float b_prior[NUM_CLUSTERS], lambda_t_w[NUM_CLUSTERS];  // computeSegPrior of this iteration
     float AtA[36], AtB[6];                                  // normal equations of the last IRLS iteration
+    float delta_sol_max;                                    // |Var - prev_sol|_inf of the last IRLS iteration (:676-679)
 };
 
 struct FrameStats {
@@ -199,6 +200,24 @@ class StaticFusion {
                                             // accumulates sequentially in fp32 (computeSegPrior, the IRLS residual sums,
                                             // the 5-frame residuals) are accumulated in fp64 instead -- what the formula
                                             // means without the reference's own summation error
+    // test hook (sfo_test_set_gemm_mode): how AtA / AtB (:640-641, an Eigen float GEMM whose internal order the reference
+    // does not show) are accumulated. 0 = [C1] (float operands, fp64 products and sums; the oracle's convention);
+    // 1 = float products, ONE sequential float accumulator per entry (the plain reading of a float GEMM);
+    // 2 = float products, four interleaved float partial sums per entry (rows r % 4: an SSE packet accumulator, what
+    //     Eigen 3.x does on the reference's -msse2 build), combined ((p0 + p1) + (p2 + p3));
+    // 3 = [C1] walked over the rows in REVERSE order (pure summation-order control).
+    // Modes 1-3 exist to measure how much of a HIP-vs-oracle difference is the convention's, not to be parity targets.
+    int gemm_mode = 0;
+    // test hook (sfo_test_set_hip_behind_camera_rule): the HIP build's rule for points warped BEHIND the camera that still
+    // project into the image (depthWarped < 0; reference FrontEnd.cpp:816-823 has no depth test and carries them through):
+    // such a pixel stays out of validPixels and computeSegPrior sees |depthWarped|.
+    bool hip_behind_camera_rule = false;
+    // test hook (sfo_test_set_exact_warp): the warp's scatter sums (:840-867, order-dependent float accumulation in the
+    // reference) accumulated in fp64 from exact products and divided once -- the value the float sums approximate.
+    // Measures how much of a HIP-vs-oracle distance is the reference's own scatter rounding (the HIP path adds the same
+    // terms as exact integers and divides once).
+    bool exact_warp = false;
+    long long behind_camera_valid = 0;      // diagnostic: validPixels entries with depthWarped < 0 since the last runSolver
     bool keep_rows = false;                 // test hook: keep the Jacobian of the last outer iteration
     std::vector<float> dbg_A, dbg_B;        // column-major 2N x 6 / 2N (FrontEnd.cpp:539-586), only with keep_rows
 

@@ -206,9 +206,12 @@ int sfo_set_prediction_device(sf_handle *h, const void *d, const void *i) {
     for (int b = 0; b < h->batch; b++) sfo_set_prediction(h, b, (const float *)d + b * n, (const float *)i + b * n);
     return SF_OK;
 }
-int sfo_advance_sequences_device(sf_handle *h, const void *pool_depth, const void *pool_intensity, const int32_t *frame_index) {
+int sfo_advance_sequences_device(sf_handle *h, const void *pool_depth, const void *pool_intensity, const int32_t *frame_index, int pool_frames) {
     // "device" pools of the CPU oracle are host buffers [frame][cols][rows]
     if (!h || !pool_depth || !pool_intensity || !frame_index) return fail(SF_ERR_ARG, "null");
+    if (pool_frames < 1) return fail(SF_ERR_ARG, "pool_frames < 1");
+    for (int b = 0; b < h->batch; b++)
+        if (frame_index[b] >= pool_frames) return fail(SF_ERR_ARG, "frame_index entry outside the pool");
     const size_t n = size_t(h->rows) * h->cols;
     for (int b = 0; b < h->batch; b++) {
         if (frame_index[b] < 0) continue;
@@ -385,6 +388,7 @@ int sfo_get_stats(sf_handle *h, int stream, sf_frame_stats *out) {
         sf_outer_trace &b = out->outer[i];
         b.level = a.level; b.k = a.k; b.n_valid = a.n_valid; b.irls_iters = a.irls_iters;
         b.aver_res = a.aver_res;
+        b.delta_sol_max = a.delta_sol_max;
         std::memcpy(b.var, a.var, sizeof(b.var));
         std::memcpy(b.twist_level, a.twist_level, sizeof(b.twist_level));
         std::memcpy(b.b_segm, a.b_segm, sizeof(b.b_segm));
@@ -474,6 +478,27 @@ int sfo_test_set_exact_sums(sf_handle *h, int on) {
     if (!h) return fail(SF_ERR_ARG, "null");
     for (auto &s : h->s) s->exact_sums = on != 0;
     return SF_OK;
+}
+// test hooks (not part of include/sf.h): summation convention of AtA / AtB and the HIP build's behind-the-camera rule
+// (sf_oracle.hpp: gemm_mode, hip_behind_camera_rule); the count of validPixels with a negative warped depth
+int sfo_test_set_gemm_mode(sf_handle *h, int mode) {
+    if (!h || mode < 0 || mode > 3) return fail(SF_ERR_ARG, "gemm mode 0..3");
+    for (auto &s : h->s) s->gemm_mode = mode;
+    return SF_OK;
+}
+int sfo_test_set_exact_warp(sf_handle *h, int on) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    for (auto &s : h->s) s->exact_warp = on != 0;
+    return SF_OK;
+}
+int sfo_test_set_hip_behind_camera_rule(sf_handle *h, int on) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    for (auto &s : h->s) s->hip_behind_camera_rule = on != 0;
+    return SF_OK;
+}
+long long sfo_test_behind_camera_valid(sf_handle *h, int stream) {
+    if (!h || stream < 0 || stream >= h->batch) return -1;
+    return h->s[stream]->behind_camera_valid;
 }
 // test hook (not part of include/sf.h): the weight function of include/sf_detmath.h, evaluated by this library
 void sfo_test_exp_neg(const float *a, int n, float *out) {

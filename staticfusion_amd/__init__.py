@@ -9,6 +9,7 @@ bench.  There is NO CPU fallback: `load()` raises if the HIP library is missing.
 import os
 
 from ._capi import Api, Solver, SurfelMap, SfParams, SfFrameStats, SfError  # noqa: F401
+from ._capi import STATUS_EIG_SKIPPED, STATUS_EMPTY_LEVEL, STATUS_SYNC_TIMEOUT  # noqa: F401
 from . import _capi as capi  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

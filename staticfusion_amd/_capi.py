@@ -24,6 +24,7 @@ VARIANT_NAMES = {"auto": 0, "throughput": 1, "latency": 2, "cluster": 3}
 
 STATUS_EIG_SKIPPED = 1
 STATUS_EMPTY_LEVEL = 2
+STATUS_SYNC_TIMEOUT = 4  # cluster build: a rendezvous timed out; the frame is not valid and the stream keeps its previous state
 
 
 class SfParams(C.Structure):
@@ -71,6 +72,7 @@ class SfOuterTrace(C.Structure):
         ("lambda_t_w", C.c_float * NUM_CLUSTERS),
         ("AtA", C.c_float * 36),
         ("AtB", C.c_float * 6),
+        ("delta_sol_max", C.c_float),
     ]
 
 
@@ -109,7 +111,7 @@ SIGNATURES = {
     "set_prediction": (C.c_int, [_H, C.c_int, _fp, _fp]),
     "set_current_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "set_prediction_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
-    "advance_sequences_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, _ip]),
+    "advance_sequences_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, _ip, C.c_int]),
     "upload_current_async": (C.c_int, [_H, _fp, _fp]),
     "commit_upload": (C.c_int, [_H]),
     "alloc_pinned": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -350,11 +352,12 @@ class Solver:
         self.api.check(self.api.get_prediction(self.h, stream, d.ctypes.data_as(_fp), i.ctypes.data_as(_fp)))
         return d.T.copy(), i.T.copy()
 
-    def advance_sequences_device(self, pool_depth_ptr, pool_intensity_ptr, frame_index):
-        """prediction := current; current := pool frame frame_index[b] (device pools [frame][cols][rows]; host index array)"""
+    def advance_sequences_device(self, pool_depth_ptr, pool_intensity_ptr, frame_index, pool_frames):
+        """prediction := current; current := pool frame frame_index[b] (device pools [pool_frames][cols][rows]; host index array)"""
         idx = np.ascontiguousarray(frame_index, dtype=np.int32)
         assert idx.shape == (self.batch_size,)
-        self.api.check(self.api.advance_sequences_device(self.h, C.c_void_p(pool_depth_ptr), C.c_void_p(pool_intensity_ptr), idx.ctypes.data_as(_ip)))
+        self.api.check(self.api.advance_sequences_device(self.h, C.c_void_p(pool_depth_ptr), C.c_void_p(pool_intensity_ptr), idx.ctypes.data_as(_ip),
+                                                         int(pool_frames)))
 
     def current_to_prediction(self):
         self.api.check(self.api.current_to_prediction(self.h))

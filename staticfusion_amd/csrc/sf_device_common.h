@@ -247,13 +247,23 @@ template <class T, class V>
 __device__ __forceinline__ void gst(gptr<T> p, int idx, V v) {
     *(gptr<T>)((__attribute__((address_space(1))) char *)p + gbyte_off(idx, (unsigned)sizeof(T))) = (T)v;
 }
+// Scope of the warp / residual accumulator cells. In the one-workgroup-per-stream builds a stream's accumulators are
+// touched by ONE workgroup between two kernel boundaries, so workgroup scope is all the coherence they need: the atomics
+// then complete in this XCD's L2 and a cell is written back once, when its line is evicted. Agent scope (what a cluster
+// of workgroups on different CUs needs) makes every atomic write through to the fabric: the zero store AND the sums both
+// reached HBM, 34 bytes written per pixel and warp where 16 are needed (profiles/r02j_traffic_by_stage.txt).
+#if defined(SF_CLUSTER) || defined(SF_ACC_AGENT)
+#define SF_ACC_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#else
+#define SF_ACC_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
 __device__ __forceinline__ void gatomic_add_at(gptr<long long> p, int idx, long long v) {
-    __hip_atomic_fetch_add((gptr<long long>)((__attribute__((address_space(1))) char *)p + gbyte_off(idx, 8u)), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add((gptr<long long>)((__attribute__((address_space(1))) char *)p + gbyte_off(idx, 8u)), v, __ATOMIC_RELAXED, SF_ACC_SCOPE);
 }
 template <class P>
-__device__ __forceinline__ long long gld_agent_i64(P p, int idx) {  // agent-scope (L1-bypassing) load of a 64-bit cell
+__device__ __forceinline__ long long gld_agent_i64(P p, int idx) {  // load of a 64-bit accumulator cell at the accumulators' scope
     return __hip_atomic_load((gptr<const long long>)((__attribute__((address_space(1))) const char *)p + gbyte_off(idx, 8u)), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
+                             SF_ACC_SCOPE);
 }
 __device__ __forceinline__ void gatomic_add(gptr<long long> p, long long v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

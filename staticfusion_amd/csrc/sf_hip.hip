@@ -157,6 +157,7 @@ struct sf_handle {
     int *seq_index_host = nullptr;
     hipEvent_t seq_done[SEQ_SLOTS] = {};
     unsigned seq_calls = 0;
+    bool seq_ready = false;  // index ring + events all created
 };
 
 static thread_local std::string g_err;
@@ -624,15 +625,22 @@ int sf_set_current_device(sf_handle *h, const void *d, const void *i) {
 int sf_set_prediction_device(sf_handle *h, const void *d, const void *i) {
     return h ? copy_batch_device(h, h->k.pyr_pred, d, i) : fail(SF_ERR_ARG, "null");
 }
-int sf_advance_sequences_device(sf_handle *h, const void *pool_depth, const void *pool_intensity, const int32_t *frame_index) {
+int sf_advance_sequences_device(sf_handle *h, const void *pool_depth, const void *pool_intensity, const int32_t *frame_index, int pool_frames) {
     if (!h || !pool_depth || !pool_intensity || !frame_index) return fail(SF_ERR_ARG, "null");
+    if (pool_frames < 1) return fail(SF_ERR_ARG, "pool_frames < 1");
     if (h->k.n0 % 4 || h->k.n_tot % 4) return fail(SF_ERR_ARG, "level sizes must be multiples of 4 pixels");
-    HIP_TRY(hipSetDevice(h->device));
+    if (((uintptr_t)pool_depth | (uintptr_t)pool_intensity) & 15u) return fail(SF_ERR_ARG, "the frame pools must be 16-byte aligned (16-byte loads)");
     const size_t B = (size_t)h->k.batch;
-    if (!h->seq_index) {
-        if (int e = dev_alloc(h, &h->seq_index, B * sf_handle::SEQ_SLOTS)) return e;
-        HIP_TRY(hipHostMalloc((void **)&h->seq_index_host, sizeof(int) * B * sf_handle::SEQ_SLOTS, hipHostMallocDefault));
-        for (auto &e : h->seq_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (size_t b = 0; b < B; b++)
+        if (frame_index[b] >= pool_frames) return fail(SF_ERR_ARG, "frame_index entry outside the pool");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->seq_ready) {  // all or nothing: a failure leaves nothing half-initialised behind (the next call starts over)
+        if (!h->seq_index)
+            if (int e = dev_alloc(h, &h->seq_index, B * sf_handle::SEQ_SLOTS)) return e;
+        if (!h->seq_index_host) HIP_TRY(hipHostMalloc((void **)&h->seq_index_host, sizeof(int) * B * sf_handle::SEQ_SLOTS, hipHostMallocDefault));
+        for (auto &e : h->seq_done)
+            if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->seq_ready = true;
     }
     const unsigned slot = h->seq_calls % sf_handle::SEQ_SLOTS;
     if (h->seq_calls >= (unsigned)sf_handle::SEQ_SLOTS) HIP_TRY(hipEventSynchronize(h->seq_done[slot]));  // eight calls ago

@@ -53,11 +53,24 @@ struct LinTile {  // linearisation tile (with halo)
     uint8_t t_null[TILE_N];
 };
 
+// Pass 1 keeps the 27 normal-equation sums per lane in fp32 and, every SF_P1_FLUSH pixel pairs, adds them -- reduced over a
+// group of P1_GROUP neighbouring lanes on the DPP network -- into fp64 sums in LDS (one set per lane group; entry-major, so
+// the group leaders of a wave touch consecutive 8-byte words). A lane's fp32 partial sum then never holds more than
+// 4 SF_P1_FLUSH terms: the rounding error of the accumulated AtA / AtB drops about tenfold against one fp32 sum over the
+// lane's whole share (<= 600 terms at QVGA), which is what moved b by 4e-5 against the oracle's fp64 sums ([C1]).
+#ifndef SF_P1_FLUSH
+#define SF_P1_FLUSH 32
+#endif
+#define P1_GROUP (SF_NT == 256 ? 4 : 16)  // 1024-thread builds: a lane sums a quarter of the terms, rows of 16 lanes share a set
+#define P1_SETS (SF_NT / P1_GROUP)
+#define P1_SETS_PER_WAVE (64 / P1_GROUP)
+
 struct SolveShared {
     union {            // the warp window and the linearisation tile are never live together; the fp64 scratch of the
         LinTile lt;    // one-lane algebra (4 x 4 inverse before a warp, motion filter after the IRLS, 3 x 3 inverse at the
-        SplatWin win;  // end of the solve) is used while neither is
+        SplatWin win;  // end of the solve) is used while neither is, and so are the fp64 sums of pass 1
         double dwork[36 * 3 + 32];
+        double p1[27][P1_SETS];
     };
     // reductions
     double red[SF_NW][28];
@@ -76,6 +89,7 @@ struct SolveShared {
     // IRLS
     float AtA[36], AtB[6], Var[6], prev_sol[6];
     float aver_res, aver_res_old, inv_max_c, inv_max_d, res_sqnorm;
+    float last_delta;  // |Var - prev_sol|_inf of the last IRLS iteration (the trace reports it)
     double sq_total;  // ||res||^2 of the last pass 2, summed over the workgroups of the cluster
     int px_begin, px_end;  // pixel range of the level the streaming passes walk: this workgroup's share of the level
     int rec_slot;          // record slot the passes stream (the stream's, or this workgroup's private one)
@@ -167,16 +181,18 @@ template <int VEC>
 struct RecVec {
     float v[R_COUNT][VEC];
     float dn[VEC];
+    unsigned labraw;  // the VEC label bytes as loaded; unpacked at the point of use (rec_label)
     int lab[VEC];
 };
 template <int VEC>
 __device__ __forceinline__ void load_rec(const RecPtrs &rp, int idx0, RecVec<VEC> &r) {
-    if (rp.with_labels) {  // uniform: without segmentation every valid pixel belongs to cluster 0 and the plane is not read
-        load_labels<VEC>(rp.lab, idx0, r.lab);
-    } else {
-#pragma unroll
-        for (int j = 0; j < VEC; j++) r.lab[j] = 0;
-    }
+    static_assert(VEC == 2, "the passes walk pixel pairs");
+    // uniform: without segmentation every valid pixel belongs to cluster 0 and the plane is not read. The bytes are kept
+    // as loaded: unpacking them here, inside the branch, made the compiler wait for the load (s_waitcnt vmcnt(0)) BEFORE
+    // the other seven loads of the record were issued -- two memory round trips per trip of the loop
+    unsigned raw = 0;
+    if (rp.with_labels) raw = *(gcu16 *)((gcchar *)rp.lab + (unsigned)idx0);
+    r.labraw = raw;
     load_plane<VEC>(rp.dnew, idx0, r.dn);
 #pragma unroll
     for (int q = 0; q < R_COUNT; q++) load_plane<VEC>(rp.p[q], idx0, r.v[q]);
@@ -781,7 +797,7 @@ __device__ __forceinline__ bool sanitize(RecVec<VEC> &r, int j) {
     r.v[R_DW][j] = ok ? r.v[R_DW][j] : 1.f;
     // the four gradients and dct of such a pixel are stored as 0 by the linearisation (dct keeps its value in the debug-plane
     // mode only): nothing to do for them here
-    r.lab[j] = ok ? r.lab[j] : 0;
+    r.lab[j] = ok ? (int)((j ? r.labraw >> 8 : r.labraw) & 255u) : 0;
     return ok;
 }
 
@@ -850,22 +866,55 @@ __device__ __forceinline__ void accum_row(float (&acc)[27], const float (&aw)[7]
     acc[25] = fmaf(aw[4], aw[6], acc[25]);  acc[26] = fmaf(aw[5], aw[6], acc[26]);
 }
 
+// sum of v over the lane's group of P1_GROUP lanes (every lane of the group ends up with the same bits: the two / four
+// exchange steps are symmetric). All 64 lanes must be active.
+__device__ __forceinline__ float p1_group_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+    if constexpr (P1_GROUP == 16) {
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));  // row_mirror
+    }
+    return v;
+}
+__device__ __forceinline__ void p1_flush(float (&acc)[27], LDS SolveShared &s, int set, bool leader) {
+#pragma unroll
+    for (int q = 0; q < 27; q++) acc[q] = p1_group_sum(acc[q]);
+    if (leader) {  // the set belongs to this lane group alone: plain read-modify-writes, one exec-mask change for all 27
+#pragma unroll
+        for (int q = 0; q < 27; q++) s.p1[q][set] += (double)acc[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 27; q++) acc[q] = 0.f;
+}
+
 template <int VAR>
 __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, LDS SolveShared &s, int tid) {
     const IrlsCtx c = make_irls_ctx(a, b, L, s);
+    const int lane = tid & 63, wave = tid >> 6;
     const float inv_c_Cauchy = 1.f / (a.p.kc_Cauchy * uniform_f(s.aver_res));
     float acc[27];
 #pragma unroll
     for (int q = 0; q < 27; q++) acc[q] = 0.f;
+    const int set = tid / P1_GROUP;
+    const bool leader = (tid % P1_GROUP) == 0;
+    if (lane < P1_SETS_PER_WAVE) {  // this wave's sets (nobody else touches them: no barrier, LDS operations of a wave are ordered)
+#pragma unroll
+        for (int q = 0; q < 27; q++) s.p1[q][wave * P1_SETS_PER_WAVE + lane] = 0.0;
+    }
     float Vr[6];
 #pragma unroll
     for (int q = 0; q < 6; q++) Vr[q] = uniform_f(s.Var[q]);
     const int last = (c.n - 2) & ~1;  // the prefetch past the end re-reads the last pair instead of branching
     RecVec<2> rv, nx;
-    if (c.begin + tid * 2 < c.n) load_rec<2>(c.rp, c.begin + tid * 2, rv);
-    for (int i0 = c.begin + tid * 2; i0 < c.n; i0 += SF_NT * 2) {
+    // the trip count is the WAVE's (its first lane's): every lane stays active to the end, so that the group sums of a
+    // flush see all their lanes; a lane past the end re-reads the last pair with weight 0
+    load_rec<2>(c.rp, min(c.begin + tid * 2, last), rv);
+    int since = 0;
+    for (int i0 = c.begin + tid * 2, iw = uniform_i(c.begin + (tid - lane) * 2); iw < c.n; i0 += SF_NT * 2, iw += SF_NT * 2) {
         load_rec<2>(c.rp, min(i0 + SF_NT * 2, last), nx);
-        const bool ok0 = sanitize<2>(rv, 0), ok1 = sanitize<2>(rv, 1);
+        const bool in = i0 < c.n;
+        const bool ok0 = sanitize<2>(rv, 0) && in, ok1 = sanitize<2>(rv, 1) && in;
         if constexpr (VAR == 1) {
             float t = rv.dn[0] + rv.dn[1];
 #pragma unroll
@@ -876,7 +925,7 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, LDS SolveS
         }
         float bseg0 = s.b_segm[rv.lab[0]], bseg1 = s.b_segm[rv.lab[1]];  // invalid pixels carry label 0 after sanitize()
         float fu0, fv0;
-        split_index(c.g, i0, fu0, fv0);
+        split_index(c.g, min(i0, last), fu0, fv0);
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const bool ok = j ? ok1 : ok0;
@@ -932,12 +981,21 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, LDS SolveS
                 accum_row(acc, aw);
         }
         rv = nx;
+        if constexpr (VAR == 0) {
+            if (++since == SF_P1_FLUSH) {  // uniform: every lane of the wave has made the same number of trips
+                since = 0;
+                p1_flush(acc, s, set, leader);
+            }
+        }
     }
-    const int lane = tid & 63, wave = tid >> 6;
+    p1_flush(acc, s, set, leader);
+    // this wave's sets, in order -> s.red[wave][0..26]
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 27) {
+        double t = 0.0;
 #pragma unroll
-    for (int q = 0; q < 27; q++) {
-        const double t = wave_sum_f64((double)acc[q]);
-        if (lane == 0) s.red[wave][q] = t;
+        for (int g = 0; g < P1_SETS_PER_WAVE; g++) t += s.p1[lane][wave * P1_SETS_PER_WAVE + g];
+        s.red[wave][lane] = t;
     }
 }
 
@@ -1149,6 +1207,7 @@ __device__ __noinline__ void irls_iteration_tail(const KArgs &a, LDS SolveShared
         float delta = 0.f;
         for (int c = 0; c < 6; c++) delta = std_max(delta, fabsf(s.prev_sol[c] - s.Var[c]));
         for (int c = 0; c < 6; c++) s.prev_sol[c] = s.Var[c];
+        s.last_delta = delta;
         s.ctrl = ((delta < a.p.irls_delta_threshold) || (k == a.p.max_iter_irls)) ? 1 : 0;
         s.n_irls++;
         s.pixel_iters += N;
@@ -1188,6 +1247,7 @@ __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level,
         if (tr) {
             if (tid == 0) {
                 tr->level = level; tr->k = kouter; tr->n_valid = 0; tr->irls_iters = 0; tr->aver_res = 0.f;
+                tr->delta_sol_max = 0.f;
             }
             if (tid < 6) tr->var[tid] = tr->twist_level[tid] = tr->AtB[tid] = 0.f;
             if (tid < 16) tr->T[tid] = s.T[tid];
@@ -1236,6 +1296,7 @@ __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level,
         if (lane == 0) {
             tr->level = level; tr->k = kouter; tr->n_valid = N; tr->irls_iters = iters_done;
             tr->aver_res = s.aver_res;
+            tr->delta_sol_max = s.last_delta;
         }
         if (lane < 6) {
             tr->var[lane] = s.Var[lane];

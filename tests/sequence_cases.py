@@ -1,0 +1,102 @@
+"""Random eight-frame sequences with carried state -- the cases of the parity hunts (tools/diag/sequence_hunt.py) and of
+the regression test that replays the seeds those hunts found (tests/test_gpu_parity_hunt.py).
+
+A case is a pure function of its seed: scene, camera twist per frame (0.2 .. 2.5 x the default step, random signs), a
+sphere that moves on its own, kb. `run_case` drives one backend (the HIP library or the oracle, same ABI) through the
+reference drivers' frame loop -- frame 0 is the first prediction, then frame-to-frame with the 5-frame residuals from
+frame 5 on (reference StaticFusion-datasets.cpp:171-184) -- and returns everything the comparisons need per frame.
+"""
+import numpy as np
+
+from staticfusion_amd.synth import DEFAULT_XI, LCG64, Scene, pose_delta, quantise_and_decimate, se3_exp
+
+N_FRAMES = 9  # frame 0 + eight solved frames
+
+
+def make_case(seed, width=320, height=240, seg=True):
+    """Frames (depth, intensity at height/2 x width/2), kb and the parameter overrides of hunt case `seed`."""
+    g = LCG64(seed)
+    scene = Scene(seed=seed, sphere=True, sphere_seed=seed + 17)
+    scale = g.uniform(0.2, 2.5)
+    xi = np.array(DEFAULT_XI) * scale * np.array([g.uniform(0.5, 1.5) * (1 if g.uniform() < 0.5 else -1) for _ in range(6)])
+    step = (g.uniform(-0.03, 0.03), g.uniform(-0.01, 0.01), g.uniform(-0.01, 0.01))
+    frames, T = [], np.eye(4)
+    for k in range(N_FRAMES):
+        d, i = scene.render(T, width, height, sphere_offset=tuple(k * s for s in step))
+        frames.append(quantise_and_decimate(d, i))
+        T = T @ se3_exp(xi)
+    kb = g.uniform(1.0, 1.6)
+    over = {} if seg else dict(segmentation_enabled=0, ctf_levels=3)  # pure odometry: BASELINE configs[1]
+    return {"seed": seed, "frames": frames, "kb": kb, "over": over, "scale": scale, "xi": xi}
+
+
+def _params(api, kb, over):
+    p = api.default_params_struct()
+    p.kb = kb
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def run_case(api, case, variant=None, prepare=None):
+    """-> list over the eight solved frames of dict(T, labels, b_img, b, counts, outer). `prepare(solver)` may set test hooks."""
+    import staticfusion_amd as sf
+
+    frames = case["frames"]
+    rows, cols = frames[0][0].shape
+    s = sf.Solver(api, rows, cols, 1, _params(api, case["kb"], case["over"]), variant=variant)
+    if prepare is not None:
+        prepare(s)
+    out = []
+    s.set_current(0, *frames[0])
+    s.current_to_prediction()
+    s.push_history(0)
+    for k in range(1, N_FRAMES):
+        s.set_prediction(0, *frames[k - 1])
+        s.set_current(0, *frames[k])
+        s.process_frame(k)
+        st = s.stats()
+        out.append({
+            "T": s.T().copy(), "labels": s.labels(0).copy(), "b_img": s.b_image().copy(), "b": s.b().copy(),
+            "counts": (int(st.n_outer), int(st.n_irls)), "status": int(st.status),
+            "outer": [(int(o.level), int(o.k), int(o.irls_iters), float(o.delta_sol_max), int(o.n_valid))
+                      for o in (st.outer[i] for i in range(st.n_outer))],
+        })
+    s.close()
+    return out
+
+
+def compare_frames(ref, got, thr):
+    """One record per frame: pose distance, discrete mismatches, b distances, and -- when the IRLS counts differ -- whether
+    it is a STOPPING-THRESHOLD FLIP: one level whose count differs by one while the `delta_sol_max` the stopping test
+    (reference FrontEnd.cpp:676-679) saw on either side lies within `flip_margin` of irls_delta_threshold."""
+    recs = []
+    for k, (a, b) in enumerate(zip(ref, got)):
+        rot, trans = pose_delta(a["T"], b["T"])
+        rec = {
+            "frame": k + 1, "rot": rot, "trans": trans,
+            "label_px": int((a["labels"] != b["labels"]).sum()),
+            "decision_px": int(((a["b_img"] > 0.5) != (b["b_img"] > 0.5)).sum()),
+            "b_img": float(np.abs(a["b_img"] - b["b_img"]).max()),
+            "b24": float(np.abs(a["b"] - b["b"]).max()),
+            "counts": list(b["counts"]), "counts_ref": list(a["counts"]),
+        }
+        if a["counts"] != b["counts"]:
+            rec["flip"] = classify_flip(a["outer"], b["outer"], thr)
+        recs.append(rec)
+    return recs
+
+
+def classify_flip(outer_ref, outer_got, thr, rel_margin=0.05):
+    """The first outer iteration whose IRLS count differs, and how close to the threshold the deciding delta was."""
+    for i, (a, b) in enumerate(zip(outer_ref, outer_got)):
+        if a[:2] != b[:2]:
+            return {"kind": "outer-structure", "outer": i}
+        if a[2] != b[2]:
+            # the side that stopped EARLIER reports the delta that passed the test; the other side's delta at that
+            # iteration is not in the trace, but both are the same quantity up to rounding
+            early = a if a[2] < b[2] else b
+            margin = abs(early[3] - thr) / thr
+            return {"kind": "threshold" if (abs(a[2] - b[2]) == 1 and margin <= rel_margin) else "other", "outer": i, "level": a[0],
+                    "irls": [a[2], b[2]], "delta_at_stop": early[3], "threshold": thr, "rel_margin": margin}
+    return {"kind": "outer-count", "outer": min(len(outer_ref), len(outer_got))}

@@ -58,11 +58,11 @@ def _worker(rank, world, port, q):
     pool_i = np.stack([col(f[1]) for sq in seqs for f in sq["frames"]])
     sq_solver = sf.Solver(api, 60, 80, D, bench.make_params(api, "sequences"))
     idx = lambda step: (np.arange(D) * F + step).astype(np.int32)
-    sq_solver.advance_sequences_device(pool_d.ctypes.data, pool_i.ctypes.data, idx(0))
+    sq_solver.advance_sequences_device(pool_d.ctypes.data, pool_i.ctypes.data, idx(0), D * F)
     sq_solver.push_history(0)
     its, err = 0, 0.0
     for step in range(1, F):
-        sq_solver.advance_sequences_device(pool_d.ctypes.data, pool_i.ctypes.data, idx(step))
+        sq_solver.advance_sequences_device(pool_d.ctypes.data, pool_i.ctypes.data, idx(step), D * F)
         d_pred, _ = sq_solver.prediction(0)
         assert np.array_equal(d_pred, seqs[0]["frames"][step - 1][0])  # prediction is the previous frame
         sq_solver.process_frame(step)

@@ -22,8 +22,7 @@ def _sweep_cases():
     return range(first, last)
 
 
-@pytest.mark.parametrize("case", _sweep_cases())
-def test_random_parameter_sweep(hip, ora, pair, case):
+def sweep_case(hip, ora, pair, case, tol_twist=5e-6, tol_b=5e-4, rtol_aver=1e-3):
     """parameters drawn from the ranges the drivers / constructor use (StaticFusion-datasets.cpp:79-94, FrontEnd.cpp:57-76)"""
     g = LCG64(9000 + case)
     u = lambda lo, hi: lo + (hi - lo) * g.uniform()
@@ -37,12 +36,17 @@ def test_random_parameter_sweep(hip, ora, pair, case):
     xi = tuple(float(u(0.4, 1.6)) * np.array(DEFAULT_XI))
     pr = pair(seed=300 + case, sphere=sphere, rows=120, cols=160, xi=xi)
     sg, so = solve_both(hip, ora, 120, 160, lambda a: driver_params(a, kb=kb, **over), pr)
-    assert_traces_match(sg, so, tol_twist=5e-6, tol_b=5e-4, rtol_aver=1e-3)
+    assert_traces_match(sg, so, tol_twist=tol_twist, tol_b=tol_b, rtol_aver=rtol_aver)
     rot, trans = pose_delta(so.T(), sg.T())
     assert rot <= POSE_TOL and trans <= POSE_TOL
     for L in range(sg.levels):
         assert np.array_equal(sg.labels(L), so.labels(L))
     assert np.array_equal(sg.b_image() > 0.5, so.b_image() > 0.5)
+
+
+@pytest.mark.parametrize("case", _sweep_cases())
+def test_random_parameter_sweep(hip, ora, pair, case):
+    sweep_case(hip, ora, pair, case)
 
 
 def test_sequence_through_the_input_stage(hip, ora):

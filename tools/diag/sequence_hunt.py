@@ -1,68 +1,150 @@
-"""One-off hunt: N random 8-frame sequences (carried state, 5-frame residuals from frame 5 on) at 160 x 120 through
-sf_process_frame on every build of the frame kernel against the oracle. Prints the worst deviations and every mismatch.
-usage (GPU box): python tools/diag/sequence_hunt.py [first_seed] [count] [render_width render_height]"""
-import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np
-import staticfusion_amd as sf
-from oracle import binding
-from staticfusion_amd.synth import DEFAULT_XI, LCG64, Scene, pose_delta, quantise_and_decimate, se3_exp
-from conftest import driver_params, make_solver
+"""Parity hunt: N random eight-frame sequences (tests/sequence_cases.py: carried state, 5-frame residuals from frame 5 on)
+through sf_process_frame on every build of the frame kernel against the oracle -- or, with --control, the ORACLE AGAINST
+ITSELF under another summation convention (no GPU needed) -- and a JSON record of every frame that is worth a look.
 
-first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 5000), (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
-W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (320, 240)  # rendered size; the solver sees half of it
-binding.build()
-ora = binding.load()
-worst = {"rot": 0.0, "trans": 0.0, "b": 0.0}
-bad = 0
-frames_total = 0
-b_over = {1e-4: 0, 1e-3: 0, 1e-2: 0}
-pose_over = {1e-6: 0, 1e-5: 0}
-for seed in range(first, first + count):
-    g = LCG64(seed)
-    scene = Scene(seed=seed, sphere=True, sphere_seed=seed + 17)
-    scale = g.uniform(0.2, 2.5)
-    xi = np.array(DEFAULT_XI) * scale * np.array([g.uniform(0.5, 1.5) * (1 if g.uniform() < 0.5 else -1) for _ in range(6)])
-    step = (g.uniform(-0.03, 0.03), g.uniform(-0.01, 0.01), g.uniform(-0.01, 0.01))
-    frames, T = [], np.eye(4)
-    for k in range(9):
-        d, i = scene.render(T, W, H, sphere_offset=tuple(k * s for s in step))
-        frames.append(quantise_and_decimate(d, i))
-        T = T @ se3_exp(xi)
-    rows, cols = frames[0][0].shape
-    kb = g.uniform(1.0, 1.6)
-    over = dict(segmentation_enabled=0, ctf_levels=3) if os.environ.get("SF_HUNT_SEG") == "0" else {}  # pure odometry (configs[1])
-    so = make_solver(ora, rows, cols, driver_params(ora, kb=kb, **over))
-    ref = []
-    so.set_current(0, *frames[0]); so.current_to_prediction(); so.push_history(0)
-    for k in range(1, 9):
-        so.set_prediction(0, *frames[k - 1]); so.set_current(0, *frames[k]); so.process_frame(k)
-        ref.append((so.T().copy(), so.labels(0).copy(), so.b_image().copy(), (so.stats().n_outer, so.stats().n_irls)))
-    for variant in ("throughput", "latency", "cluster"):
-        sg = make_solver(sf.load().with_variant(variant), rows, cols, driver_params(sf.load(), kb=kb, **over))
-        sg.set_current(0, *frames[0]); sg.current_to_prediction(); sg.push_history(0)
-        for k in range(1, 9):
-            sg.set_prediction(0, *frames[k - 1]); sg.set_current(0, *frames[k]); sg.process_frame(k)
-            T_o, lab_o, b_o, cnt_o = ref[k - 1]
-            rot, trans = pose_delta(T_o, sg.T())
-            db = float(np.abs(sg.b_image() - b_o).max())
-            worst["rot"], worst["trans"], worst["b"] = max(worst["rot"], rot), max(worst["trans"], trans), max(worst["b"], db)
-            frames_total += 1
-            for t in b_over:
-                b_over[t] += db > t
-            for t in pose_over:
-                pose_over[t] += max(rot, trans) > t
-            ok = rot <= 1e-4 and trans <= 1e-4 and np.array_equal(sg.labels(0), lab_o) and np.array_equal(sg.b_image() > 0.5, b_o > 0.5) \
-                and (sg.stats().n_outer, sg.stats().n_irls) == cnt_o
-            if not ok:
-                bad += 1
-                print("MISMATCH seed %d %s frame %d: rot %.2e trans %.2e labels %d px decisions %d px counts %s vs %s" % (
-                    seed, variant, k, rot, trans, int((sg.labels(0) != lab_o).sum()), int(((sg.b_image() > 0.5) != (b_o > 0.5)).sum()),
-                    (sg.stats().n_outer, sg.stats().n_irls), cnt_o))
-                break
-        sg.close()
-    so.close()
-print("%d sequences x 3 builds x 8 frames at %dx%d: %d mismatching runs; worst pose %.2e rad %.2e m, worst |b - b_oracle| %.2e" % (
-    count, cols, rows, bad, worst["rot"], worst["trans"], worst["b"]))
-print("frames %d; |b - b_oracle| above %s; pose difference above %s" % (frames_total, dict(b_over), dict(pose_over)))
+    python tools/diag/sequence_hunt.py --first 20000 --count 1000 --json profiles/r03_hunt_160x120_s20000.json
+    python tools/diag/sequence_hunt.py --first 20000 --count 1000 --control gemm2 --json profiles/r03_control_gemm2.json
+    python tools/diag/sequence_hunt.py --first 7000 --count 60 --size 640x480 ...        (the solver then sees QVGA)
+
+--control MODE  compare oracle [C1] (float operands, fp64 sums) with the oracle in MODE:
+    gemm1  AtA / AtB accumulated in ONE float per entry          gemm2  four interleaved float partial sums (SSE packets)
+    gemm3  [C1] over the rows in reverse order                   exact  the per-cluster fp32 sums in fp64 (sfo_test_set_exact_sums)
+JSON: {"summary": {...}, "frames": [every frame with a discrete mismatch, a pose distance > --keep-pose or b > --keep-b]}.
+"""
+import argparse
+import ctypes
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+CONTROL_MODES = {"gemm1": ("gemm", 1), "gemm2": ("gemm", 2), "gemm3": ("gemm", 3), "exact": ("exact", 1)}
+
+
+def _control_prepare(mode):
+    kind, val = CONTROL_MODES[mode]
+
+    def prepare(solver):
+        lib = solver.api.lib
+        fn = lib.sfo_test_set_gemm_mode if kind == "gemm" else lib.sfo_test_set_exact_sums
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        assert fn(solver.h, val) == 0
+
+    return prepare
+
+
+def _worker(job):
+    """One seed on the CPU: the case, the oracle's frames, and (control) the second oracle's frames."""
+    seed, W, H, seg, control = job
+    from oracle import binding
+    from sequence_cases import make_case, run_case
+
+    ora = binding.load()
+    case = make_case(seed, W, H, seg)
+    ref = run_case(ora, case)
+    other = run_case(ora, case, prepare=_control_prepare(control)) if control else None
+    return seed, case, ref, other
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--first", type=int, default=5000)
+    ap.add_argument("--count", type=int, default=20)
+    ap.add_argument("--size", default="320x240", help="RENDERED size; the solver sees half of it")
+    ap.add_argument("--no-seg", action="store_true", help="pure odometry (BASELINE configs[1] parameters)")
+    ap.add_argument("--builds", default="throughput,latency,cluster")
+    ap.add_argument("--control", choices=sorted(CONTROL_MODES), default=None)
+    ap.add_argument("--procs", type=int, default=0)
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--keep-pose", type=float, default=1e-5)
+    ap.add_argument("--keep-b", type=float, default=1e-3)
+    a = ap.parse_args()
+    W, H = (int(x) for x in a.size.split("x"))
+    from oracle import binding
+    from sequence_cases import compare_frames
+
+    binding.build()
+    thr = float(binding.load().default_params_struct().irls_delta_threshold)
+    builds = [] if a.control else [b for b in a.builds.split(",") if b]
+    if builds:
+        import staticfusion_amd as sf
+        from sequence_cases import run_case
+
+        hip = sf.load()
+    cap = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        cap = None if q == "max" else int(float(q) / float(p))
+    except Exception:
+        pass
+    procs = a.procs or max(1, min(len(os.sched_getaffinity(0)), cap or 64) - (1 if builds else 0))
+
+    pose_bins, b_bins = (1e-6, 1e-5, 1e-4), (1e-5, 1e-4, 1e-3, 1e-2)
+    summ = {"frames": 0, "runs": 0, "label_mismatch_frames": 0, "decision_mismatch_frames": 0, "count_mismatch_frames": 0,
+            "threshold_flips": 0, "other_count_mismatches": 0, "pose_over": {str(t): 0 for t in pose_bins},
+            "b24_over": {str(t): 0 for t in b_bins}, "b_img_over": {str(t): 0 for t in b_bins},
+            "worst": {"rot": 0.0, "trans": 0.0, "b24": 0.0, "b_img": 0.0}, "pose_over_1e-4_not_flip": 0}
+    kept = []
+    t0 = time.time()
+    jobs = [(s, W, H, not a.no_seg, a.control) for s in range(a.first, a.first + a.count)]
+    with mp.get_context("spawn").Pool(procs) as pool:
+        for seed, case, ref, other in pool.imap(_worker, jobs, chunksize=1):
+            runs = [("oracle:" + a.control, other)] if a.control else [(b, run_case(hip.with_variant(b), case)) for b in builds]
+            for name, got in runs:
+                summ["runs"] += 1
+                after_flip = False
+                for rec in compare_frames(ref, got, thr):
+                    summ["frames"] += 1
+                    pose = max(rec["rot"], rec["trans"])
+                    for t in pose_bins:
+                        summ["pose_over"][str(t)] += pose > t
+                    for t in b_bins:
+                        summ["b24_over"][str(t)] += rec["b24"] > t
+                        summ["b_img_over"][str(t)] += rec["b_img"] > t
+                    for k in ("rot", "trans", "b24", "b_img"):
+                        summ["worst"][k] = max(summ["worst"][k], rec[k])
+                    summ["label_mismatch_frames"] += rec["label_px"] > 0
+                    summ["decision_mismatch_frames"] += rec["decision_px"] > 0
+                    flip = rec.get("flip")
+                    if flip:
+                        summ["count_mismatch_frames"] += 1
+                        if flip["kind"] == "threshold" and not after_flip:
+                            summ["threshold_flips"] += 1
+                        elif not after_flip:
+                            summ["other_count_mismatches"] += 1
+                    # a flipped frame changes the carried state: later frames of that run are not independent evidence
+                    rec["after_flip"] = after_flip
+                    if pose > 1e-4 and not (flip or after_flip):
+                        summ["pose_over_1e-4_not_flip"] += 1
+                    if flip:
+                        after_flip = True
+                    if rec["label_px"] or rec["decision_px"] or flip or pose > a.keep_pose or rec["b24"] > a.keep_b:
+                        rec.update(seed=seed, build=name, motion_scale=case["scale"])
+                        kept.append(rec)
+                        if rec["label_px"] or rec["decision_px"] or flip or pose > 1e-4:
+                            print("seed %d %s frame %d: rot %.2e trans %.2e labels %d px decisions %d px counts %s vs %s %s" % (
+                                seed, name, rec["frame"], rec["rot"], rec["trans"], rec["label_px"], rec["decision_px"], rec["counts"],
+                                rec["counts_ref"], (flip or {}).get("kind", "")), flush=True)
+    summ.update(first_seed=a.first, count=a.count, solver_size="%dx%d" % (W // 2, H // 2), segmentation=not a.no_seg,
+                compared="oracle [C1] vs oracle %s" % a.control if a.control else "HIP builds %s vs oracle" % ",".join(builds),
+                irls_delta_threshold=thr, seconds=round(time.time() - t0, 1))
+    if builds:
+        from bench import git_head, source_sha
+
+        summ["build"] = {"head": git_head(), "src_sha": source_sha(), "backend": hip.backend_name()}
+    print(json.dumps(summ))
+    if a.json:
+        os.makedirs(os.path.dirname(os.path.abspath(a.json)), exist_ok=True)
+        with open(a.json, "w") as f:
+            json.dump({"summary": summ, "frames": kept}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

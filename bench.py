@@ -81,6 +81,7 @@ def parse():
     ap.add_argument("--no-full-solver", action="store_true", help="static workload: skip the configs[2] block")
     ap.add_argument("--no-sequences", action="store_true", help="static workload: skip the sequences blocks")
     ap.add_argument("--seq-batches", default="16384,4096", help="static workload: stream counts of the sequences blocks")
+    ap.add_argument("--launch-per-frame", action="store_true", help="A/B: one kernel launch per step instead of one launch for the K timed steps")
     ap.add_argument("--pass-reps", type=int, default=4, help="repetitions of each isolated IRLS pass (roofline.irls_passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
@@ -327,15 +328,24 @@ def run_pairs_workload(hx, args, workload, batch, with_parity):
             "max_iter_irls": int(params.max_iter_irls), "max_iter_per_level": int(params.max_iter_per_level),
             "kernel_build": "%s (%d threads per workgroup, %d workgroup(s) per stream)" % variant + ", %d workgroups resident per CU (grid %d)" % resident,
             "parallelism": "independent streams, %d GPU(s)" % hx.world,
-            "step": "sf_process_frame: pyramid(old)+runSolver(true)+residuals+segm image for every stream, one launch",
+            "step": "the frame sequence of sf_process_frame -- pyramid(old) + runSolver(true) + residuals + segm image -- for every stream; "
+                    + ("one launch per step" if os.environ.get("SF_TIMED_LAUNCH_PER_FRAME") else "the K timed steps are ONE launch of sf_frame_kernel "
+                       "(sf_process_frames): a stream starts its next frame when ITS previous one is done, no barrier over the batch between steps"),
+            "launches_in_timed_region": args.steps if os.environ.get("SF_TIMED_LAUNCH_PER_FRAME") else 1,
         },
         "roofline": {
             "kernel": "sf_frame_kernel (%s build)" % variant[0],
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            # HBM bytes per launch from the PMC counters, or null when no measurement of THESE sources exists
-            "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+            # HBM bytes per launch from the PMC counters (measured per frame of every stream, tools/measure_traffic.sh, times the
+            # frames of this launch), or null when no measurement of THESE sources exists
+            "traffic": traffic["hbm_bytes_per_launch"] * (1 if os.environ.get("SF_TIMED_LAUNCH_PER_FRAME") else args.steps) if traffic else None,
             "traffic_provenance": traffic, "traffic_note": why,
-            "algorithmic_bytes_per_launch": alg_bytes_launch,
+            # one launch covers frames_per_launch steps (sf_process_frames); bytes and duration per STEP, i.e. per frame of
+            # every stream, are what `achieved` divides -- the same ratio as bytes per launch / launch duration
+            "frames_per_launch": 1 if os.environ.get("SF_TIMED_LAUNCH_PER_FRAME") else args.steps,
+            "algorithmic_bytes_per_launch": alg_bytes_launch * (1 if os.environ.get("SF_TIMED_LAUNCH_PER_FRAME") else args.steps),
+            "kernel_launch_ms": k_ms * (1 if os.environ.get("SF_TIMED_LAUNCH_PER_FRAME") else args.steps),
+            "algorithmic_bytes_per_step": alg_bytes_launch,
             "algorithmic_bytes_breakdown_per_stream": {k: v / float(len(stats_last)) for k, v in per_stream.items()},
             "kernel_ms_avg": k_ms,
             # the north star's "residual / Jacobian kernel" on its own: the two streaming passes of one IRLS iteration
@@ -445,22 +455,28 @@ def run_sequences_workload(hx, args, B, pool):
     c0 = solver.counters()
     hx.barrier(solver)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        solver.advance_sequences_device(pool_d.data_ptr(), pool_i.data_ptr(), index_at(step), D * F)
-        solver.process_frame(step)
-        step += 1
+    if args.launch_per_frame:
+        for _ in range(args.steps):
+            solver.advance_sequences_device(pool_d.data_ptr(), pool_i.data_ptr(), index_at(step), D * F)
+            solver.process_frame(step)
+            step += 1
+    else:  # the K timed steps = K frames of every stream in ONE launch (sf_process_sequence_frames_device)
+        solver.process_sequence_frames_device(pool_d.data_ptr(), pool_i.data_ptr(), np.stack([index_at(step + q) for q in range(args.steps)]), D * F, step)
+        step += args.steps
     hx.barrier(solver)
     elapsed = time.perf_counter() - t0
     c1 = solver.counters()
     frames_timed, iters_total = c1[0] - c0[0], c1[1] - c0[1]
     assert frames_timed == B * args.steps
-    # kernel duration + unit counts from three more, un-timed launches
-    k_ms, stats_last = [], None
+    # kernel duration: the timed launch itself (HIP events on the handle's stream around it) / its frames; launch-per-frame
+    # mode and the unit counts: three more, un-timed launches
+    k_ms, stats_last = ([] if args.launch_per_frame else [solver.last_solver_kernel_ms() / args.steps]), None
     for _ in range(3):
         solver.advance_sequences_device(pool_d.data_ptr(), pool_i.data_ptr(), index_at(step), D * F)
         solver.process_frame(step)
         solver.synchronize()
-        k_ms.append(solver.last_solver_kernel_ms())
+        if args.launch_per_frame:
+            k_ms.append(solver.last_solver_kernel_ms())
         step += 1
     ncheck = min(B, 4 * D)
     stats_last = [solver.stats(b) for b in range(ncheck)]
@@ -507,13 +523,20 @@ def run_sequences_workload(hx, args, B, pool):
             "max_iter_irls": int(params.max_iter_irls), "max_iter_per_level": int(params.max_iter_per_level),
             "kernel_build": "%s (%d threads per workgroup, %d workgroup(s) per stream)" % variant + ", %d workgroups resident per CU (grid %d)" % resident,
             "parallelism": "independent sequences, %d GPU(s)" % hx.world,
-            "step": "sf_advance_sequences_device (prediction := current, current := next frame from the HBM pool) + sf_process_frame",
+            "step": "prediction := current, current := next frame from the HBM pool, then the frame sequence of sf_process_frame, for every stream; "
+                    + ("one launch per step" if args.launch_per_frame else "the K timed steps are ONE launch of sf_frame_kernel (sf_process_sequence_frames_device): "
+                       "a stream starts its next frame when ITS previous one is done"),
+            "launches_in_timed_region": args.steps if args.launch_per_frame else 1,
         }),
         "roofline": {
             "kernel": "sf_frame_kernel (%s build)" % variant[0],
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic["hbm_bytes_per_launch"] if traffic else None, "traffic_provenance": traffic, "traffic_note": why,
-            "algorithmic_bytes_per_launch": alg_bytes_launch,
+            "traffic": traffic["hbm_bytes_per_launch"] * (1 if args.launch_per_frame else args.steps) if traffic else None,
+            "traffic_provenance": traffic, "traffic_note": why,
+            "frames_per_launch": 1 if args.launch_per_frame else args.steps,
+            "algorithmic_bytes_per_launch": alg_bytes_launch * (1 if args.launch_per_frame else args.steps),
+            "kernel_launch_ms": kms * (1 if args.launch_per_frame else args.steps),
+            "algorithmic_bytes_per_step": alg_bytes_launch,
             "algorithmic_bytes_breakdown_per_stream": {k: v / float(len(stats_last)) for k, v in per_stream.items()},
             "kernel_ms_avg": kms,
         },
@@ -523,6 +546,8 @@ def run_sequences_workload(hx, args, B, pool):
 
 def main():
     args = parse()
+    if args.launch_per_frame:
+        os.environ["SF_TIMED_LAUNCH_PER_FRAME"] = "1"  # sf_timed_process_frames honours it (the pairs workloads)
     hx = Harness(args)
     want_parity = not args.no_cpu_baseline
     seq_blocks = []

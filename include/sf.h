@@ -62,7 +62,11 @@ enum {
     SF_STATUS_EIG_SKIPPED = 1, /* non-finite covariance: pose update skipped (reference FrontEnd.cpp:720-724) */
     SF_STATUS_EMPTY_LEVEL = 2, /* a level had no valid pixel (reference divides by zero there, FrontEnd.cpp:505-509) */
     SF_STATUS_SYNC_TIMEOUT = 4 /* SF_VARIANT_CLUSTER: a workgroup waited too long for the others of its stream (they were not all
-                                  resident: something else occupied the GPU); the results of this frame are not valid */
+                                  resident: something else occupied the GPU). The images of this frame (labels, b image) are
+                                  not valid; the stream's solver state (T_odometry, twists, b, covariance, per-cluster
+                                  residuals, pose ring) is that of its last good frame. STICKY: every further frame of the
+                                  stream reports it and does nothing until sf_clear_sync_timeout; after that, restart the
+                                  frame counter like at start-up (the 5-frame ring took the images of the failed frame) */
 };
 
 /* The reference's parameter set: public members written by the drivers
@@ -190,6 +194,22 @@ int SF_FN(set_prediction_device)(sf_handle *h, const void *d_depth, const void *
  * call returns). */
 int SF_FN(advance_sequences_device)(sf_handle *h, const void *pool_depth, const void *pool_intensity, const int32_t *frame_index,
                                     int pool_frames);
+/* n_frames consecutive frames of every stream in ONE launch: the result of
+ *     for (k = 0; k < n_frames; k++) sf_process_frame(h, im_count0 + k);
+ * on the inputs as they are (bit for bit, every stream), without a barrier over the batch between the frames: the launch
+ * hands out (frame, stream) pairs and a stream's frame k starts as soon as ITS frame k - 1 is done, so streams that need
+ * few iterations run ahead of the slow ones instead of waiting for them at every frame (the tail of a launch per frame).
+ * T_out: NULL, or host memory for n_frames * batch * 16 floats that receives T_odometry (column-major) of every stream
+ * after every frame, [frame][stream][16]; with T_out the call returns when the launch has finished, without it the call
+ * is asynchronous like sf_process_frame. The getters report the state after the last frame. SF_VARIANT_CLUSTER handles
+ * run the frames one launch at a time (their workgroups meet inside a frame). */
+int SF_FN(process_frames)(sf_handle *h, int im_count0, int n_frames, float *T_out);
+/* The same for sequences resident in HBM: frame k of stream b is preceded by that stream's step of
+ * sf_advance_sequences_device (prediction := current, current := pool frame frame_index[k * batch + b]; a negative entry
+ * leaves the images alone). frame_index: HOST array [n_frames][batch]. The replay loop of the dataset drivers
+ * (StaticFusion-imagesequenceassoc.cpp:140-191 without the map) for `batch` sequences and n_frames frames, one launch. */
+int SF_FN(process_sequence_frames_device)(sf_handle *h, const void *pool_depth, const void *pool_intensity, const int32_t *frame_index,
+                                          int pool_frames, int im_count0, int n_frames, float *T_out);
 /* Overlapped upload for PCIe-fed deployments: sf_upload_current_async starts copying depthCurrent / intensityCurrent
  * of the WHOLE batch (host buffers laid out [batch][cols][rows]; page-locked memory from sf_alloc_pinned makes the
  * copy truly asynchronous) into a staging block on a second HIP stream and returns at once -- the solver launches
@@ -422,9 +442,9 @@ int SF_FN(get_counters)(sf_handle *h, int64_t *frames, int64_t *n_irls, int64_t 
  * 5 IRLS setup 6 IRLS pass 1 7 6x6 solve 8 IRLS pass 2 9 b-solve/convergence 10 filter/update
  * 11 residuals-vs-history 12 segm image + history push 13 total; 14..20 K-means sub-stages
  * (init, centre sort, assignment, stable partition, sequential sums, level-0 labels, connectivity +
- * label pyramid); 23 is a counter, not a timer: warp tiles that were replayed because some of their targets fell
- * outside the tile's accumulation window (one-workgroup builds). */
-int SF_FN(get_stage_profile)(sf_handle *h, int64_t ticks[24]);
+ * label pyramid); 21..23 belong to the profiling builds; 24 is a counter, not a timer: warp tiles that were replayed
+ * because some of their targets fell outside the tile's accumulation window (one-workgroup builds). */
+int SF_FN(get_stage_profile)(sf_handle *h, int64_t ticks[32]);
 /* The IRLS streaming passes in isolation: `reps` executions of pass `which` (1 = weights + normal
  * equations, 2 = residuals + label sums) over the level-0 records of every stream left by the last
  * solve, one launch of sf_irls_pass_kernel. variant 0 = product code; 1 = loads only; 2 = no
@@ -433,7 +453,16 @@ int SF_FN(get_stage_profile)(sf_handle *h, int64_t ticks[24]);
  * Infinity Cache; an experiment, partial sums are not combined). Elapsed HIP-event milliseconds of the
  * launch. Not part of a solve. */
 int SF_FN(microbench_pass)(sf_handle *h, int which, int variant, int reps, float *elapsed_ms);
-/* Elapsed ms of the most recent solver kernel launch (HIP events around that launch). */
+/* SF_VARIANT_CLUSTER: forget a rendezvous timeout (SF_STATUS_SYNC_TIMEOUT) of every stream of the handle: granules, epochs and
+ * the sticky flag are reset after the handle's stream has drained; the solver state is left as it is. A no-op for the
+ * other builds (no rendezvous). */
+int SF_FN(clear_sync_timeout)(sf_handle *h);
+/* Test support (SF_VARIANT_CLUSTER): from the next launch on, the workgroup of rank `rank` of every stream idles stall_ms
+ * before its first stage -- a late workgroup, as a co-running kernel causes -- and every rendezvous gives up after
+ * spin_limit polls (0 = the product's bound). rank < 0 switches it off. */
+int SF_FN(debug_stall_rank)(sf_handle *h, int rank, float stall_ms, unsigned spin_limit);
+/* Elapsed ms of the most recent solver kernel launch (HIP events around that launch; a launch of sf_process_frames
+ * covers all its frames). */
 int SF_FN(last_solver_kernel_ms)(sf_handle *h, float *ms);
 
 #ifdef __cplusplus

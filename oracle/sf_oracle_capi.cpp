@@ -222,6 +222,26 @@ int sfo_advance_sequences_device(sf_handle *h, const void *pool_depth, const voi
     }
     return SF_OK;
 }
+int sfo_process_frames(sf_handle *h, int im_count0, int n_frames, float *T_out) {
+    if (!h || im_count0 < 0 || n_frames < 1) return fail(SF_ERR_ARG, "bad argument");
+    for (int k = 0; k < n_frames; k++) {
+        if (int e = sfo_process_frame(h, im_count0 + k)) return e;
+        if (T_out)
+            for (int b = 0; b < h->batch; b++) std::memcpy(T_out + (size_t(k) * h->batch + b) * 16, h->s[b]->T_odometry.m, 16 * sizeof(float));
+    }
+    return SF_OK;
+}
+int sfo_process_sequence_frames_device(sf_handle *h, const void *pool_depth, const void *pool_intensity, const int32_t *frame_index,
+                                       int pool_frames, int im_count0, int n_frames, float *T_out) {
+    if (!h || !pool_depth || !pool_intensity || !frame_index || im_count0 < 0 || n_frames < 1) return fail(SF_ERR_ARG, "bad argument");
+    for (int k = 0; k < n_frames; k++) {
+        if (int e = sfo_advance_sequences_device(h, pool_depth, pool_intensity, frame_index + size_t(k) * h->batch, pool_frames)) return e;
+        if (int e = sfo_process_frame(h, im_count0 + k)) return e;
+        if (T_out)
+            for (int b = 0; b < h->batch; b++) std::memcpy(T_out + (size_t(k) * h->batch + b) * 16, h->s[b]->T_odometry.m, 16 * sizeof(float));
+    }
+    return SF_OK;
+}
 // the CPU oracle has no second stream: the "asynchronous" upload copies at commit time from the caller's buffers
 static const float *g_up_d = nullptr, *g_up_i = nullptr;
 int sfo_upload_current_async(sf_handle *h, const float *d, const float *i) {
@@ -782,12 +802,14 @@ int sfo_get_counters(sf_handle *h, int64_t *frames, int64_t *n_irls, int64_t *n_
     if (pixel_iters) *pixel_iters = h->cum_pix;
     return SF_OK;
 }
-int sfo_get_stage_profile(sf_handle *h, int64_t ticks[24]) {
+int sfo_get_stage_profile(sf_handle *h, int64_t ticks[32]) {
     if (!h || !ticks) return fail(SF_ERR_ARG, "null");
-    for (int q = 0; q < 24; q++) ticks[q] = 0;  // the oracle keeps no stage timers
+    for (int q = 0; q < 32; q++) ticks[q] = 0;  // the oracle keeps no stage timers
     return SF_OK;
 }
 int sfo_microbench_pass(sf_handle *, int, int, int, float *) { return fail(SF_ERR_STATE, "not available in the CPU oracle"); }
+int sfo_clear_sync_timeout(sf_handle *h) { return h ? SF_OK : fail(SF_ERR_ARG, "null"); }  // one thread: nothing to time out
+int sfo_debug_stall_rank(sf_handle *, int, float, unsigned) { return fail(SF_ERR_STATE, "not available in the CPU oracle"); }
 int sfo_last_solver_kernel_ms(sf_handle *h, float *ms) {
     if (!h || !ms) return fail(SF_ERR_ARG, "null");
     *ms = h->last_ms;

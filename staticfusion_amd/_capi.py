@@ -112,6 +112,8 @@ SIGNATURES = {
     "set_current_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "set_prediction_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "advance_sequences_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, _ip, C.c_int]),
+    "process_frames": (C.c_int, [_H, C.c_int, C.c_int, _fp]),
+    "process_sequence_frames_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, _ip, C.c_int, C.c_int, C.c_int, _fp]),
     "upload_current_async": (C.c_int, [_H, _fp, _fp]),
     "commit_upload": (C.c_int, [_H]),
     "alloc_pinned": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -172,6 +174,8 @@ SIGNATURES = {
     "get_stage_profile": (C.c_int, [_H, C.POINTER(C.c_int64)]),
     "microbench_pass": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, _fp]),
     "last_solver_kernel_ms": (C.c_int, [_H, _fp]),
+    "clear_sync_timeout": (C.c_int, [_H]),
+    "debug_stall_rank": (C.c_int, [_H, C.c_int, C.c_float, C.c_uint]),
 }
 
 
@@ -359,6 +363,29 @@ class Solver:
         self.api.check(self.api.advance_sequences_device(self.h, C.c_void_p(pool_depth_ptr), C.c_void_p(pool_intensity_ptr), idx.ctypes.data_as(_ip),
                                                          int(pool_frames)))
 
+    def _traj(self, n_frames, want):
+        return np.zeros((n_frames, self.batch_size, 16), np.float32) if want else None
+
+    @staticmethod
+    def _traj_out(T):
+        # [frame][stream] 4x4 (row, column) matrices from the column-major storage
+        return None if T is None else np.ascontiguousarray(T.reshape(T.shape[0], T.shape[1], 4, 4).transpose(0, 1, 3, 2))
+
+    def process_frames(self, im_count0, n_frames, trajectory=False):
+        """n_frames x process_frame in one launch (sf_process_frames); trajectory=True returns T of every frame and stream"""
+        T = self._traj(n_frames, trajectory)
+        self.api.check(self.api.process_frames(self.h, im_count0, n_frames, T.ctypes.data_as(_fp) if trajectory else None))
+        return self._traj_out(T)
+
+    def process_sequence_frames_device(self, pool_depth_ptr, pool_intensity_ptr, frame_index, pool_frames, im_count0, trajectory=False):
+        """frame_index: [n_frames][batch] pool frames; per frame and stream the advance step, then process_frame; one launch"""
+        idx = np.ascontiguousarray(frame_index, dtype=np.int32)
+        assert idx.ndim == 2 and idx.shape[1] == self.batch_size
+        T = self._traj(idx.shape[0], trajectory)
+        self.api.check(self.api.process_sequence_frames_device(self.h, C.c_void_p(pool_depth_ptr), C.c_void_p(pool_intensity_ptr), idx.ctypes.data_as(_ip),
+                                                               int(pool_frames), im_count0, idx.shape[0], T.ctypes.data_as(_fp) if trajectory else None))
+        return self._traj_out(T)
+
     def current_to_prediction(self):
         self.api.check(self.api.current_to_prediction(self.h))
 
@@ -497,15 +524,15 @@ class Solver:
 
     def stage_profile(self):
         """dict stage -> seconds (lane-0 wall clock summed over streams since creation)"""
-        t = (C.c_int64 * 24)()
+        t = (C.c_int64 * 32)()
         self.api.check(self.api.get_stage_profile(self.h, t))
         return {n: t[i] * 1e-8 for i, n in enumerate(self.STAGES)}
 
     def splat_replays(self):
-        """warp tiles replayed for targets outside their accumulation window (slot 23 of the stage profile: a counter)"""
-        t = (C.c_int64 * 24)()
+        """warp tiles replayed for targets outside their accumulation window (slot 24 of the stage profile: a counter)"""
+        t = (C.c_int64 * 32)()
         self.api.check(self.api.get_stage_profile(self.h, t))
-        return int(t[23])
+        return int(t[24])
 
     def microbench_pass(self, which, variant, reps):
         ms = C.c_float()
@@ -516,6 +543,12 @@ class Solver:
         ms = C.c_float()
         self.api.check(self.api.timed_process_frames(self.h, im_count, calls, C.byref(ms)))
         return ms.value
+
+    def clear_sync_timeout(self):
+        self.api.check(self.api.clear_sync_timeout(self.h))
+
+    def debug_stall_rank(self, rank, stall_ms=0.0, spin_limit=0):
+        self.api.check(self.api.debug_stall_rank(self.h, rank, stall_ms, spin_limit))
 
     def last_solver_kernel_ms(self):
         ms = C.c_float()

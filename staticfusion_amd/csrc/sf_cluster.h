@@ -50,12 +50,16 @@ struct ClusterShared {
     gu64 *sync;      // [2][full_G][SF_SYNC_WORDS] granules of this stream
     unsigned epoch;  // tag of the last rendezvous (continues across launches through StreamState::sync_epoch)
     int failed;      // a spin ran into its bound: every later rendezvous returns at once, the frame reports SF_STATUS_SYNC_TIMEOUT
+    int *fail_flag;  // StreamState::sync_failed of the stream: set (agent scope) by ANY workgroup of the cluster that times out.
+                     // A late workgroup finds every granule it waits for and never times out itself, although the others
+                     // went on with stale words long ago: whoever commits results asks commit_ok(), which reads this flag
+    unsigned spin_limit;
     unsigned in[SF_SYNC_WORDS];
     unsigned all[SF_GATHER_RANKS * SF_SYNC_WORDS];
 };
 
 __device__ __forceinline__ void cluster_init(LDS ClusterShared &cs, int tid, int G, int rank, int shared_slot, int private_slot,
-                                             gu64 *sync, unsigned epoch) {
+                                             gu64 *sync, unsigned epoch, int *fail_flag = nullptr, unsigned spin_limit = SF_SYNC_SPIN_LIMIT) {
     if (tid == 0) {
         cs.G = cs.full_G = G;
         cs.rank = cs.full_rank = rank;
@@ -65,8 +69,27 @@ __device__ __forceinline__ void cluster_init(LDS ClusterShared &cs, int tid, int
         cs.sync = sync;
         cs.epoch = epoch;
         cs.failed = 0;
+        cs.fail_flag = fail_flag;
+        cs.spin_limit = spin_limit ? spin_limit : SF_SYNC_SPIN_LIMIT;
     }
     __syncthreads();
+}
+// a spin ran into its bound: this workgroup stops waiting for good, and the stream is marked for everybody (sticky: the
+// host clears it with sf_clear_sync_timeout)
+__device__ __forceinline__ void cluster_fail(LDS ClusterShared &cs) {
+    cs.failed = 1;
+    int *f = *(int *volatile LDS *)&cs.fail_flag;
+    if (f) __hip_atomic_store(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// May this workgroup store results into the stream's persistent state? Not when ANY workgroup of the cluster has timed
+// out in this launch (or an earlier one): the words it gathered since may be stale. A workgroup that times out sets the
+// flag BEFORE the late one arrives, and nobody gets past a rendezvous before the late one has arrived: the flag is up by
+// the time a writer that missed the timeout asks.
+__device__ __forceinline__ bool commit_ok(LDS ClusterShared &cs) {
+    int *f = uniform_ptr(cs.fail_flag);
+    if (!f) return true;  // one workgroup per stream: no rendezvous, nothing to time out
+    const int bad = uniform_i(cs.failed) | __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_amdgcn_readfirstlane(bad) == 0;
 }
 // solo = true: the next stages are run by this workgroup alone, on its private slot (every workgroup of the cluster does
 // the same work redundantly and arrives at bit-identical state); false: back to sharing the work
@@ -120,8 +143,8 @@ __device__ __forceinline__ void cluster_gather(LDS ClusterShared &cs, int n, int
         unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         while ((unsigned)(x >> 32) != e) {
-            if (++spins > SF_SYNC_SPIN_LIMIT || sync_failed(cs)) {
-                cs.failed = 1;
+            if (++spins > *(volatile LDS unsigned *)&cs.spin_limit || sync_failed(cs)) {
+                cluster_fail(cs);
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -158,8 +181,8 @@ __device__ __forceinline__ void cluster_barrier(LDS ClusterShared &cs, int tid) 
         gu64 *g = sync_words(uniform_ptr(cs.sync), G, e, tid);
         unsigned spins = 0;
         while ((unsigned)(__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != e) {
-            if (++spins > SF_SYNC_SPIN_LIMIT || sync_failed(cs)) {
-                cs.failed = 1;
+            if (++spins > *(volatile LDS unsigned *)&cs.spin_limit || sync_failed(cs)) {
+                cluster_fail(cs);
                 break;
             }
             __builtin_amdgcn_s_sleep(1);

@@ -30,8 +30,8 @@ enum {
     PF_PYR_OLD = 0, PF_PYR_NEW, PF_KMEANS, PF_WARP, PF_LINEARISE, PF_IRLS_INIT, PF_PASS1, PF_SOLVE6, PF_PASS2,
     PF_TAIL, PF_FILTER, PF_RESIDUALS, PF_SEGM_HIST, PF_TOTAL,
     PF_KM_INIT, PF_KM_SORT, PF_KM_ASSIGN, PF_KM_PARTITION, PF_KM_SUM, PF_KM_LABEL0, PF_KM_CONN_PYR,
-    PF_SPLAT_REPLAYS = 23,  // not a timer: warp tiles replayed for targets outside their window (tiled_splat, lazy mode)
-    SF_PROF_SLOTS = 24
+    PF_SPLAT_REPLAYS = 24,  // not a timer (a slot of its own: 21..23 are shared by the profiling builds and the isolated-pass kernel): warp tiles replayed for targets outside their window (tiled_splat, lazy mode)
+    SF_PROF_SLOTS = 32
 };
 
 // record planes written by the linearisation and streamed by the IRLS passes.  Only what cannot be
@@ -49,7 +49,22 @@ enum {
     ST_SOLVE = 8,        // coarse-to-fine loop of runSolver
     ST_RESIDUALS = 16,   // computeResidualsAgainstPreviousImage(index)
     ST_SEGM_IMAGE = 32,  // buildSegmImage
-    ST_PUSH_HISTORY = 64 // ring[im_count % 5] = current
+    ST_PUSH_HISTORY = 64, // ring[im_count % 5] = current
+    ST_AUTO_RESIDUALS = 128 // several frames per launch: ST_RESIDUALS from the frame with im_count >= SF_HISTORY on
+};
+
+// Several consecutive frames of every stream in ONE launch of the frame kernel (sf_process_frames /
+// sf_process_sequence_frames_device): the queue then hands out (frame, stream) pairs, frame-major, and a workgroup starts
+// frame k of a stream as soon as frame k - 1 of THAT stream is done -- no barrier over the batch between frames, so the
+// workgroups never line up again (a launch per frame makes all of them start with the same HBM-bound stage and ends with
+// a tail in which the streams that needed most iterations run alone).
+struct FrameLaunch {
+    int stage_mask, im_count, n_frames;
+    int *frame_done;        // [batch] frames of THIS launch completed per stream (zeroed by the host); null for one frame
+    const int *seq_index;   // [n_frames][batch] pool frame of (frame, stream), < 0: leave the stream's images alone; or null
+    const float *pool_d, *pool_i;  // [pool frame][n0]
+    float *traj;            // [n_frames][batch][16] T_odometry after every frame, or null
+    unsigned spin_limit;    // polls a workgroup waits for the previous frame of its stream
 };
 
 // fixed-point scales of the order-independent accumulations
@@ -81,6 +96,8 @@ struct StreamState {
     int32_t last_first;             // 1 if that iteration ran on Warped := Pred (the first of a solve)
     uint32_t sync_epoch;            // cluster build: tag of the last rendezvous of this stream's workgroups (sf_cluster.h)
     int32_t last_slot;              // record slot of the last executed outer iteration (cluster build: may be a private one)
+    int32_t sync_failed;            // cluster build, sticky: a rendezvous of this stream timed out (sf_cluster.h: cluster_fail). Its frames
+                                    // report SF_STATUS_SYNC_TIMEOUT and leave the state untouched until sf_clear_sync_timeout
     float inv_max_c, inv_max_d;     // 1/max of the raw pre-weights of that iteration
     long long cum_frames, cum_irls, cum_outer, cum_pixel_iters;  // totals since sf_create
     long long prof[SF_PROF_SLOTS];  // cumulative 100 MHz ticks per stage (lane 0 of the workgroup)
@@ -120,6 +137,11 @@ struct KArgs {
     // batch + b * cluster_g + r the private one of its workgroup r (coarse levels run redundantly per workgroup)
     int cluster_g;
     unsigned long long *sync;
+    // test support (sf_debug_stall_rank): the workgroup of this rank of every stream idles `debug_stall_ticks` of the
+    // 100 MHz clock before its first stage -- a late workgroup, as a co-running kernel causes -- and the rendezvous give up
+    // after `sync_spin_limit` polls (0: SF_SYNC_SPIN_LIMIT)
+    int debug_stall_rank;
+    unsigned debug_stall_ticks, sync_spin_limit;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -475,7 +497,7 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
                 __syncthreads();
             }
             if (!((uniform_i((int)win.ovf[tile >> 5]) >> (tile & 31)) & 1)) continue;
-            if (tid == 0 && replayed) *replayed += 1;  // diagnostic counter (slot 23 of sf_get_stage_profile)
+            if (tid == 0 && replayed) *replayed += 1;  // diagnostic counter (slot 24 of sf_get_stage_profile)
         }
         const int tv0 = (tile % tiles_v) * SPLAT_TV, tu0 = (tile / tiles_v) * SPLAT_TU;
         // ---- phase 1: clear the window, load + project this lane's source pixels, window origin

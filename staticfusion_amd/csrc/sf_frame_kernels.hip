@@ -97,25 +97,85 @@ __device__ __forceinline__ void run_stages(const KArgs &a, int b, int stage_mask
 }
 
 #ifndef SF_CLUSTER
-__global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__restrict__ ka, int stage_mask, int im_count) {
+// prediction := current, current := pool frame f of stream b (what sf_advance_kernel does between two launches), by the
+// workgroup that is about to solve the frame
+__device__ __forceinline__ void advance_stream(const KArgs &a, int b, const float *pool_d, const float *pool_i, int f, int tid) {
+    typedef float __attribute__((ext_vector_type(4))) f4;
+    typedef __attribute__((address_space(1))) const f4 gcf4;
+    typedef __attribute__((address_space(1))) f4 gf4;
+    const size_t so = (size_t)b * a.n_tot, po = (size_t)f * a.n0;
+    const auto cur_d = as_global(a.pyr_new[0] + so), cur_i = as_global(a.pyr_new[1] + so);
+    const auto pred_d = as_global(a.pyr_pred[0] + so), pred_i = as_global(a.pyr_pred[1] + so);
+    const auto nd = as_global(pool_d + po), ni = as_global(pool_i + po);
+    for (int q = tid * 4; q < a.n0; q += SF_NT * 4) {
+        const f4 cd = *(gcf4 *)(cur_d + q), ci = *(gcf4 *)(cur_i + q);
+        const f4 d = *(gcf4 *)(nd + q), i = *(gcf4 *)(ni + q);
+        *(gf4 *)(pred_d + q) = cd;
+        *(gf4 *)(pred_i + q) = ci;
+        *(gf4 *)(cur_d + q) = d;
+        *(gf4 *)(cur_i + q) = i;
+    }
+}
+
+__global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__restrict__ ka, const FrameLaunch fl) {
     __shared__ FrameShared sh;
     __shared__ ClusterShared cs;
     __shared__ int s_next;
     const KArgs &a = *ka;
     const int tid = threadIdx.x;
+    const int total = a.batch * fl.n_frames;
     for (;;) {
-        if (tid == 0) {
-            const int ticket = atomicAdd(a.queue, 1);
-            // longest-expected-first when the host supplied an order (sf_hip.hip: streams sorted by the IRLS iterations of their
-            // previous frame): the heavy streams of a launch do not end up alone in its tail
-            s_next = (ticket < a.batch && a.order) ? a.order[ticket] : ticket;
+        if (tid == 0) s_next = atomicAdd(a.queue, 1);
+        __syncthreads();
+        const int ticket = __builtin_amdgcn_readfirstlane(s_next);  // provably wave-uniform: scalar branches around the barriers
+        __syncthreads();
+        if (ticket >= total) break;
+        // frame-major: every frame k of every stream has a smaller ticket than any frame k + 1, so the frame a workgroup
+        // waits for below is always held by a workgroup that is running (or done) -- no deadlock
+        const int k = (fl.n_frames > 1) ? ticket / a.batch : 0;
+        const int j = ticket - k * a.batch;
+        // longest-expected-first when the host supplied an order (sf_hip.hip: streams sorted by the IRLS iterations of their
+        // previous frame): the heavy streams of a launch do not end up alone in its tail
+        const int b = a.order ? __builtin_amdgcn_readfirstlane(a.order[j]) : j;
+        int mask = fl.stage_mask;
+        if ((mask & ST_AUTO_RESIDUALS) && fl.im_count + k >= SF_HISTORY) mask |= ST_RESIDUALS;
+        if (fl.frame_done) {
+            if (k > 0) {
+                // frame k - 1 of this stream may still be running on another CU (another XCD): poll its counter, then an
+                // agent-scope acquire (this CU's L1 may hold lines of the stream from two frames ago)
+                if (tid == 0) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(fl.frame_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) {
+                        if (++spins > fl.spin_limit) {  // cannot happen (see above); never hang the device on a bug
+                            a.stats[b].status |= SF_STATUS_SYNC_TIMEOUT;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+            }
+            if (fl.seq_index) {
+                const int f = __builtin_amdgcn_readfirstlane(fl.seq_index[(size_t)k * a.batch + b]);
+                if (f >= 0) advance_stream(a, b, fl.pool_d, fl.pool_i, f, tid);
+                __syncthreads();
+            }
         }
-        __syncthreads();
-        const int b = __builtin_amdgcn_readfirstlane(s_next);  // provably wave-uniform: scalar branches around the barriers
-        __syncthreads();
-        if (b >= a.batch) break;
         cluster_init(*(LDS ClusterShared *)&cs, tid, 1, 0, b, b, nullptr, 0);  // this workgroup alone, on the stream's own slot
-        run_stages(a, b, stage_mask, im_count, *(LDS FrameShared *)&sh, *(LDS ClusterShared *)&cs, tid);
+        run_stages(a, b, mask, fl.im_count + k, *(LDS FrameShared *)&sh, *(LDS ClusterShared *)&cs, tid);
+        if (fl.frame_done) {
+            if (fl.traj && tid < 16) fl.traj[((size_t)k * a.batch + b) * 16 + tid] = a.state[b].T[tid];
+            // everything this workgroup wrote for the stream is visible to whoever takes its next frame: every wave's
+            // stores have left, then ONE agent-scope release, then the counter (MI355X_MICROARCH.md, inter-workgroup visibility)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(fl.frame_done + b, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         // NOTE: the loop body must END with a barrier. With a lane-0-only block here the compiler
         // fuses it with the lane-0-only queue pop at the loop top into an outer loop, and the other
         // lanes of wave 0 then spin on the barrier of the inner loop forever (observed hang).
@@ -127,24 +187,37 @@ __global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__
 // time, so the grid never exceeds the CUs). Workgroup j of XCD x -- blocks are dealt to the XCDs round robin, an
 // observation the mapping only uses for speed -- serves stream (j / G) * 8 + x as rank j % G: the workgroups of a stream
 // share an L2.
-__global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__restrict__ ka, int stage_mask, int im_count) {
+__global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__restrict__ ka, const FrameLaunch fl) {
     __shared__ FrameShared sh;
     __shared__ ClusterShared cs;
     const KArgs &a = *ka;
     const int tid = threadIdx.x;
+    const int stage_mask = fl.stage_mask, im_count = fl.im_count;  // one frame per launch: all workgroups of a stream are resident together
     const int G = a.cluster_g;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int b = (j / G) * 8 + xcd, rank = j % G;
     if (b >= a.batch) return;
     StreamState &st = a.state[b];
+    // sticky: after a timeout the stream's granules and epochs are in no defined state. Its frames do nothing but report
+    // the status until the host has reset them (sf_clear_sync_timeout); the solver state stays that of the last good frame
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&st.sync_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        if (tid == 0 && rank == 0) a.stats[b].status |= SF_STATUS_SYNC_TIMEOUT;
+        return;
+    }
+    if (G > 1 && a.debug_stall_rank == rank && a.debug_stall_ticks) {  // test support: this workgroup is late
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (long long)a.debug_stall_ticks) __builtin_amdgcn_s_sleep(127);
+    }
     cluster_init(*(LDS ClusterShared *)&cs, tid, G, rank, b, a.batch + b * G + rank, (gu64 *)a.sync + (size_t)b * 2 * G * SF_SYNC_WORDS,
-                 st.sync_epoch);
+                 st.sync_epoch, G > 1 ? &st.sync_failed : nullptr, a.sync_spin_limit);
     run_stages(a, b, stage_mask, im_count, *(LDS FrameShared *)&sh, *(LDS ClusterShared *)&cs, tid);
     // the epoch carries over to the next launch (every workgroup counted the same rendezvous)
     __syncthreads();
     if (tid == 0 && rank == 0) {
-        st.sync_epoch = cs.epoch;
-        if (cs.failed) a.stats[b].status |= SF_STATUS_SYNC_TIMEOUT;
+        if (commit_ok(*(LDS ClusterShared *)&cs))
+            st.sync_epoch = cs.epoch;
+        else
+            a.stats[b].status |= SF_STATUS_SYNC_TIMEOUT;
     }
 }
 #endif
@@ -194,8 +267,8 @@ extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_launch_de
     hipLaunchKernelGGL(sf_debug_rows_kernel, dim3(grid), dim3(SF_NT), 0, st, ka, b, out);
 }
 
-extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_launch_frame)(int grid, hipStream_t st, const KArgs *ka, int stage_mask, int im_count) {
-    hipLaunchKernelGGL(sf_frame_kernel, dim3(grid), dim3(SF_NT), 0, st, ka, stage_mask, im_count);
+extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_launch_frame)(int grid, hipStream_t st, const KArgs *ka, const FrameLaunch *fl) {
+    hipLaunchKernelGGL(sf_frame_kernel, dim3(grid), dim3(SF_NT), 0, st, ka, *fl);
 }
 extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_launch_irls_pass)(int grid, hipStream_t st, const KArgs *ka, int which, int variant, int reps, int slices) {
 #ifndef SF_CLUSTER

@@ -27,19 +27,19 @@ struct FrameVariant {
     int id;  // SF_VARIANT_*
     const char *name;
     void (*geometry)(int *threads, int *blocks_per_cu);
-    void (*launch_frame)(int grid, hipStream_t st, const KArgs *ka, int stage_mask, int im_count);
+    void (*launch_frame)(int grid, hipStream_t st, const KArgs *ka, const FrameLaunch *fl);
     void (*launch_irls_pass)(int grid, hipStream_t st, const KArgs *ka, int which, int variant, int reps, int slices);
     void (*launch_debug_rows)(int grid, hipStream_t st, const KArgs *ka, int b, float *out);
 };
-extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_nt256(int, hipStream_t, const KArgs *, int, int);
+extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_nt256(int, hipStream_t, const KArgs *, const FrameLaunch *);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_irls_pass_nt256(int, hipStream_t, const KArgs *, int, int, int, int);
-extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_nt256o5(int, hipStream_t, const KArgs *, int, int);
+extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_nt256o5(int, hipStream_t, const KArgs *, const FrameLaunch *);
 extern "C" __attribute__((visibility("hidden"))) void sf_variant_geometry_nt256o5(int *, int *);
-extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_nt1024(int, hipStream_t, const KArgs *, int, int);
+extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_nt1024(int, hipStream_t, const KArgs *, const FrameLaunch *);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_irls_pass_nt1024(int, hipStream_t, const KArgs *, int, int, int, int);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_debug_rows_nt256(int, hipStream_t, const KArgs *, int, float *);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_debug_rows_nt1024(int, hipStream_t, const KArgs *, int, float *);
-extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_ntcluster(int, hipStream_t, const KArgs *, int, int);
+extern "C" __attribute__((visibility("hidden"))) void sf_launch_frame_ntcluster(int, hipStream_t, const KArgs *, const FrameLaunch *);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_irls_pass_ntcluster(int, hipStream_t, const KArgs *, int, int, int, int);
 extern "C" __attribute__((visibility("hidden"))) void sf_launch_debug_rows_ntcluster(int, hipStream_t, const KArgs *, int, float *);
 extern "C" __attribute__((visibility("hidden"))) void sf_variant_geometry_ntcluster(int *, int *);
@@ -76,6 +76,14 @@ __global__ __launch_bounds__(1024) void sf_order_kernel(const sf_frame_stats *st
 }
 
 // the nearest K-means seed of every level-1 pixel (KArgs::km_seed_lab): once per handle, with the device arithmetic
+// sf_clear_sync_timeout: epochs and the sticky timeout flag of every stream (the granules are zeroed by a memset)
+__global__ __launch_bounds__(256) void sf_clear_sync_kernel(StreamState *state, int batch) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < batch) {
+        state[b].sync_epoch = 0;
+        state[b].sync_failed = 0;
+    }
+}
 __global__ __launch_bounds__(256) void sf_seed_label_kernel(uint8_t *out, int rows_km, int cols_km) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows_km * cols_km) return;
@@ -158,6 +166,13 @@ struct sf_handle {
     hipEvent_t seq_done[SEQ_SLOTS] = {};
     unsigned seq_calls = 0;
     bool seq_ready = false;  // index ring + events all created
+    // multi-frame launches (sf_process_frames / sf_process_sequence_frames_device)
+    int *d_frame_done = nullptr;     // [batch]
+    int *d_multi_index = nullptr;    // [capacity frames][batch]
+    int *h_multi_index = nullptr;    // pinned staging of the same size
+    float *d_traj = nullptr;         // [capacity frames][batch][16]
+    int multi_capacity = 0;          // frames the three buffers hold
+    int solver_timed_frames = 1;     // frames of the launch evk0 / evk1 bracket
 };
 
 static thread_local std::string g_err;
@@ -224,7 +239,9 @@ static bool use_five_per_cu(const sf_handle *h) {
     return h->k.p.segmentation_enabled != 0;
 }
 
-static int launch(sf_handle *h, int mask, int im_count) {
+// One launch of the frame kernel: `n_frames` consecutive frames of every stream (1: the per-call API). ml: the per-launch
+// pointers of a multi-frame launch (frame counters, index table, pools, trajectory), or null.
+static int launch(sf_handle *h, int mask, int im_count, int n_frames = 1, const FrameLaunch *ml = nullptr) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemsetAsync(h->k.queue, 0, sizeof(int), h->stream));
     if (h->args_dirty) {
@@ -232,12 +249,19 @@ static int launch(sf_handle *h, int mask, int im_count) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         h->args_dirty = false;
     }
-    int grid = h->cluster_grid ? h->cluster_grid : std::min(h->k.batch, h->max_blocks);
+    const long long items = (long long)h->k.batch * n_frames;
+    int grid = h->cluster_grid ? h->cluster_grid : (int)std::min<long long>(items, h->max_blocks);
     auto launch_frame = h->fv->launch_frame;
     if (use_five_per_cu(h)) {
         launch_frame = sf_launch_frame_nt256o5;
-        grid = std::min(h->k.batch, h->max_blocks_o5);
+        grid = (int)std::min<long long>(items, h->max_blocks_o5);
     }
+    FrameLaunch fl{};
+    if (ml) fl = *ml;
+    fl.stage_mask = mask;
+    fl.im_count = im_count;
+    fl.n_frames = n_frames;
+    fl.spin_limit = 1u << 27;
     const bool timed = (mask & ST_SOLVE) != 0;
     if (h->k.order && (mask & ST_SOLVE) && !std::getenv("SF_NO_STREAM_ORDER")) {
         // more streams than resident workgroups: hand the streams out longest-expected-first (their previous frame's IRLS
@@ -251,16 +275,17 @@ static int launch(sf_handle *h, int mask, int im_count) {
         hipEvent_t &ev = g_cluster_done[h->device];
         if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         else HIP_TRY(hipStreamWaitEvent(h->stream, ev, 0));
-        launch_frame(grid, h->stream, (const KArgs *)h->d_args, mask, im_count);
+        launch_frame(grid, h->stream, (const KArgs *)h->d_args, &fl);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev, h->stream));
     } else {
-        launch_frame(grid, h->stream, (const KArgs *)h->d_args, mask, im_count);
+        launch_frame(grid, h->stream, (const KArgs *)h->d_args, &fl);
         HIP_TRY(hipGetLastError());
     }
     if (timed) {
         HIP_TRY(hipEventRecord(h->evk1, h->stream));
         h->solver_timed = true;
+        h->solver_timed_frames = n_frames;
     }
     return SF_OK;
 }
@@ -334,6 +359,9 @@ void sf_destroy(sf_handle *h) {
     if (h->evk0) (void)hipEventDestroy(h->evk0);
     if (h->evk1) (void)hipEventDestroy(h->evk1);
     if (h->seq_index_host) (void)hipHostFree(h->seq_index_host);
+    if (h->d_multi_index) (void)hipFree(h->d_multi_index);
+    if (h->h_multi_index) (void)hipHostFree(h->h_multi_index);
+    if (h->d_traj) (void)hipFree(h->d_traj);
     for (auto &e : h->seq_done)
         if (e) (void)hipEventDestroy(e);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -465,6 +493,7 @@ int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, 
                                     "workgroups resident at once, at most CUs / 8 workgroups per XCD");
         }
         k.cluster_g = G;
+        k.debug_stall_rank = -1;
         h->cluster_grid = 8 * streams_per_xcd * G;
         slots = (size_t)batch * (1 + G);
     }
@@ -761,6 +790,82 @@ int sf_process_frame(sf_handle *h, int im_count) {
     int m = ST_PYR_OLD | solve_mask(h, 1) | ST_SEGM_IMAGE | ST_PUSH_HISTORY;
     if (im_count - SF_HISTORY >= 0) m |= ST_RESIDUALS;
     return launch(h, m, im_count);
+}
+
+// ---- several frames per launch ----------------------------------------------------------------
+static int multi_buffers(sf_handle *h, int n_frames, bool want_index, bool want_traj) {
+    const size_t B = (size_t)h->k.batch;
+    if (!h->d_frame_done)
+        if (int e = dev_alloc(h, &h->d_frame_done, B)) return e;
+    if (n_frames > h->multi_capacity) {  // grow: the old buffers may still be in use by a queued launch
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->d_multi_index) (void)hipFree(h->d_multi_index);
+        if (h->h_multi_index) (void)hipHostFree(h->h_multi_index);
+        if (h->d_traj) (void)hipFree(h->d_traj);
+        h->d_multi_index = nullptr; h->h_multi_index = nullptr; h->d_traj = nullptr; h->multi_capacity = 0;
+        HIP_TRY(hipMalloc((void **)&h->d_multi_index, sizeof(int) * B * n_frames));
+        HIP_TRY(hipHostMalloc((void **)&h->h_multi_index, sizeof(int) * B * n_frames, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&h->d_traj, sizeof(float) * 16 * B * n_frames));
+        h->multi_capacity = n_frames;
+    }
+    (void)want_index; (void)want_traj;
+    return SF_OK;
+}
+static int process_frames(sf_handle *h, const void *pool_depth, const void *pool_intensity, const int32_t *frame_index, int pool_frames,
+                          int im_count0, int n_frames, float *T_out) {
+    if (!h || im_count0 < 0 || n_frames < 1 || n_frames > 4096) return fail(SF_ERR_ARG, "bad argument");
+    const size_t B = (size_t)h->k.batch;
+    const bool seq = pool_depth || pool_intensity || frame_index;
+    if (seq) {
+        if (!pool_depth || !pool_intensity || !frame_index) return fail(SF_ERR_ARG, "null");
+        if (pool_frames < 1) return fail(SF_ERR_ARG, "pool_frames < 1");
+        if (h->k.n0 % 4 || h->k.n_tot % 4) return fail(SF_ERR_ARG, "level sizes must be multiples of 4 pixels");
+        if (((uintptr_t)pool_depth | (uintptr_t)pool_intensity) & 15u) return fail(SF_ERR_ARG, "the frame pools must be 16-byte aligned (16-byte loads)");
+        for (size_t q = 0; q < B * n_frames; q++)
+            if (frame_index[q] >= pool_frames) return fail(SF_ERR_ARG, "frame_index entry outside the pool");
+    }
+    if (h->cluster_grid || n_frames == 1) {
+        // the cluster build keeps all workgroups of a stream resident together, one frame per launch: the same calls one by one
+        for (int k = 0; k < n_frames; k++) {
+            if (seq)
+                if (int e = sf_advance_sequences_device(h, pool_depth, pool_intensity, frame_index + (size_t)k * B, pool_frames)) return e;
+            if (int e = sf_process_frame(h, im_count0 + k)) return e;
+            if (T_out) {
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                HIP_TRY(hipMemcpy2D(T_out + (size_t)k * B * 16, 16 * sizeof(float), h->k.state, sizeof(StreamState), 16 * sizeof(float), B, hipMemcpyDeviceToHost));
+            }
+        }
+        return SF_OK;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    if (int e = multi_buffers(h, n_frames, seq, T_out != nullptr)) return e;
+    HIP_TRY(hipMemsetAsync(h->d_frame_done, 0, sizeof(int) * B, h->stream));
+    FrameLaunch ml{};
+    ml.frame_done = h->d_frame_done;
+    if (seq) {
+        HIP_TRY(hipStreamSynchronize(h->stream));  // the staging block of the previous call has been consumed
+        std::memcpy(h->h_multi_index, frame_index, sizeof(int) * B * n_frames);
+        HIP_TRY(hipMemcpyAsync(h->d_multi_index, h->h_multi_index, sizeof(int) * B * n_frames, hipMemcpyHostToDevice, h->stream));
+        ml.seq_index = h->d_multi_index;
+        ml.pool_d = (const float *)pool_depth;
+        ml.pool_i = (const float *)pool_intensity;
+    }
+    if (T_out) ml.traj = h->d_traj;
+    const int m = ST_PYR_OLD | solve_mask(h, 1) | ST_SEGM_IMAGE | ST_PUSH_HISTORY | ST_AUTO_RESIDUALS;
+    if (int e = launch(h, m, im_count0, n_frames, &ml)) return e;
+    if (T_out) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpy(T_out, h->d_traj, sizeof(float) * 16 * B * n_frames, hipMemcpyDeviceToHost));
+    }
+    return SF_OK;
+}
+int sf_process_frames(sf_handle *h, int im_count0, int n_frames, float *T_out) {
+    return process_frames(h, nullptr, nullptr, nullptr, 0, im_count0, n_frames, T_out);
+}
+int sf_process_sequence_frames_device(sf_handle *h, const void *pool_depth, const void *pool_intensity, const int32_t *frame_index, int pool_frames,
+                                      int im_count0, int n_frames, float *T_out) {
+    if (!pool_depth || !pool_intensity || !frame_index) return fail(SF_ERR_ARG, "null");
+    return process_frames(h, pool_depth, pool_intensity, frame_index, pool_frames, im_count0, n_frames, T_out);
 }
 
 // ---- getters (synchronise the handle's stream, then copy) ----------------------------------
@@ -1600,8 +1705,12 @@ int sf_timed_process_frames(sf_handle *h, int im_count, int calls, float *elapse
     if (!h || calls < 1) return fail(SF_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    for (int c = 0; c < calls; c++)
-        if (int e = sf_process_frame(h, im_count + c)) return e;
+    if (std::getenv("SF_TIMED_LAUNCH_PER_FRAME")) {  // A/B: one launch per frame, as before multi-frame launches existed
+        for (int c = 0; c < calls; c++)
+            if (int e = sf_process_frame(h, im_count + c)) return e;
+    } else if (int e = sf_process_frames(h, im_count, calls, nullptr)) {
+        return e;
+    }
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev1));
     float ms = 0.f;
@@ -1626,11 +1735,11 @@ int sf_get_counters(sf_handle *h, int64_t *frames, int64_t *n_irls, int64_t *n_o
     if (pixel_iters) *pixel_iters = p;
     return SF_OK;
 }
-int sf_get_stage_profile(sf_handle *h, int64_t ticks[24]) {
+int sf_get_stage_profile(sf_handle *h, int64_t ticks[32]) {
     if (!h || !ticks) return fail(SF_ERR_ARG, "null");
     std::vector<StreamState> st(h->k.batch);
     if (int e = d2h(h, st.data(), h->k.state, st.size() * sizeof(StreamState))) return e;
-    for (int q = 0; q < 24; q++) ticks[q] = 0;
+    for (int q = 0; q < SF_PROF_SLOTS; q++) ticks[q] = 0;
     for (auto &s : st)
         for (int q = 0; q < SF_PROF_SLOTS; q++) ticks[q] += s.prof[q];
     return SF_OK;
@@ -1639,6 +1748,7 @@ int sf_microbench_pass(sf_handle *h, int which, int variant, int reps, float *el
     const int slices = (variant >> 8) ? (variant >> 8) : 1;  // bits 8.. of `variant`: workgroups per stream (experiment)
     variant &= 255;
     if (!h || (which != 1 && which != 2) || variant < 0 || variant > 2 || reps < 1 || slices > 64) return fail(SF_ERR_ARG, "bad argument");
+    if (h->fv->id == SF_VARIANT_CLUSTER) return fail(SF_ERR_STATE, "the isolated passes are not built for the cluster variant");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemsetAsync(h->k.queue, 0, sizeof(int), h->stream));
     const int grid = std::min(h->k.batch * slices, h->max_blocks);
@@ -1650,6 +1760,27 @@ int sf_microbench_pass(sf_handle *h, int which, int variant, int reps, float *el
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     if (elapsed_ms) *elapsed_ms = ms;
+    return SF_OK;
+}
+int sf_clear_sync_timeout(sf_handle *h) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    if (!h->k.cluster_g) return SF_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));  // no launch of this handle is polling the granules any more
+    HIP_TRY(hipMemsetAsync(h->k.sync, 0, sizeof(unsigned long long) * (size_t)h->k.batch * 2 * h->k.cluster_g * SF_SYNC_WORDS, h->stream));
+    hipLaunchKernelGGL(sf_clear_sync_kernel, dim3((h->k.batch + 255) / 256), dim3(256), 0, h->stream, h->k.state, h->k.batch);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SF_OK;
+}
+int sf_debug_stall_rank(sf_handle *h, int rank, float stall_ms, unsigned spin_limit) {
+    if (!h) return fail(SF_ERR_ARG, "null");
+    if (!h->k.cluster_g) return fail(SF_ERR_STATE, "only the cluster build has rendezvous");
+    if (rank >= h->k.cluster_g || stall_ms < 0.f || stall_ms > 10000.f) return fail(SF_ERR_ARG, "rank / stall out of range");
+    h->k.debug_stall_rank = rank;
+    h->k.debug_stall_ticks = rank < 0 ? 0u : (unsigned)(stall_ms * 1.0e5f);  // 100 MHz wall clock
+    h->k.sync_spin_limit = spin_limit;
+    h->args_dirty = true;
     return SF_OK;
 }
 int sf_last_solver_kernel_ms(sf_handle *h, float *ms) {

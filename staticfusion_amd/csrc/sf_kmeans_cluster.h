@@ -502,7 +502,7 @@ __device__ __noinline__ void stage_kmeans_cluster(const KArgs &a, int b, LDS KmC
         __syncthreads();
         if (stop) break;
     }
-    if (writer) {
+    if (writer && commit_ok(cs)) {
         if (tid < 3 * SF_NC) st.kmeans[tid] = s.cent_a[tid];
         if (tid == 0) a.stats[b].kmeans_iters = iters;
     }
@@ -597,7 +597,7 @@ __device__ __noinline__ void stage_kmeans_cluster(const KArgs &a, int b, LDS KmC
             unsigned m = 0;
             for (int p = 0; p < G; p++) m |= cs.all[p * SF_NC + tid];
             s.conn[tid] = m;
-            if (writer) st.conn[tid] = m;
+            if (writer && commit_ok(cs)) st.conn[tid] = m;
         }
         __syncthreads();
     }

@@ -158,7 +158,7 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
         cs.in[2 * SF_NC + tid] = (unsigned)s.lab_cnt[tid];
     }
     cluster_gather(cs, 3 * SF_NC, tid);
-    if (tid < SF_NC && cl_writer(cs)) {
+    if (tid < SF_NC && cl_writer(cs) && commit_ok(cs)) {
         long long t = 0;
         int c = 0;
         for (int p = 0; p < G; p++) {
@@ -225,5 +225,5 @@ __device__ __noinline__ void stage_push_history(const KArgs &a, int b, int im_co
             *(gf4 *)((gc *)ibuf + o1) = c1;
         }
     }
-    if (tid < 16 && cl_writer(cs)) st.hist_T[slot][tid] = st.T[tid];
+    if (tid < 16 && cl_writer(cs) && commit_ok(cs)) st.hist_T[slot][tid] = st.T[tid];
 }

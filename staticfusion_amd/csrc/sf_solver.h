@@ -1398,13 +1398,16 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, LDS SolveShared 
             }
     }
     __syncthreads();
-    if (cl_writer(cs)) {  // ONE workgroup of a cluster stores the stream's results (all of them hold the same values)
+    const bool commit = commit_ok(cs);  // false: a rendezvous of this frame timed out somewhere in the cluster -- the values
+                                        // in LDS may come from stale words; the stream keeps the state of its last good frame
+    if (cl_writer(cs) && !commit && tid == 0) a.stats[b].status = s.status | SF_STATUS_SYNC_TIMEOUT;
+    if (cl_writer(cs) && commit) {  // ONE workgroup of a cluster stores the stream's results (all of them hold the same values)
         if (tid == 0) {
             sf_frame_stats &fs = a.stats[b];
             fs.n_outer = s.n_outer;
             fs.n_irls = s.n_irls;
             fs.pixel_iters = s.pixel_iters;
-            fs.status = s.status | (sync_failed(cs) ? SF_STATUS_SYNC_TIMEOUT : 0);
+            fs.status = s.status;
             st.last_level = last_L;
             st.last_first = s.first;
             st.last_slot = last_slot;

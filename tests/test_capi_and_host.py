@@ -143,3 +143,26 @@ def test_bench_algorithmic_bytes():
     assert out["linearise"] == 88 * (100 + 400) and out["warp"] == 32 * 400
     assert out["pyramid"] == 2 * 48 * 100 and out["kmeans"] == 20 * 100 * 3
     assert out["segm_image"] == 8 * 400 and out["residuals"] == 32 * 400
+
+
+def test_frames_in_one_call_on_the_oracle(ora):
+    """sf_process_frames through the binding: the trajectory block is [frame][stream] 4 x 4 (row, column) and the call
+    equals the frames one by one (on the CPU oracle the entry point IS that loop; the GPU test compares launches)."""
+    import numpy as np
+    from conftest import driver_params, make_solver
+    from staticfusion_amd.synth import make_pair
+
+    pr = [make_pair(seed=5 + q, sphere=True, out_rows=30, out_cols=40) for q in range(2)]
+    solvers = [make_solver(ora, 30, 40, driver_params(ora), batch=2) for _ in range(2)]
+    for s in solvers:
+        for b in range(2):
+            s.set_current(b, *pr[b]["new"])
+            s.set_prediction(b, *pr[b]["old"])
+    one, many = solvers
+    T = many.process_frames(0, 3, trajectory=True)
+    assert T.shape == (3, 2, 4, 4)
+    for k in range(3):
+        one.process_frame(k)
+        for b in range(2):
+            assert np.array_equal(T[k, b], one.T(b))
+    assert np.array_equal(many.b(1), one.b(1))

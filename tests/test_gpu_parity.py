@@ -184,7 +184,7 @@ def test_warp_with_targets_outside_the_tile_windows(hip, ora, pair):
     """A patch of picket fence (3-pixel bands at a third of the depth) in the predicted depth image, under a sideways
     motion: neighbouring source pixels of the patch move by very different amounts, so the targets of its tiles do not fit
     their accumulation windows. The one-workgroup builds then take the replay path of the splat (the accumulator columns
-    are zeroed lazily there, sf_device_common.h) -- the counter in slot 23 of the stage profile says that they really did
+    are zeroed lazily there, sf_device_common.h) -- the counter in slot 24 of the stage profile says that they really did
     -- and the warped images still equal the oracle's. (The rest of the image keeps the estimate well conditioned.)"""
     pr = pair(seed=21, rows=240, cols=320, xi=(0.05, 0.0, 0.0, 0.0, 0.0, 0.0))
     d_old = pr["old"][0].copy()

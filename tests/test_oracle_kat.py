@@ -213,3 +213,36 @@ def test_frame_sequence_history_and_residuals(ora, pair):
         else:
             assert np.isfinite(cr).sum() >= 12 and np.nanmax(cr) < 0.2
     assert (s.b_image() > 0.5).mean() > 0.9
+
+
+def test_behind_camera_rule_switch_changes_only_such_inputs(ora):
+    """sfo_test_set_hip_behind_camera_rule (the HIP build's treatment of points warped behind the camera):
+    identical results on an ordinary pair (no such point), fewer valid pixels on a pair built to have them."""
+    import ctypes
+
+    from conftest import driver_params, make_solver
+    from staticfusion_amd.synth import make_pair
+
+    lib = ora.lib
+    lib.sfo_test_set_hip_behind_camera_rule.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.sfo_test_behind_camera_valid.restype = ctypes.c_longlong
+    lib.sfo_test_behind_camera_valid.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    ordinary = make_pair(seed=11, sphere=True, out_rows=60, out_cols=80)
+    near = make_pair(seed=5, sphere=False, out_rows=60, out_cols=80, xi=(0.0, 0.0, 0.12, 0.0, 0.0, 0.0))
+    d_old = near["old"][0].copy()
+    d_old[20:40, 30:50] = 0.06
+    near = {"old": (d_old, near["old"][1]), "new": near["new"]}
+    for pr, expect_behind in ((ordinary, False), (near, True)):
+        res = []
+        for rule in (0, 1):
+            s = make_solver(ora, 60, 80, driver_params(ora), pr)
+            assert lib.sfo_test_set_hip_behind_camera_rule(s.h, rule) == 0
+            s.build_pyramid(True)
+            s.run_solver(True)
+            res.append((s.T().copy(), [s.stats().outer[i].n_valid for i in range(s.stats().n_outer)], lib.sfo_test_behind_camera_valid(s.h, 0)))
+        (T0, nv0, behind0), (T1, nv1, _) = res
+        assert (behind0 > 0) == expect_behind
+        if expect_behind:
+            assert nv0 != nv1 and sum(nv1[:len(nv0)]) < sum(nv0[:len(nv1)]) + 1
+        else:
+            assert nv0 == nv1 and np.array_equal(T0, T1)

@@ -16,6 +16,8 @@ import ctypes
 ora = binding.load(); hip = sf.load().with_variant(variant)
 EXACT_WARP = os.environ.get("SF_ORACLE_EXACT_WARP") == "1"  # the oracle's warp sums in fp64 (sfo_test_set_exact_warp)
 ora.lib.sfo_test_set_exact_warp.argtypes = [ctypes.c_void_p, ctypes.c_int]
+EXACT_SUMS = os.environ.get("SF_ORACLE_EXACT_SUMS") == "1"  # ... and its per-cluster float sums (sfo_test_set_exact_sums)
+ora.lib.sfo_test_set_exact_sums.argtypes = [ctypes.c_void_p, ctypes.c_int]
 w = dict(b=0.0, b_last=0.0, ata=0.0, atb=0.0, var=0.0, rot=0.0, trans=0.0, aver=0.0)
 for seed in range(1234, 1234 + n_seeds):
     pr = make_pair(seed=seed, sphere=True, out_rows=240, out_cols=320)
@@ -23,6 +25,7 @@ for seed in range(1234, 1234 + n_seeds):
     for api in (hip, ora):
         s = make_solver(api, 240, 320, driver_params(api), pr)
         if api is ora and EXACT_WARP: ora.lib.sfo_test_set_exact_warp(s.h, 1)
+        if api is ora and EXACT_SUMS: ora.lib.sfo_test_set_exact_sums(s.h, 1)
         s.build_pyramid(True); s.run_solver(True); S.append((s.stats(), s.T().copy())); s.close()
     (a, Ta), (o, To) = S
     assert a.n_outer == o.n_outer and a.n_irls == o.n_irls, (seed, a.n_outer, o.n_outer, a.n_irls, o.n_irls)
@@ -39,4 +42,4 @@ for seed in range(1234, 1234 + n_seeds):
         w["aver"] = max(w["aver"], abs(x.aver_res / y.aver_res - 1))
     r, t = pose_delta(To, Ta); w["rot"] = max(w["rot"], r); w["trans"] = max(w["trans"], t)
 print("%s [%s] vs oracle%s, %d seeds: |b-b_o| max %.2e (last outer %.2e) | AtA rel %.2e AtB rel %.2e | var %.2e | aver_res rel %.2e | pose %.2e rad %.2e m" % (
-    os.path.basename(sf.LIB), variant, " (fp64 warp sums)" if EXACT_WARP else "", n_seeds, w["b"], w["b_last"], w["ata"], w["atb"], w["var"], w["aver"], w["rot"], w["trans"]))
+    os.path.basename(sf.LIB), variant, (" (fp64 warp sums)" if EXACT_WARP else "") + (" (fp64 cluster sums)" if EXACT_SUMS else ""), n_seeds, w["b"], w["b_last"], w["ata"], w["atb"], w["var"], w["aver"], w["rot"], w["trans"]))

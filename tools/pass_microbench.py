@@ -30,7 +30,7 @@ for which in (1, 2):
         print("pass %d %-16s %8.3f ms  %6.2f Gpx/s  streamed(%d B/px) %7.1f GB/s  algorithmic(30 B/px/pass) %7.1f GB/s" % (
             which, name, ms, px / ms / 1e6, bpp, bpp * px / ms / 1e6, 30.0 * px / ms / 1e6))
 import ctypes as C
-t = (C.c_int64 * 24)()
+t = (C.c_int64 * 32)()
 api.check(api.get_stage_profile(s.h, t))
 if t[23] > 0:
     print("shader clock during the last pass launch: %.0f MHz (s_memtime ticks %d / 100 MHz ticks %d)" % (100.0 * t[22] / t[23], t[22], t[23]))

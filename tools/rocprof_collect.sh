@@ -6,6 +6,7 @@ set -u
 TAG=$1; WL=$2; B=$3
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+export SF_TIMED_LAUNCH_PER_FRAME=1  # bytes per FRAME of every stream: one launch per frame under the counters
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 CMD="python tools/prof_run.py --workload $WL --batch $B --steps 3"

@@ -41,17 +41,17 @@ for k in s.STAGES:
 
 if a.lib and "filterprof" in a.lib:
     import ctypes
-    t0 = (ctypes.c_int64 * 24)()
+    t0 = (ctypes.c_int64 * 32)()
     api.check(api.get_stage_profile(s.h, t0))
     print("  filter: 6x6 inverse %.1f us, Jacobi %.1f us, rest (log / exp / products on one lane) %.1f us per frame" % tuple(1e-2 * t0[q] / (frames + 5 * a.batch) for q in (21, 22, 23)))
 if a.lib and "kmcfine" in a.lib:
     import ctypes
-    t0 = (ctypes.c_int64 * 24)()
+    t0 = (ctypes.c_int64 * 32)()
     api.check(api.get_stage_profile(s.h, t0))
     names = ["loads+counts", "barrier 1", "offsets", "scatter", "barrier 2", "sums", "publish"]
     print("  cluster k-means collect+sum, shader cycles per frame (divide by ~2300 for us): " + ", ".join("%s %.0fk" % (n, 1e-3 * t0[16 + i] / (frames + 5 * a.batch)) for i, n in enumerate(names)))
 if a.lib and "kmprof" in a.lib:
     import ctypes
-    t = (ctypes.c_int64 * 24)()
+    t = (ctypes.c_int64 * 32)()
     api.check(api.get_stage_profile(s.h, t))
     print("  Lloyd search trips (wave 0): %d over %d chunks = %.2f per chunk; k-means iterations of stream 0: %d" % (t[21], t[22], t[21] / max(1, t[22]), s.stats(0).kmeans_iters))

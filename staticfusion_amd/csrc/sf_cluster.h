@@ -102,8 +102,13 @@ __device__ __forceinline__ void cluster_set_solo(LDS ClusterShared &cs, int tid,
     }
     __syncthreads();
 }
+#ifdef SF_CLUSTER
 __device__ __forceinline__ int cl_G(const LDS ClusterShared &cs) { return uniform_i(cs.G); }
 __device__ __forceinline__ int cl_rank(const LDS ClusterShared &cs) { return uniform_i(cs.rank); }
+#else  // one workgroup per stream: compile-time constants (the rendezvous code and the strided loops fold away)
+__device__ __forceinline__ constexpr int cl_G(const LDS ClusterShared &) { return 1; }
+__device__ __forceinline__ constexpr int cl_rank(const LDS ClusterShared &) { return 0; }
+#endif
 __device__ __forceinline__ int cl_slot(const LDS ClusterShared &cs) { return uniform_i(cs.slot); }
 __device__ __forceinline__ bool cl_writer(const LDS ClusterShared &cs) { return uniform_i(cs.writer) != 0; }
 

@@ -65,6 +65,7 @@ struct FrameLaunch {
     const float *pool_d, *pool_i;  // [pool frame][n0]
     float *traj;            // [n_frames][batch][16] T_odometry after every frame, or null
     unsigned spin_limit;    // polls a workgroup waits for the previous frame of its stream
+    int flip_ok;            // sequences: swap the roles of the two pyramid buffers instead of copying prediction := current
 };
 
 // fixed-point scales of the order-independent accumulations
@@ -96,6 +97,8 @@ struct StreamState {
     int32_t last_first;             // 1 if that iteration ran on Warped := Pred (the first of a solve)
     uint32_t sync_epoch;            // cluster build: tag of the last rendezvous of this stream's workgroups (sf_cluster.h)
     int32_t last_slot;              // record slot of the last executed outer iteration (cluster build: may be a private one)
+    int32_t flip;                   // 1: the stream's two pyramid buffers have swapped roles (pyr_plane): only INSIDE a launch of
+                                    // several frames of a sequence (sf_frame_kernels.hip), 0 whenever the host looks
     int32_t sync_failed;            // cluster build, sticky: a rendezvous of this stream timed out (sf_cluster.h: cluster_fail). Its frames
                                     // report SF_STATUS_SYNC_TIMEOUT and leave the state untouched until sf_clear_sync_timeout
     float inv_max_c, inv_max_d;     // 1/max of the raw pre-weights of that iteration
@@ -143,6 +146,17 @@ struct KArgs {
     int debug_stall_rank;
     unsigned debug_stall_ticks, sync_spin_limit;
 };
+
+// The two pyramid buffers of a stream: set 0 = new (depthCurrent and its levels), set 1 = Pred. When consecutive frames
+// of a SEQUENCE are solved inside one launch, the prediction of frame k + 1 is the current image of frame k and its pyramid
+// is the pyramid frame k built: the buffers swap roles (StreamState::flip) instead of 0.6 MB being copied and a pyramid
+// rebuilt bit for bit. Every stage takes its base pointers here.
+__device__ __forceinline__ float *pyr_plane(const KArgs &a, int b, int set, int ch) {
+    // an atomic (vector-memory) load: never the scalar data cache, which this workgroup's own store would not update
+    const int f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.state[b].flip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    float *const *tab = ((set ^ f) & 1) ? a.pyr_pred : a.pyr_new;
+    return tab[ch] + (size_t)b * a.n_tot;
+}
 
 // ---------------------------------------------------------------------------------------------
 //  wave / workgroup reductions (deterministic: fixed shuffle tree, fixed wave order)
@@ -407,11 +421,27 @@ __device__ __forceinline__ long long mul_packed_w(int jf, int w) {
 // depth / intensity of a target pixel from its fixed-point accumulators: sum(w * value) / sum(w).
 // The integer sums are exact; one int64 -> float conversion and one IEEE float division round twice
 // (<= 1 ulp from the exact quotient, the same order as the reference's own float accumulation).
+// The two quotients share the divisor (an integer in [1, 2^20], exact in float): one hardware reciprocal (1 ulp), refined
+// by a Newton step, and a residual correction per quotient -- the correctly rounded quotient in all but a vanishing share
+// of the cases, within 1 ulp always, at a third of the instructions of two IEEE division sequences.
+#ifndef SF_FAST_NORMALISE
+#define SF_FAST_NORMALISE 1
+#endif
 __device__ __forceinline__ void normalise_acc(long long sd, long long packed, float &dw, float &iw) {
     const long long si = (long long)((unsigned long long)packed << (64 - ACC_W_SHIFT)) >> (64 - ACC_W_SHIFT);
     const float wf = (float)(unsigned)((packed - si) >> ACC_W_SHIFT);
-    dw = ((float)sd * (1.f / 67108864.f)) / wf;
-    iw = ((float)si * (1.f / FIX_INTENS)) / wf;
+    const float nd = (float)sd * (1.f / 67108864.f), ni = (float)si * (1.f / FIX_INTENS);
+#if SF_FAST_NORMALISE
+    float r = __builtin_amdgcn_rcpf(wf);
+    r = fmaf(fmaf(-wf, r, 1.f), r, r);
+    float q = nd * r;
+    dw = fmaf(fmaf(-wf, q, nd), r, q);
+    q = ni * r;
+    iw = fmaf(fmaf(-wf, q, ni), r, q);
+#else
+    dw = nd / wf;
+    iw = ni / wf;
+#endif
 }
 
 // initializeKMeans (reference KMeans.cpp:63-101): the seed a level-1 pixel starts with is the nearest of 24 seed positions

@@ -98,22 +98,39 @@ __device__ __forceinline__ void run_stages(const KArgs &a, int b, int stage_mask
 
 #ifndef SF_CLUSTER
 // prediction := current, current := pool frame f of stream b (what sf_advance_kernel does between two launches), by the
-// workgroup that is about to solve the frame
-__device__ __forceinline__ void advance_stream(const KArgs &a, int b, const float *pool_d, const float *pool_i, int f, int tid) {
+// workgroup that is about to solve the frame. copy_pred = false: the pyramid buffers have just swapped roles (the old
+// current pyramid IS the prediction pyramid now), only the new frame is copied in.
+__device__ __forceinline__ void advance_stream(const KArgs &a, int b, const float *pool_d, const float *pool_i, int f, bool copy_pred, int tid) {
     typedef float __attribute__((ext_vector_type(4))) f4;
     typedef __attribute__((address_space(1))) const f4 gcf4;
     typedef __attribute__((address_space(1))) f4 gf4;
-    const size_t so = (size_t)b * a.n_tot, po = (size_t)f * a.n0;
-    const auto cur_d = as_global(a.pyr_new[0] + so), cur_i = as_global(a.pyr_new[1] + so);
-    const auto pred_d = as_global(a.pyr_pred[0] + so), pred_i = as_global(a.pyr_pred[1] + so);
+    const size_t po = (size_t)f * a.n0;
+    const auto cur_d = as_global(pyr_plane(a, b, 0, 0)), cur_i = as_global(pyr_plane(a, b, 0, 1));
+    const auto pred_d = as_global(pyr_plane(a, b, 1, 0)), pred_i = as_global(pyr_plane(a, b, 1, 1));
     const auto nd = as_global(pool_d + po), ni = as_global(pool_i + po);
     for (int q = tid * 4; q < a.n0; q += SF_NT * 4) {
-        const f4 cd = *(gcf4 *)(cur_d + q), ci = *(gcf4 *)(cur_i + q);
         const f4 d = *(gcf4 *)(nd + q), i = *(gcf4 *)(ni + q);
-        *(gf4 *)(pred_d + q) = cd;
-        *(gf4 *)(pred_i + q) = ci;
+        if (copy_pred) {
+            const f4 cd = *(gcf4 *)(cur_d + q), ci = *(gcf4 *)(cur_i + q);
+            *(gf4 *)(pred_d + q) = cd;
+            *(gf4 *)(pred_i + q) = ci;
+        }
         *(gf4 *)(cur_d + q) = d;
         *(gf4 *)(cur_i + q) = i;
+    }
+}
+// both pyramids of stream b, every level: exchange the contents of the two buffers (a stream left with flip = 1 at the
+// end of a launch -- a frame_index < 0 broke the alternation -- goes back to the layout the host expects)
+__device__ __forceinline__ void unflip_stream(const KArgs &a, int b, int tid) {
+    typedef float __attribute__((ext_vector_type(4))) f4;
+    typedef __attribute__((address_space(1))) f4 gf4;
+    for (int ch = 0; ch < 2; ch++) {
+        const auto x = as_global(a.pyr_new[ch] + (size_t)b * a.n_tot), y = as_global(a.pyr_pred[ch] + (size_t)b * a.n_tot);
+        for (int q = tid * 4; q < a.n_tot; q += SF_NT * 4) {
+            const f4 vx = *(gf4 *)(x + q), vy = *(gf4 *)(y + q);
+            *(gf4 *)(x + q) = vy;
+            *(gf4 *)(y + q) = vx;
+        }
     }
 }
 
@@ -158,7 +175,21 @@ __global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__
             }
             if (fl.seq_index) {
                 const int f = __builtin_amdgcn_readfirstlane(fl.seq_index[(size_t)k * a.batch + b]);
-                if (f >= 0) advance_stream(a, b, fl.pool_d, fl.pool_i, f, tid);
+                if (f >= 0) {
+                    // The prediction of this frame is the current image of the previous one, whose pyramid the previous frame
+                    // of this launch has built: from the second frame on the two pyramid buffers swap roles instead (no copy,
+                    // no createImagePyramid(true): the same bits). The swaps alternate 0 -> 1 -> 0; the last frame only swaps
+                    // BACK, so that the launch ends in the layout the host expects.
+                    const int flip = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.state[b].flip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    const bool swap = fl.flip_ok && k > 0 && (flip == 1 || k < fl.n_frames - 1);
+                    if (swap) {
+                        __syncthreads();
+                        if (tid == 0) a.state[b].flip = flip ^ 1;
+                        __syncthreads();
+                        mask &= ~ST_PYR_OLD;
+                    }
+                    advance_stream(a, b, fl.pool_d, fl.pool_i, f, !swap, tid);
+                }
                 __syncthreads();
             }
         }
@@ -166,6 +197,12 @@ __global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__
         run_stages(a, b, mask, fl.im_count + k, *(LDS FrameShared *)&sh, *(LDS ClusterShared *)&cs, tid);
         if (fl.frame_done) {
             if (fl.traj && tid < 16) fl.traj[((size_t)k * a.batch + b) * 16 + tid] = a.state[b].T[tid];
+            if (k == fl.n_frames - 1 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.state[b].flip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
+                __syncthreads();
+                unflip_stream(a, b, tid);
+                __syncthreads();
+                if (tid == 0) a.state[b].flip = 0;
+            }
             // everything this workgroup wrote for the stream is visible to whoever takes its next frame: every wave's
             // stores have left, then ONE agent-scope release, then the counter (MI355X_MICROARCH.md, inter-workgroup visibility)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -141,7 +141,7 @@ __device__ __forceinline__ void km_search_n(const LDS KmShared &s, const int (&l
 __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const size_t sb = (size_t)b * a.n_tot;
-    const auto depth = as_global((const float *)a.pyr_new[0] + sb);
+    const auto depth = as_global((const float *)pyr_plane(a, b, 0, 0));
     const LevelCoord lc0 = level_coord(a, 0), lc1 = level_coord(a, 1);
     const auto labels = as_global(a.labels + sb);
     StreamState &st = a.state[b];

@@ -305,7 +305,7 @@ __device__ __noinline__ void stage_kmeans_cluster(const KArgs &a, int b, LDS KmC
     const bool writer = cl_writer(cs);
     const int nown = (SF_NC - rank + G - 1) / G;  // clusters (seeds) rank, rank + G, ... : local index q <-> cluster rank + q G
     const size_t sb = (size_t)b * a.n_tot;
-    const auto depth = as_global((const float *)a.pyr_new[0] + sb);
+    const auto depth = as_global((const float *)pyr_plane(a, b, 0, 0));
     const LevelCoord lc0 = level_coord(a, 0), lc1 = level_coord(a, 1);
     const auto labels = as_global(a.labels + sb);
     StreamState &st = a.state[b];

@@ -27,9 +27,8 @@ __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, int which, int
         if (L > 0) cluster_barrier(cs, tid);  // level L-1 complete (written by this workgroup / by the cluster's workgroups)
         for (int si = 0; si < 2; si++) {
             if (L == 0 || !((which >> si) & 1)) continue;
-            float *const *set = (si == 0) ? a.pyr_pred : a.pyr_new;
-            const auto depth = as_global(set[0] + (size_t)b * a.n_tot);
-            const auto inten = as_global(set[1] + (size_t)b * a.n_tot);
+            const auto depth = as_global(pyr_plane(a, b, si == 0 ? 1 : 0, 0));
+            const auto inten = as_global(pyr_plane(a, b, si == 0 ? 1 : 0, 1));
             const auto d_here = depth + a.loff[L], i_here = inten + a.loff[L];
             {
             const auto d_prev = depth + a.loff[L - 1], i_prev = inten + a.loff[L - 1];

@@ -226,8 +226,8 @@ __device__ __forceinline__ void split_index(const LevelGeom &g, int idx, float &
 __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveShared &s, LDS ClusterShared &cs, int tid) {
     const int rows_i = a.lrows[L], cols_i = a.lcols[L], n = a.ln[L], o = a.loff[L];
     const int G = cl_G(cs), rank = cl_rank(cs);
-    const size_t sb = (size_t)b * a.n_tot, rb = (size_t)cl_slot(cs) * a.n0;
-    const auto dpred = as_global((const float *)a.pyr_pred[0] + sb + o), ipred = as_global((const float *)a.pyr_pred[1] + sb + o);
+    const size_t rb = (size_t)cl_slot(cs) * a.n0;
+    const auto dpred = as_global((const float *)pyr_plane(a, b, 1, 0) + o), ipred = as_global((const float *)pyr_plane(a, b, 1, 1) + o);
     const auto acc_d = as_global(a.acc_d + rb);
     const auto acc_i = as_global(a.acc_i + rb);
 
@@ -288,8 +288,8 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
     const int rows_i = a.lrows[L], cols_i = a.lcols[L], o = a.loff[L];
     const int G = cl_G(cs), rank = cl_rank(cs);  // a cluster's workgroups take every G-th tile
     const size_t sb = (size_t)b * a.n_tot, rb = (size_t)cl_slot(cs) * a.n0;
-    const auto dnew = as_global((const float *)a.pyr_new[0] + sb + o), inew = as_global((const float *)a.pyr_new[1] + sb + o);
-    const auto dpred = as_global((const float *)a.pyr_pred[0] + sb + o), ipred = as_global((const float *)a.pyr_pred[1] + sb + o);
+    const auto dnew = as_global((const float *)pyr_plane(a, b, 0, 0) + o), inew = as_global((const float *)pyr_plane(a, b, 0, 1) + o);
+    const auto dpred = as_global((const float *)pyr_plane(a, b, 1, 0) + o), ipred = as_global((const float *)pyr_plane(a, b, 1, 1) + o);
     const auto acc_d = as_global((const long long *)a.acc_d + rb), acc_i = as_global((const long long *)a.acc_i + rb);
     const auto labels = as_global((const uint8_t *)a.labels + sb + o);
     gptr<float> rec[R_COUNT];
@@ -548,7 +548,7 @@ __device__ __noinline__ void solve_seg_prior(const KArgs &a, int b, int L, LDS S
     const int n = a.ln[L];
     const float kz = a.p.kz;
     const size_t sb = (size_t)b * a.n_tot + a.loff[L], rb = (size_t)cl_slot(cs) * a.n0;
-    const auto dnew = uniform_ptr((gcfloat *)(a.pyr_new[0] + sb));
+    const auto dnew = uniform_ptr((gcfloat *)(pyr_plane(a, b, 0, 0) + a.loff[L]));
     const auto dwp = uniform_ptr((gcfloat *)(a.rec[R_DW] + rb));
     const auto labp = uniform_ptr((gcu8 *)(a.labels + sb));
     if (tid < SF_NC) {
@@ -818,7 +818,7 @@ __device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, c
     const size_t rb = (size_t)uniform_i(s.rec_slot) * a.n0;
 #pragma unroll
     for (int q = 0; q < R_COUNT; q++) c.rp.p[q] = uniform_ptr((gcfloat *)(a.rec[q] + rb));
-    c.rp.dnew = uniform_ptr((gcfloat *)(a.pyr_new[0] + (size_t)b * a.n_tot + a.loff[L]));
+    c.rp.dnew = uniform_ptr((gcfloat *)(pyr_plane(a, b, 0, 0) + a.loff[L]));
     c.rp.lab = uniform_ptr((gcu8 *)(a.rec_lab + rb));
     c.rp.with_labels = uniform_i(a.p.segmentation_enabled);
     c.n = uniform_i(s.px_end);
@@ -1464,7 +1464,7 @@ __device__ __forceinline__ void debug_rows(const KArgs &a, int b, float *out, in
     g.inv_max_c = st.inv_max_c;
     g.inv_max_d = st.inv_max_d;
     g.first = st.last_first;
-    const float *dnew = a.pyr_new[0] + (size_t)b * a.n_tot + a.loff[L];
+    const float *dnew = pyr_plane(a, b, 0, 0) + a.loff[L];
     for (int idx = gtid; idx < n; idx += gstride) {
         const float dw = a.rec[R_DW][rb + idx];
         if (!(dw > 0.f)) {

@@ -76,7 +76,10 @@ def test_points_warped_behind_the_camera(hip, ora):
     assert (g.n_outer, g.n_irls, g.status) == (o.n_outer, o.n_irls, o.status)
     assert np.array_equal(trace_array(g, "n_valid"), trace_array(o, "n_valid"))
     assert np.array_equal(trace_array(g, "lambda_t_w"), trace_array(o, "lambda_t_w"))
-    assert np.abs(trace_array(g, "b_prior") - trace_array(o, "b_prior")).max() < 2e-5
+    # b_prior to 1e-3 only: where the near surface (warped to -6 cm) and the wall behind it (2.9 m) land in ONE cell, the cell's weighted
+    # mean jumps by 0.2 m when a centi-pixel coordinate falls on the other side of an integer (a 1e-8 difference of T): 28 such cells
+    # at level 0 here (tools/diag/behind_camera_case.py), which move one cluster's prior by 4e-4 -- the scene, not the rule
+    assert np.abs(trace_array(g, "b_prior") - trace_array(o, "b_prior")).max() < 1e-3
     rot, trans = pose_delta(runs["oracle+rule"].T(), runs["hip"].T())
     assert rot <= 1e-4 and trans <= 1e-4, (rot, trans)
     for L in range(runs["hip"].levels):

@@ -172,7 +172,11 @@ def test_frame_sequence_with_history(hip, ora):
         assert np.array_equal(sg.labels(0), so.labels(0))
         cg, co = sg.cluster_residuals(), so.cluster_residuals()
         assert np.array_equal(np.isnan(cg), np.isnan(co))
-        assert np.allclose(cg[~np.isnan(cg)], co[~np.isnan(co)], rtol=2e-3, atol=2e-5)
+        # 1e-3: measured 1.2e-4 ... 6.5e-4 over three sequences and all builds (tools/diag/residual_dev.py, profiles/r03f_residual_dev.txt)
+        # -- and the oracle against ITSELF with these sums in fp64 instead of its sequential float (3200 terms per cluster) differs by
+        # 1.4e-4 ... 6.2e-4: the reference's own summation error, not the port's (the HIP sums are exact Q32.32 integers); single
+        # pixels of the 5-frame warp that land on the other side of a centi-pixel account for the rest (2e-4 ... 3.7e-4 against fp64 sums)
+        assert np.allclose(cg[~np.isnan(cg)], co[~np.isnan(co)], rtol=1e-3, atol=1e-6)
         bg, bo = sg.b_image(), so.b_image()
         assert np.array_equal(bg > 0.5, bo > 0.5), k  # the static / dynamic decision the map uses (Shaders/data.vert:180)
         assert np.abs(bg - bo).max() < 1e-4, k

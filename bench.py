@@ -156,8 +156,15 @@ def source_sha():
 
 
 def git_head():
+    """HEAD of the checkout, or -- on a GPU box, which receives a snapshot without .git -- what __graft_entry__.build() /
+    tools/stamp_head.sh recorded in staticfusion_amd/csrc/BUILD_HEAD when the libraries were built."""
     try:
         return subprocess.check_output(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        pass
+    try:
+        with open(os.path.join(ROOT, "staticfusion_amd", "csrc", "BUILD_HEAD")) as f:
+            return f.read().strip() or None
     except Exception:
         return None
 

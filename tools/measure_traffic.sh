@@ -2,7 +2,7 @@
 # HBM bytes per launch of the frame kernel from the PMC counters, tagged with the identity of the sources measured:
 # what bench.py reports as roofline.traffic (and refuses to report when the tag does not match the running sources).
 # Run ON THE GPU BOX via gpurun; copy gpurun_out/traffic_<workload>_b<batch>.json to profiles/.
-# usage: tools/measure_traffic.sh <workload: static|sphere> <batch> [variant]
+# usage: tools/measure_traffic.sh <workload: static|sphere|sequences> <batch> [variant]
 set -u
 WL=$1; B=$2; VAR=${3:-throughput}
 cd "$(dirname "$0")/.."

@@ -19,10 +19,10 @@ api = sf.load()
 p = bench.make_params(api, a.workload)
 s = sf.Solver(api, 240, 320, a.batch, p)
 if a.workload == "sequences":
-    import multiprocessing as mp
     D, F = 2, 12 + a.steps
-    with mp.get_context("spawn").Pool(min(len(os.sched_getaffinity(0)), 16)) as pool:
-        seqs = [make_sequence(1000 + q, F, sphere=True, pool=pool) for q in range(D)]
+    # no process pool here: rocprofv3 follows every child process, and a pool of spawned workers under it never came back
+    # (round 3: the orphans kept the GPU busy for everything that ran after them)
+    seqs = [make_sequence(1000 + q, F, sphere=True) for q in range(D)]
     col = lambda x: np.ascontiguousarray(np.asarray(x, np.float32).T).ravel()
     hiprt = ctypes.CDLL("libamdhip64.so")
     ptrs = []

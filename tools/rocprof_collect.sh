@@ -11,7 +11,7 @@ OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 CMD="python tools/prof_run.py --workload $WL --batch $B --steps 3"
 # default output of this rocprofv3 is a rocpd sqlite database; tools/rocprof_summarise.py reads it
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $CMD > $OUT/fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write -- $CMD > $OUT/write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $CMD > $OUT/fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write -- $CMD > $OUT/write.log 2>&1
 find $OUT -name "*.csv" | head -20

@@ -7,9 +7,9 @@ export TMPDIR=/tmp
 OUT=/tmp/tbs_$WL
 rm -rf $OUT; mkdir -p $OUT
 CMD="python tools/traffic_by_stage.py --workload $WL --batch $B"
-timeout 300 rocprofv3 --kernel-trace -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f -- $CMD > $OUT/fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w -- $CMD > $OUT/write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f -- $CMD > $OUT/fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w -- $CMD > $OUT/write.log 2>&1
 python - <<PY
 import sqlite3, glob, collections
 def load(d):

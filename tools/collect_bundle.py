@@ -62,7 +62,7 @@ for f in ("bench_default", "bench_under_rocprof", "bench_with_traffic"):
     tr = lambda r: r["traffic_provenance"] and round(r["traffic_provenance"]["ratio_to_algorithmic"], 3)
     print(f, "static", round(x["value"]), round(x["frames_per_s"]), round(x["ms_per_step"], 2), round(x["roofline"]["frac"], 4), tr(x["roofline"]),
           "| sphere", round(fs["value"]), round(fs["frames_per_s"]), round(fs["ms_per_step"], 2), round(fs["roofline"]["frac"], 4), tr(fs["roofline"]))
-    for q in x["sequences"]:
+    for q in x.get("sequences", []):
         print("    sequences", q["streams_per_gpu"], round(q["value"]), round(q["frames_per_s"]), round(q["ms_per_step"], 2), round(q["roofline"]["frac"], 4), tr(q["roofline"]))
     print("    irls passes", {k: round(v["frac"], 3) for k, v in x["roofline"]["irls_passes"].items()})
 print("cpu 1 core it/s, frames/s:", round(d["cpu_baseline"]["value"]), round(d["cpu_baseline"]["frames_per_s"], 1), "| sphere",

@@ -733,7 +733,18 @@ __device__ __noinline__ void solve_filter_and_update(const KArgs &a, LDS SolveSh
 //  relative on a row entry).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float vabs(float x) { return fabsf(x); }
+// The rows and residuals of the passes contract multiply-add pairs explicitly (the library is built -ffp-contract=off because
+// the reference has no FMA; the linearisation, whose planes are bit-compared, has none). -DSF_ROWS_FMA=0 -- part of the
+// `precise` build, libsf_hip_precise.so, together with IEEE weights -- evaluates the same expressions with separate,
+// individually rounded multiplies and adds: what the contraction costs in parity is measured, not asserted.
+#ifndef SF_ROWS_FMA
+#define SF_ROWS_FMA 1
+#endif
+#if SF_ROWS_FMA
 __device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a, b, c); }
+#else
+__device__ __forceinline__ float vfma(float a, float b, float c) { return a * b + c; }
+#endif
 
 // T = float: one pixel per lane and step (packed pixel pairs buy nothing on gfx950, §5.1 of DESIGN.md)
 template <class T>
@@ -944,8 +955,8 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, LDS SolveS
             fact_residuals<float>(p, Vr, res_c, res_d);
             const float tc = res_c * inv_c_Cauchy, td = res_d * inv_c_Cauchy;
 #if SF_FAST_WEIGHTS
-            const float w_c = b_weight * vrsq(fmaf(tc, tc, 1.f));
-            const float w_d = b_weight * vrsq(fmaf(td, td, 1.f));
+            const float w_c = b_weight * vrsq(vfma(tc, tc, 1.f));
+            const float w_d = b_weight * vrsq(vfma(td, td, 1.f));
 #else
             const float w_c = b_weight * vrsq(1.f + tc * tc);
             const float w_d = b_weight * vrsq(1.f + td * td);
@@ -955,10 +966,10 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, LDS SolveS
                 const float P = w_c * p.pc, Q = w_c * p.qc;
                 aw[0] = -P;
                 aw[1] = -Q;
-                aw[2] = fmaf(P, p.xd, Q * p.yd);
-                aw[3] = fmaf(P, p.xyd, Q * p.yyd);
-                aw[4] = -fmaf(P, p.xxd, Q * p.xyd);
-                aw[5] = fmaf(P, p.y, -(Q * p.x));
+                aw[2] = vfma(P, p.xd, Q * p.yd);
+                aw[3] = vfma(P, p.xyd, Q * p.yyd);
+                aw[4] = -vfma(P, p.xxd, Q * p.xyd);
+                aw[5] = vfma(P, p.y, -(Q * p.x));
                 aw[6] = -(w_c * p.bct);
             }
             if constexpr (VAR == 2)
@@ -969,10 +980,10 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, LDS SolveS
                 const float W = w_d * p.twd, Pd = w_d * p.pd, Qd = w_d * p.qd;
                 aw[0] = -Pd;
                 aw[1] = -Qd;
-                aw[2] = fmaf(Pd, p.xd, fmaf(Qd, p.yd, W));
-                aw[3] = fmaf(Pd, p.xyd, fmaf(Qd, p.yyd, W * p.y));
-                aw[4] = -fmaf(Pd, p.xxd, fmaf(Qd, p.xyd, W * p.x));
-                aw[5] = fmaf(Pd, p.y, -(Qd * p.x));
+                aw[2] = vfma(Pd, p.xd, vfma(Qd, p.yd, W));
+                aw[3] = vfma(Pd, p.xyd, vfma(Qd, p.yyd, W * p.y));
+                aw[4] = -vfma(Pd, p.xxd, vfma(Qd, p.xyd, W * p.x));
+                aw[5] = vfma(Pd, p.y, -(Qd * p.x));
                 aw[6] = -(w_d * p.bdt);
             }
             if constexpr (VAR == 2)
@@ -1480,8 +1491,8 @@ __device__ __forceinline__ void debug_rows(const KArgs &a, int b, float *out, in
         const float g2[6] = {0.f, -1.f, p.yd, p.yyd, -p.xyd, -p.x};
         const float g3[6] = {0.f, 0.f, 1.f, p.y, -p.x, 0.f};
         for (int c = 0; c < 6; c++) {
-            out[(size_t)c * n + idx] = fmaf(p.pc, g1[c], p.qc * g2[c]);
-            out[(size_t)(7 + c) * n + idx] = fmaf(p.twd, g3[c], fmaf(p.pd, g1[c], p.qd * g2[c]));
+            out[(size_t)c * n + idx] = vfma(p.pc, g1[c], p.qc * g2[c]);
+            out[(size_t)(7 + c) * n + idx] = vfma(p.twd, g3[c], vfma(p.pd, g1[c], p.qd * g2[c]));
         }
         out[(size_t)6 * n + idx] = -p.bct;
         out[(size_t)13 * n + idx] = -p.bdt;

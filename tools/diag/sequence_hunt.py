@@ -9,6 +9,7 @@ ITSELF under another summation convention (no GPU needed) -- and a JSON record o
 --control MODE  compare oracle [C1] (float operands, fp64 sums) with the oracle in MODE:
     gemm1  AtA / AtB accumulated in ONE float per entry          gemm2  four interleaved float partial sums (SSE packets)
     gemm3  [C1] over the rows in reverse order                   exact  the per-cluster fp32 sums in fp64 (sfo_test_set_exact_sums)
+    warp   the warp's scatter sums in fp64 from exact products (sfo_test_set_exact_warp)
 JSON: {"summary": {...}, "frames": [every frame with a discrete mismatch, a pose distance > --keep-pose or b > --keep-b]}.
 """
 import argparse
@@ -25,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
-CONTROL_MODES = {"gemm1": ("gemm", 1), "gemm2": ("gemm", 2), "gemm3": ("gemm", 3), "exact": ("exact", 1)}
+CONTROL_MODES = {"gemm1": ("gemm", 1), "gemm2": ("gemm", 2), "gemm3": ("gemm", 3), "exact": ("exact", 1), "warp": ("warp", 1)}
 
 
 def _control_prepare(mode):
@@ -33,7 +34,7 @@ def _control_prepare(mode):
 
     def prepare(solver):
         lib = solver.api.lib
-        fn = lib.sfo_test_set_gemm_mode if kind == "gemm" else lib.sfo_test_set_exact_sums
+        fn = {"gemm": lib.sfo_test_set_gemm_mode, "exact": lib.sfo_test_set_exact_sums, "warp": lib.sfo_test_set_exact_warp}[kind]
         fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
         assert fn(solver.h, val) == 0
 

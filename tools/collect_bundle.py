@@ -17,7 +17,7 @@ def cp(src, dst=None):
     return False
 
 
-for f in ("bench_default.json", "bench_under_rocprof.json", "bench_with_traffic.json", "rocprofv3_stats_bench.csv", "stage_profiles.txt",
+for f in ("bench_default.json", "bench_under_rocprof.json", "rocprofv3_stats_bench.csv", "stage_profiles.txt",
           "traffic_by_stage_sphere.txt", "traffic_by_stage_static.txt", "pass_microbench_b512.txt", "parity_report.md", "parity_report.json",
           "b_summary.txt", "hunt_160x120_s5000_n240.json", "hunt_160x120_s20000_n1000.json", "hunt_qvga_s7000_n60.json",
           "hunt_qvga_noseg_s7000_n60.json"):
@@ -56,7 +56,7 @@ o5 = sorted(((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r i
 res["timed_launches"]["full_solver"]["trace_ms_candidates_longest_first"] = [round(x, 3) for x in o5[:3]]
 json.dump(res, open(os.path.join(P, "%s_rocprofv3_trace_summary.json" % T), "w"), indent=1)
 print("timed launches, trace vs HIP events:", json.dumps(res["timed_launches"]))
-for f in ("bench_default", "bench_under_rocprof", "bench_with_traffic"):
+for f in ("bench_default", "bench_under_rocprof"):
     x = last(os.path.join(G, "%s_%s.json" % (T, f)))
     fs = x["full_solver"]
     tr = lambda r: r["traffic_provenance"] and round(r["traffic_provenance"]["ratio_to_algorithmic"], 3)

@@ -50,7 +50,7 @@ res["timed_launches"] = {
     "static": {"trace_ms": max((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if r["Kernel_Name"].startswith("sf_frame_kernel_nt256(")),
                "bench_hip_events_ms": b["roofline"]["kernel_launch_ms"]},
     "full_solver": {"bench_hip_events_ms": b["full_solver"]["roofline"]["kernel_launch_ms"]},
-    "sequences": [{"streams": q["streams_per_gpu"], "bench_hip_events_ms": q["roofline"]["kernel_launch_ms"]} for q in b["sequences"]],
+    "sequences": [{"streams": q["streams_per_gpu"], "bench_hip_events_ms": q["roofline"]["kernel_launch_ms"]} for q in b.get("sequences", [])],
 }
 o5 = sorted(((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if r["Kernel_Name"].startswith("sf_frame_kernel_nt256o5(")), reverse=True)
 res["timed_launches"]["full_solver"]["trace_ms_candidates_longest_first"] = [round(x, 3) for x in o5[:3]]

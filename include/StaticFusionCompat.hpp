@@ -178,6 +178,9 @@ class StaticFusionCompat {
     // the drivers' ring buffer writes: depthBuffer[i%5] = depthCurrent; intensityBuffer[i%5] = ...;
     // odomBuffer[i%5] = T_odometry   (StaticFusion-datasets.cpp:182-184)
     void pushBuffers(int im_count) { check(sf_push_history(h_, im_count), "push_history"); }
+    // no counterpart in the reference: with SF_VARIANT=cluster (24 workgroups share the one stream) a frame whose workgroups were not
+    // all resident reports SF_STATUS_SYNC_TIMEOUT and the solver keeps the state of its last good frame; this puts it back into service
+    void clearSyncTimeout() { check(sf_clear_sync_timeout(h_), "clear_sync_timeout"); }
 
     sf_handle *handle() { return h_; }
 

@@ -740,6 +740,11 @@ __device__ __forceinline__ float vabs(float x) { return fabsf(x); }
 #ifndef SF_ROWS_FMA
 #define SF_ROWS_FMA 1
 #endif
+// pass 1 folds each row's pre-weight into its Cauchy weight (one reciprocal square root per row instead of two): part of the
+// product build's arithmetic, off in the `precise` build, which keeps the reference's two-step association
+#ifndef SF_P1_FOLD
+#define SF_P1_FOLD (SF_FAST_WEIGHTS && SF_ROWS_FMA)
+#endif
 #if SF_ROWS_FMA
 __device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a, b, c); }
 #else
@@ -751,9 +756,12 @@ template <class T>
 struct PixFact {
     T x, y, xd, yd, xyd, xxd, yyd;  // geometry: x, y, x/d, y/d, xy/d, x^2/d + d, y^2/d + d
     T pc, qc, pd, qd, twd, bct, bdt;
+    T ac, ad;                       // RAW form only: the arguments 1 + e_c, 0.01 + e_d of the two pre-weights
 };
 
-template <class T>
+// RAW = true: the same record WITHOUT the pre-weights: pc = dcu f/d, ..., bct = dct, bdt = ddt, twd = 1, and the arguments of the
+// two reciprocal square roots in o.ac / o.ad -- for pass 1, which folds each pre-weight into the Cauchy weight of its row (below)
+template <class T, bool RAW = false>
 __device__ __forceinline__ void fact_from_record(const LevelGeom &g, T fu, T fv, T dn, T dw, T dcu_, T dcv_, T dct_, T ddu_,
                                                  T ddv_, PixFact<T> &o) {
     const T xn = (g.inv_f_pyr * (fu - g.disp_u_i)) * dn;
@@ -772,16 +780,28 @@ __device__ __forceinline__ void fact_from_record(const LevelGeom &g, T fu, T fv,
     const T ddt_ = dn - dw;
     const T error_l_c = 10.f * (vabs(dct_) + vabs(dcu_) + vabs(dcv_));
     const T error_l_d = 200.f * (vabs(ddt_) + vabs(ddu_) + vabs(ddv_));
-    const T twc = (g.inv_max_c * vrsq(1.f + error_l_c)) * g.kph;
-    o.twd = g.inv_max_d * vrsq(0.01f + error_l_d);
     const T inv_d = vrcpw(d);
     const T fd = g.f_inv * inv_d;
-    o.pc = twc * (dcu_ * fd);
-    o.qc = twc * (dcv_ * fd);
-    o.pd = o.twd * (ddu_ * fd);
-    o.qd = o.twd * (ddv_ * fd);
-    o.bct = twc * dct_;
-    o.bdt = o.twd * ddt_;
+    if constexpr (RAW) {
+        o.ac = 1.f + error_l_c;
+        o.ad = 0.01f + error_l_d;
+        o.twd = 1.f;
+        o.pc = dcu_ * fd;
+        o.qc = dcv_ * fd;
+        o.pd = ddu_ * fd;
+        o.qd = ddv_ * fd;
+        o.bct = dct_;
+        o.bdt = ddt_;
+    } else {
+        const T twc = (g.inv_max_c * vrsq(1.f + error_l_c)) * g.kph;
+        o.twd = g.inv_max_d * vrsq(0.01f + error_l_d);
+        o.pc = twc * (dcu_ * fd);
+        o.qc = twc * (dcv_ * fd);
+        o.pd = o.twd * (ddu_ * fd);
+        o.qd = o.twd * (ddv_ * fd);
+        o.bct = twc * dct_;
+        o.bdt = o.twd * ddt_;
+    }
     o.xd = o.x * inv_d;
     o.yd = o.y * inv_d;
     o.xyd = o.xd * o.y;
@@ -904,6 +924,10 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, LDS SolveS
     const IrlsCtx c = make_irls_ctx(a, b, L, s);
     const int lane = tid & 63, wave = tid >> 6;
     const float inv_c_Cauchy = 1.f / (a.p.kc_Cauchy * uniform_f(s.aver_res));
+#if SF_P1_FOLD
+    const float fold_kc = c.g.inv_max_c * c.g.kph, fold_kd = c.g.inv_max_d;                    // pre-weight = k rsq(a)
+    const float fold_gc = fold_kc * inv_c_Cauchy, fold_gd = fold_kd * inv_c_Cauchy;
+#endif
     float acc[27];
 #pragma unroll
     for (int q = 0; q < 27; q++) acc[q] = 0.f;
@@ -947,6 +971,22 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, LDS SolveS
                 fv = wrap ? 0.f : fv0 + 1.f;
             }
             PixFact<float> p;
+#if SF_P1_FOLD
+            // The weight a row finally carries is (pre-weight) x (Cauchy weight) = k rsq(a) b rsq(1 + (k rsq(a) R / c)^2) with R the
+            // residual of the UNWEIGHTED row, a = 1 + e_c (0.01 + e_d) and k = kph / max (1 / max): that is b k rsq(a + (k R / c)^2) --
+            // one reciprocal square root per row instead of two, and the rows are scaled once instead of twice. Same mathematics;
+            // the rounding of a row entry moves by ~1e-7 relative like the factored rows themselves (pass 2 and the debug
+            // expansion of the rows keep the two-step form).
+            fact_from_record<float, true>(c.g, fu, fv, rv.dn[j], rv.v[R_DW][j], rv.v[R_DCU][j], rv.v[R_DCV][j], rv.v[R_DCT][j],
+                                          rv.v[R_DDU][j], rv.v[R_DDV][j], p);
+            if (j == 0) asm volatile("" : "+v"(bseg0), "+v"(bseg1));  // LDS reads stay unconditional, landed by now
+            const float b_weight = ok ? std_max(0.f, std_min(1.f, j ? bseg1 : bseg0)) : 0.f;
+            float raw_c, raw_d;
+            fact_residuals<float>(p, Vr, raw_c, raw_d);
+            const float uc = raw_c * fold_gc, ud = raw_d * fold_gd;
+            const float w_c = (b_weight * fold_kc) * vrsq(fmaf(uc, uc, p.ac));
+            const float w_d = (b_weight * fold_kd) * vrsq(fmaf(ud, ud, p.ad));
+#else
             fact_from_record<float>(c.g, fu, fv, rv.dn[j], rv.v[R_DW][j], rv.v[R_DCU][j], rv.v[R_DCV][j], rv.v[R_DCT][j],
                                     rv.v[R_DDU][j], rv.v[R_DDV][j], p);
             if (j == 0) asm volatile("" : "+v"(bseg0), "+v"(bseg1));  // LDS reads stay unconditional, landed by now
@@ -960,6 +1000,7 @@ __device__ __noinline__ void irls_pass1(const KArgs &a, int b, int L, LDS SolveS
 #else
             const float w_c = b_weight * vrsq(1.f + tc * tc);
             const float w_d = b_weight * vrsq(1.f + td * td);
+#endif
 #endif
             float aw[7];
             {

@@ -59,7 +59,8 @@ def run_case(api, case, variant=None, prepare=None):
         out.append({
             "T": s.T().copy(), "labels": s.labels(0).copy(), "b_img": s.b_image().copy(), "b": s.b().copy(),
             "counts": (int(st.n_outer), int(st.n_irls)), "status": int(st.status),
-            "outer": [(int(o.level), int(o.k), int(o.irls_iters), float(o.delta_sol_max), int(o.n_valid))
+            "outer": [(int(o.level), int(o.k), int(o.irls_iters), float(o.delta_sol_max), int(o.n_valid),
+                       float(np.sqrt(np.sum(np.array(o.twist_level[:], dtype=np.float64) ** 2))))
                       for o in (st.outer[i] for i in range(st.n_outer))],
         })
     s.close()
@@ -68,8 +69,9 @@ def run_case(api, case, variant=None, prepare=None):
 
 def compare_frames(ref, got, thr):
     """One record per frame: pose distance, discrete mismatches, b distances, and -- when the IRLS counts differ -- whether
-    it is a STOPPING-THRESHOLD FLIP: one level whose count differs by one while the `delta_sol_max` the stopping test
-    (reference FrontEnd.cpp:676-679) saw on either side lies within `flip_margin` of irls_delta_threshold."""
+    it is a STOPPING-THRESHOLD FLIP: one level whose IRLS count differs while the `delta_sol_max` that passed the stopping
+    test (reference FrontEnd.cpp:676-679) on the side that stopped first lies within 5 % of irls_delta_threshold -- or a
+    LEVEL-EXIT tie (classify_flip)."""
     recs = []
     for k, (a, b) in enumerate(zip(ref, got)):
         rot, trans = pose_delta(a["T"], b["T"])
@@ -88,15 +90,20 @@ def compare_frames(ref, got, thr):
 
 
 def classify_flip(outer_ref, outer_got, thr, rel_margin=0.05):
-    """The first outer iteration whose IRLS count differs, and how close to the threshold the deciding delta was."""
+    """The first outer iteration whose IRLS count differs, and how close to the threshold the deciding delta was. The path has
+    a second discontinuity of the same kind: a level is left when the norm of its twist falls below 0.04 (reference
+    FrontEnd.cpp:1130); when the two runs disagree on THAT, their sequences of (level, k) differ from the next entry on."""
     for i, (a, b) in enumerate(zip(outer_ref, outer_got)):
         if a[:2] != b[:2]:
-            return {"kind": "outer-structure", "outer": i}
+            prev = outer_ref[i - 1] if i else None
+            margin = abs(prev[5] - 0.04) / 0.04 if prev else 1.0
+            return {"kind": "level-exit" if margin <= rel_margin else "outer-structure", "outer": i, "twist_norm_before": prev and prev[5], "rel_margin": margin}
         if a[2] != b[2]:
             # the side that stopped EARLIER reports the delta that passed the test; the other side's delta at that
             # iteration is not in the trace, but both are the same quantity up to rounding
             early = a if a[2] < b[2] else b
             margin = abs(early[3] - thr) / thr
-            return {"kind": "threshold" if (abs(a[2] - b[2]) == 1 and margin <= rel_margin) else "other", "outer": i, "level": a[0],
+            # (the side that went on may need more than one further iteration -- up to max_iter_irls -- before ITS delta passes)
+            return {"kind": "threshold" if margin <= rel_margin else "other", "outer": i, "level": a[0],
                     "irls": [a[2], b[2]], "delta_at_stop": early[3], "threshold": thr, "rel_margin": margin}
     return {"kind": "outer-count", "outer": min(len(outer_ref), len(outer_got))}

@@ -68,7 +68,9 @@ def _check_run(hip, case, ref, thr, allow_flip):
         flip = r.get("flip")
         if flip and not after_flip:
             assert allow_flip, (where, flip)
-            assert flip["kind"] == "threshold", (where, flip)  # one level, one iteration, the deciding delta at the threshold
+            # one level, one iteration, the deciding delta at the threshold -- or the level-exit test (norm of the level's twist
+            # against 0.04, FrontEnd.cpp:1130) decided in the last digit
+            assert flip["kind"] in ("threshold", "level-exit"), (where, flip)
             flips.append((r["frame"], flip))
             after_flip = True
         if not after_flip:

@@ -116,7 +116,7 @@ def main():
                     flip = rec.get("flip")
                     if flip:
                         summ["count_mismatch_frames"] += 1
-                        if flip["kind"] == "threshold" and not after_flip:
+                        if flip["kind"] in ("threshold", "level-exit") and not after_flip:
                             summ["threshold_flips"] += 1
                         elif not after_flip:
                             summ["other_count_mismatches"] += 1

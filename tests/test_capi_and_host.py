@@ -166,3 +166,29 @@ def test_frames_in_one_call_on_the_oracle(ora):
         for b in range(2):
             assert np.array_equal(T[k, b], one.T(b))
     assert np.array_equal(many.b(1), one.b(1))
+
+
+def test_bench_head_stamp_fallback(tmp_path, monkeypatch):
+    """bench.git_head(): the checkout's HEAD, or -- on a GPU box, which gets a snapshot without .git -- the stamp build() left
+    beside the libraries (staticfusion_amd/csrc/BUILD_HEAD)."""
+    import subprocess
+
+    import bench
+
+    head = bench.git_head()
+    assert head is None or len(head) >= 7
+    stamp = os.path.join(ROOT, "staticfusion_amd", "csrc", "BUILD_HEAD")
+    had = open(stamp).read() if os.path.exists(stamp) else None
+    try:
+        open(stamp, "w").write("abcdef012345+dirty\n")
+
+        def no_git(*a, **k):
+            raise OSError("no git here")
+
+        monkeypatch.setattr(subprocess, "check_output", no_git)
+        assert bench.git_head() == "abcdef012345+dirty"
+    finally:
+        if had is None:
+            os.remove(stamp)
+        else:
+            open(stamp, "w").write(had)

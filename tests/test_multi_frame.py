@@ -138,3 +138,32 @@ def test_argument_checks(hip, pair):
         s.process_frames(-1, 2)
     T = s.process_frames(0, 1, trajectory=True)  # one frame: the plain call
     assert np.array_equal(T[0, 1], s.T(1))
+
+
+def test_pool_arguments_are_checked(hip, pair):
+    """a frame number outside the pool or a misaligned pool must be refused on the host, nothing launched."""
+    import ctypes
+
+    import staticfusion_amd as sf
+
+    hiprt = ctypes.CDLL("libamdhip64.so")
+    s = make_solver(hip, 60, 80, driver_params(hip), pair(seed=3, rows=60, cols=80, sphere=True), batch=2)
+    n0 = 60 * 80
+    ptr = ctypes.c_void_p()
+    assert hiprt.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(4 * n0 * 3 + 64)) == 0
+    base = ptr.value
+    ok = np.array([0, 2], np.int32)
+    s.advance_sequences_device(base, base, ok, 3)
+    before = s.plane(capi.SET_NEW, capi.CH_DEPTH, 0, 1).copy()
+    with pytest.raises(sf.SfError):
+        s.advance_sequences_device(base, base, np.array([0, 3], np.int32), 3)   # frame 3 of a pool of 3
+    with pytest.raises(sf.SfError):
+        s.advance_sequences_device(base + 4, base, ok, 3)                        # not 16-byte aligned
+    with pytest.raises(sf.SfError):
+        s.process_sequence_frames_device(base, base, np.array([[0, 1], [1, 7]], np.int32), 3, 1)
+    with pytest.raises(sf.SfError):
+        s.advance_sequences_device(base, base, ok, 0)
+    assert np.array_equal(s.plane(capi.SET_NEW, capi.CH_DEPTH, 0, 1), before)  # nothing was launched by the refused calls
+    s.advance_sequences_device(base, base, np.array([-1, 1], np.int32), 3)     # a negative entry leaves that stream alone
+    s.synchronize()
+    hiprt.hipFree(ptr)

@@ -485,45 +485,84 @@ __device__ __forceinline__ unsigned km_nearest_seed(int rows_km, int cols_km, un
 #define WIN_CELLS (WIN_V * WIN_U)
 
 #define SPLAT_MAX_LAZY_TILES 512
+#define SPLAT_LAZY_COLS 640  // lazy mode keeps a row watermark per accumulator column (SplatMarks)
+#ifndef SF_SPLAT_FRESH
+#define SF_SPLAT_FRESH 1
+#endif
 struct SplatWin {
     long long d[WIN_CELLS];
     long long i[WIN_CELLS];  // packed like the global cell
     int vmin, umin;
     unsigned ovf[SPLAT_MAX_LAZY_TILES / 32];  // lazy mode: tiles with targets outside their window (replayed at the end)
 };
-// Lazy zeroing (one workgroup per stream only): instead of a pass that zeroes the whole accumulator image before the
-// splat, the tile loop zeroes the accumulator COLUMNS a window reaches right before the first window that reaches them
-// (windows move left to right with the source tiles, a watermark keeps what is done). The lines are still in L2 when the
-// window's atomics arrive a few microseconds later, so a cell costs one write-back instead of a zero write, a fetch
-// and a second write-back. Targets outside a tile's window (rare: strong local stretch) cannot go straight to the
-// global cells then -- their column may not be zeroed yet -- so the tile is flagged and replayed after the last tile.
+// Lazy initialisation (one workgroup per stream only): no pass zeroes the accumulator image before the splat. A watermark
+// per accumulator COLUMN (SplatMarks: rows [0, zrow[c]) of column c hold zero or sums) tells the flush of a window which
+// of its cells nobody has written yet: those are STORED -- the window's value, zero included -- and only cells below the
+// watermark, which an earlier window reached, take atomics; rows between the watermark and the window's first row are
+// stored as zero, and what no window reached is zeroed after the last tile. A cell then crosses the fabric once on its way
+// out (the L2 writes stores through and gives a line up after an atomic: zero + atomic cost two write-backs and a fetch)
+// instead of being zeroed first and added to afterwards. The tiles walk down a strip of SPLAT_TU columns and then move
+// right, so the watermark of a column only grows. Targets outside a tile's window (rare: strong local stretch) cannot go
+// straight to the global cells -- their cell may not be initialised yet -- so the tile is flagged and replayed after the
+// last tile. (-DSF_SPLAT_FRESH=0: the round-2 form -- zero the columns a window reaches first, atomics for every cell.)
+struct SplatMarks {
+    unsigned short zrow[SPLAT_LAZY_COLS];
+};
 __device__ __forceinline__ bool splat_lazy_ok(int rows_i, int cols_i, int G) {
     const int tiles = ((rows_i + SPLAT_TV - 1) / SPLAT_TV) * ((cols_i + SPLAT_TU - 1) / SPLAT_TU);
-    return G == 1 && tiles <= SPLAT_MAX_LAZY_TILES;
+    return G == 1 && tiles <= SPLAT_MAX_LAZY_TILES && cols_i <= SPLAT_LAZY_COLS && rows_i < 65536;
 }
 
 // Src::load(v, u, idx, z, xr, yr, iw) -> bool valid
 template <class Src>
 __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int cols_i, const Src &src, gptr<long long> acc_d,
-                                            gptr<long long> acc_i, LDS SplatWin &win, int tid, int tile_first = 0, int tile_step = 1,
-                                            bool lazy = false, long long *replayed = nullptr) {
+                                            gptr<long long> acc_i, LDS SplatWin &win, LDS SplatMarks &marks, int tid, int tile_first = 0,
+                                            int tile_step = 1, bool lazy = false, long long *replayed = nullptr) {
     const int lane = tid & 63;
     const int tiles_v = (rows_i + SPLAT_TV - 1) / SPLAT_TV, tiles_u = (cols_i + SPLAT_TU - 1) / SPLAT_TU;
     const int n_tiles = tiles_v * tiles_u;
     int zcol = 0;  // lazy: accumulator columns [0, zcol) are zero or hold sums already
     if (lazy) {
         if (tid < SPLAT_MAX_LAZY_TILES / 32) win.ovf[tid] = 0;  // ordered before its first use by the tile loop's barriers
+#if SF_SPLAT_FRESH
+        for (int c = tid; c < cols_i; c += SF_NT) marks.zrow[c] = 0;
+#endif
     }
+    // the rows [from, to) of column c, for every lane that raises `flag`, zeroed by the whole wave (call it wave-uniformly)
+    auto zero_flagged = [&](bool flag, int c, int from, int to) {
+        for (unsigned long long m = __ballot(flag); m; m &= m - 1) {
+            const int l = __builtin_ctzll(m);
+            const int cc = __builtin_amdgcn_readlane(c, l), tt = __builtin_amdgcn_readlane(to, l);
+            for (int v = __builtin_amdgcn_readlane(from, l) + lane; v < tt; v += 64) {
+                gst(acc_d, v + cc * rows_i, 0ll);
+                gst(acc_i, v + cc * rows_i, 0ll);
+            }
+        }
+    };
+    int pend_u0 = -1, pend_z = 0;  // the columns the last flush reached and their new watermark (set one trip later: no barrier of its own)
     // lazy: a second walk over the tiles (it >= n_tiles) replays the flagged ones for their out-of-window targets
     for (int it = tile_first; it < (lazy ? 2 * n_tiles : n_tiles); it += tile_step) {  // a cluster's workgroups take every G-th tile
         const bool replay = it >= n_tiles;
+        if (SF_SPLAT_FRESH && pend_u0 >= 0) {  // (the flush that read the watermarks ended with a barrier)
+            if (tid < WIN_U && pend_u0 + tid < cols_i && pend_z > (int)marks.zrow[pend_u0 + tid]) marks.zrow[pend_u0 + tid] = (unsigned short)pend_z;
+            pend_u0 = -1;
+        }
         const int tile = replay ? it - n_tiles : it;
         if (replay) {
             if (it == n_tiles) {  // every tile flushed: zero what no window reached; the flags are complete
+#if SF_SPLAT_FRESH
+                __syncthreads();  // the last window's watermarks (set at the top of this trip) are visible
+                for (int c0 = 0; c0 < cols_i; c0 += SF_NT) {  // a lane per column; a column short of the last row is rare
+                    const int c = c0 + tid;
+                    const int z = c < cols_i ? (int)marks.zrow[c] : rows_i;
+                    zero_flagged(z < rows_i, c, z, rows_i);
+                }
+#else
                 for (int idx = zcol * rows_i + tid; idx < cols_i * rows_i; idx += SF_NT) {
                     gst(acc_d, idx, 0ll);
                     gst(acc_i, idx, 0ll);
                 }
+#endif
                 __syncthreads();
             }
             if (!((uniform_i((int)win.ovf[tile >> 5]) >> (tile & 31)) & 1)) continue;
@@ -583,8 +622,8 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
         }
         __syncthreads();
         const int wv0 = uniform_i(win.vmin), wu0 = uniform_i(win.umin);
-        if (lazy && !replay && wu0 != 0x7fffffff) {  // zero the columns this window reaches first (stores ordered before the
-                                                     // flush's atomics by the barrier in front of phase 3)
+        if (!SF_SPLAT_FRESH && lazy && !replay && wu0 != 0x7fffffff) {  // zero the columns this window reaches first (stores ordered
+                                                                        // before the flush's atomics by the barrier in front of phase 3)
             const int need = min(cols_i, wu0 + WIN_U);
             if (need > zcol) {
                 for (int idx = zcol * rows_i + tid; idx < need * rows_i; idx += SF_NT) {
@@ -647,7 +686,44 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
         }
         __syncthreads();
         // ---- phase 3: add the touched cells to the global accumulators (consecutive lanes -> consecutive v)
-        if (!replay)
+        if (SF_SPLAT_FRESH && lazy) {
+            if (!replay && wu0 != 0x7fffffff) {  // (no valid source pixel in the tile: nothing to flush, no column reached)
+                // Groups of 16 lanes take 16 rows that start on a multiple of 16 (a 128-byte line of cells where the level's
+                // rows are a multiple of 16, as at QVGA's level 0): the stores are whole lines, written once. Rows [r0, znew)
+                // of every window column: the window's cells and the padding up to the next multiple of 16 either side.
+                const int vend = min(wv0 + WIN_V, rows_i);
+                const int znew = min((vend + 15) & ~15, rows_i), r0 = wv0 & ~15;
+                const int ng = (znew - r0 + 15) >> 4;  // groups per column
+                // gi / ng == (gi * mdiv) >> 16 for gi * ng < 65536 (mdiv = floor(65536 / ng) + 1; the quotient is far from an
+                // integer unless ng is a power of two, where the reciprocal is exact)
+                const unsigned mdiv = (unsigned)(65536.f * __builtin_amdgcn_rcpf((float)ng)) + 1u;
+                const int total = ng * min(WIN_U, cols_i - wu0);
+                for (int g0 = 0; g0 < total; g0 += SF_NT / 16) {  // (wave-uniform trip count: zero_flagged wants the whole wave)
+                    const int gi = g0 + (tid >> 4);
+                    const int du = (int)(((unsigned)gi * mdiv) >> 16), gr = gi - du * ng;
+                    const int c = wu0 + du, v = r0 + (gr << 4) + (tid & 15);
+                    const bool live = gi < total && v < znew;
+                    const int z = live ? (int)marks.zrow[c] : 0x7fff;
+                    const int dv = v - wv0;
+                    const bool in_win = live && dv >= 0 && v < vend;
+                    const int q = in_win ? dv + du * WIN_V : 0;
+                    const long long packed = in_win ? win.i[q] : 0ll, sd = in_win ? win.d[q] : 0ll;
+                    const int t = v + c * g.rows_i;
+                    if (live && v >= z) {  // nobody has written this cell: the window's value -- or zero -- is its value
+                        gst(acc_d, t, sd);
+                        gst(acc_i, t, packed);
+                    } else if (packed != 0) {
+                        gatomic_add_at(acc_d, t, sd);
+                        gatomic_add_at(acc_i, t, packed);
+                    }
+                    // rows between the watermark and r0 (a column the window above did not reach): the first lane of the column's
+                    // first group reports it
+                    zero_flagged(live && gr == 0 && (tid & 15) == 0 && z < r0, c, z, r0);
+                }
+                pend_u0 = wu0;
+                pend_z = znew;
+            }
+        } else if (!replay)
         for (int q = tid; q < WIN_CELLS; q += SF_NT) {
             const long long packed = win.i[q];
             if (packed == 0) continue;  // sum(w) >= 1 makes a touched cell non-zero

@@ -14,6 +14,7 @@ struct ResShared {
     int lab_cnt[SF_NC];
     double dwork[32];
     SplatWin win;
+    SplatMarks marks;
 };
 
 __device__ __forceinline__ int level0_label(const KArgs &a, gptr<const uint8_t> labels0, int idx) {
@@ -91,7 +92,7 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
             return z != 0.f && dc != 0.f;
         }
     } src{dbuf, ibuf, dcur, inv_f_i, g.disp_u_i, g.disp_v_i};
-    tiled_splat(g, rows, cols, src, acc_d, acc_i, s.win, tid, rank, G, lazy, &st.prof[PF_SPLAT_REPLAYS]);
+    tiled_splat(g, rows, cols, src, acc_d, acc_i, s.win, s.marks, tid, rank, G, lazy, &st.prof[PF_SPLAT_REPLAYS]);
     cluster_rendezvous(cs, tid);
 
     // residuals, cluster-wise (:1036-1068): per-lane running sums per label, flushed to the workgroup bins

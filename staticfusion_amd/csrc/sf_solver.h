@@ -99,7 +99,11 @@ struct SolveShared {
     // small solves
     float M6[6 * 7], tmp6[6], y6[6];
     int tr6[6];
-    float M24[SF_NC * (SF_NC + 1)], tmp24[SF_NC], y24[SF_NC], seg_diag[SF_NC], aver_res_label[SF_NC];
+    union {
+        float M24[SF_NC * (SF_NC + 1)];  // factored and used inside solve_irls
+        SplatMarks marks;                // the warp's column watermarks (solve_warp, between two solve_irls)
+    };
+    float tmp24[SF_NC], y24[SF_NC], seg_diag[SF_NC], aver_res_label[SF_NC];
     int tr24[SF_NC];
     int seg_allzero;
     long long prof[SF_PROF_SLOTS], t_last;
@@ -270,7 +274,7 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
             return z != 0.f;
         }
     } src{dpred, ipred, level_coord(a, L)};
-    tiled_splat(g, rows_i, cols_i, src, acc_d, acc_i, s.win, tid, rank, G, lazy, &a.state[b].prof[PF_SPLAT_REPLAYS]);
+    tiled_splat(g, rows_i, cols_i, src, acc_d, acc_i, s.win, s.marks, tid, rank, G, lazy, &a.state[b].prof[PF_SPLAT_REPLAYS]);
     cluster_rendezvous(cs, tid);  // all atomics of the workgroup(s) performed: the linearisation reads the cells with atomic loads
 }
 

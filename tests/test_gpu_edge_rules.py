@@ -91,3 +91,53 @@ def test_points_warped_behind_the_camera(hip, ora):
     n = min(len(nv_g), len(nv_r))
     first = int(np.argmax(nv_g[:n] != nv_r[:n]))
     assert (nv_g[:n] != nv_r[:n]).any() and nv_g[first] < nv_r[first]
+
+
+def test_first_touch_splat_on_odd_geometry(hip, ora):
+    """The one-workgroup builds' splat keeps no zeroed accumulator image: a window's flush STORES the cells nobody has written
+    yet (a row watermark per column says which, sf_device_common.h) in groups of 16 rows. What that bookkeeping has to get
+    right, all in one scene: rows that are not a multiple of 16 (200: the last group of a column is short), source tiles
+    without a valid pixel (three strips of 16 predicted columns are holes: their windows do not exist, the columns they would
+    have reached are zeroed at the end), a block of holes at the top of another strip (its first window starts far down: the
+    rows above are skipped rows), and a motion with a strong roll, under which the windows of the tiles of one strip reach
+    different columns. The warped images of every level and the five-frame residuals (the second user of the splat) equal the
+    oracle's; the cluster build (zero pass + atomics on every cell) runs the same comparison."""
+    from staticfusion_amd import _capi as capi
+    from staticfusion_amd.synth import Scene, quantise_and_decimate, se3_exp
+    from test_gpu_parity import POSE_TOL, assert_planes_close
+
+    rows, cols = 200, 264
+    scene = Scene(seed=31, sphere=True)
+    xi = np.array((0.010, -0.005, 0.008, 0.03, -0.006, 0.003))  # the fourth component turns the image about the optical axis
+    frames, T = [], np.eye(4)
+    for k in range(7):
+        d, i = quantise_and_decimate(*scene.render(T, 2 * cols, 2 * rows, sphere_offset=(0.02 * k, 0, 0)))
+        d = d.copy()
+        d[:, 96:144] = 0     # three source strips without a valid pixel
+        d[0:120, 208:232] = 0  # a strip whose first valid row is far down
+        frames.append((d, i))
+        T = T @ se3_exp(xi)
+    assert frames[0][0].shape == (rows, cols)
+    solvers = [make_solver(api, rows, cols, driver_params(api, kb=1.5, ctf_levels=3, debug_planes=1)) for api in (hip, ora)]
+    for s in solvers:
+        s.set_current(0, *frames[0])
+        s.current_to_prediction()
+        s.push_history(0)
+    for k in range(1, 7):
+        for s in solvers:
+            s.set_prediction(0, *frames[k - 1])
+            s.set_current(0, *frames[k])
+            s.process_frame(k)
+        sg, so = solvers
+        rot, trans = pose_delta(so.T(), sg.T())
+        assert rot <= POSE_TOL and trans <= POSE_TOL, (k, rot, trans)
+        assert np.array_equal(sg.labels(0), so.labels(0))
+        a, b = sg.stats(), so.stats()
+        assert (a.n_outer, a.n_irls) == (b.n_outer, b.n_irls), k
+        for L in range(3):
+            for ch in range(2):  # warped depth and intensity as the last linearisation of the level saw them
+                assert_planes_close(sg.plane(capi.SET_WARPED, ch, L), so.plane(capi.SET_WARPED, ch, L), frac=0.97)
+        if k >= 5:
+            cg, co = sg.cluster_residuals(), so.cluster_residuals()
+            assert np.array_equal(np.isnan(cg), np.isnan(co))
+            assert np.allclose(cg[~np.isnan(cg)], co[~np.isnan(co)], rtol=1e-3, atol=1e-6)  # (tolerance: test_frame_sequence_with_history)

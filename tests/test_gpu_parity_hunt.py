@@ -34,6 +34,10 @@ pytestmark = pytest.mark.gpu
 
 NAMED_SEEDS = (5211, 20115, 20527)
 QVGA_SEEDS = range(31000, 31040)
+# the 600-sequence QVGA hunt on round 3's final sources (profiles/r03o_hunt_qvga_s8000_n600.json): every sequence in which a build left
+# the pose bar. 8163, 8328, 8340: stopping-threshold ties (the oracle against its own gemm2 / gemm1 / fp64-warp readings leaves the
+# bar on the same three sequences, profiles/r03o_control_*). 8171: no tie -- see test_qvga_sequence_with_an_ill_conditioned_frame
+QVGA_NAMED_SEEDS = (8163, 8328, 8340)
 _cache = {}
 
 
@@ -86,6 +90,37 @@ def test_frames_the_round_2_hunts_found(hip, ora, seed):
     recs, flips = _check_run(hip, case, ref, thr, allow_flip=True)
     worst = max(max(r["rot"], r["trans"]) for r in recs)
     print("seed %d %s: worst pose distance %.2e, threshold flips %s" % (seed, hip.default_variant, worst, [(f, x["level"], x["irls"], "%.3e" % x["delta_at_stop"]) for f, x in flips]))
+
+
+@pytest.mark.parametrize("seed", QVGA_NAMED_SEEDS)
+def test_qvga_frames_the_round_3_hunt_found(hip, ora, seed):
+    (case, ref), = _cases([(seed, 640, 480)])
+    thr = float(ora.default_params_struct().irls_delta_threshold)
+    recs, flips = _check_run(hip, case, ref, thr, allow_flip=True)
+    print("QVGA seed %d %s: worst pose distance %.2e, flips %s" % (seed, hip.default_variant, max(max(r["rot"], r["trans"]) for r in recs),
+                                                                  [(f, x["kind"]) for f, x in flips]))
+
+
+def test_qvga_sequence_with_an_ill_conditioned_frame(hip, ora):
+    """Seed 8171 at QVGA, frame 6: 6.8e-4 m from the oracle on the throughput and latency builds (2.5e-7 on the cluster build) with
+    IDENTICAL iteration counts. tools/diag/frame_trace_diff.py shows where it comes from: the b field carried into the frame
+    differs by 2e-3 / 2e-4 (values the oracle's own readings reach in 1.5 % of the frames), and at the second-coarsest level --
+    1064 valid pixels, clusters of a few dozen -- that moves the b of one cluster by 0.055 and with it the level's twist by
+    1e-3; the finer levels take most of it back. An ill-conditioned frame of the algorithm (slow motion, 0.38 x the default step,
+    a sphere crossing small clusters), not a tie: what holds is every discrete outcome, the counts, and the pose to 1e-3."""
+    (case, ref), = _cases([(8171, 640, 480)])
+    from sequence_cases import run_case as _run
+
+    got = _run(hip, case)
+    thr = float(ora.default_params_struct().irls_delta_threshold)
+    for r in compare_frames(ref, got, thr):
+        where = (8171, hip.default_variant, r["frame"])
+        assert r["label_px"] == 0 and r["decision_px"] == 0, where
+        assert r["rot"] <= 1e-3 and r["trans"] <= 1e-3, (where, r["rot"], r["trans"])
+        if r["frame"] <= 6:
+            assert r["counts"] == r["counts_ref"], where
+        if r["frame"] < 6:
+            assert r["rot"] <= POSE_TOL and r["trans"] <= POSE_TOL, (where, r["rot"], r["trans"])
 
 
 def test_fresh_qvga_sequences(hip, ora):

@@ -192,3 +192,21 @@ def test_bench_head_stamp_fallback(tmp_path, monkeypatch):
             os.remove(stamp)
         else:
             open(stamp, "w").write(had)
+
+
+def test_traffic_evidence_belongs_to_the_sources():
+    """bench.py prints `roofline.traffic` only when profiles/traffic_<workload>_b<batch>.json was measured on the running device
+    sources (their hash is in the file). After a change of those sources the files are stale until tools/refresh_evidence.sh has
+    run on a GPU box: that is reported here as a skip with the reason -- visible in every CPU run -- instead of going unnoticed until
+    the bench line carries null."""
+    import glob
+    import json
+
+    import bench
+
+    now = bench.source_sha()
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*_b*.json")))
+    assert files, "no PMC traffic evidence committed"
+    stale = [os.path.basename(f) for f in files if json.load(open(f)).get("src_sha") != now]
+    if stale:
+        pytest.skip("PMC traffic evidence is stale for the sources %s (%s): run tools/refresh_evidence.sh on a GPU box" % (now, ", ".join(stale)))

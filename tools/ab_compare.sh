@@ -13,7 +13,8 @@ C=$PWD/staticfusion_amd/csrc
 TMP=$(mktemp)
 for r in $(seq 1 $REPS); do
   for w in sphere static; do
-    for lib in $A $B; do
+    if [ $((r % 2)) -eq 1 ]; then order="$A $B"; else order="$B $A"; fi  # alternate who goes first: the second run of a pair is the warmer one
+    for lib in $order; do
       out=$(SF_HIP_LIB=$C/$lib timeout -k 10 300 python tools/stage_profile.py --batch $BATCH --workload $w --steps 10)
       fps=$(echo "$out" | grep workload | sed -E 's/.* ([0-9]+) frames\/s.*/\1/')
       extra=""
@@ -30,6 +31,8 @@ for l in open(sys.argv[1]):
     w, lib, fps = l.split(); rows[(w, lib)].append(float(fps))
 for w in ("sphere", "static"):
     a, b = rows[(w, sys.argv[2])], rows[(w, sys.argv[3])]
+    if sys.argv[2] == sys.argv[3]:  # A against A: the pairs of one repetition in running order (what the order alone does)
+        a, b = a[0::2], a[1::2]
     if a and b:
         print("%s: mean %.0f -> %.0f frames/s, B / A = %.4f (per repetition: %s)" % (w, sum(a) / len(a), sum(b) / len(b), (sum(b) / len(b)) / (sum(a) / len(a)),
               " ".join("%.4f" % (y / x) for x, y in zip(a, b))))

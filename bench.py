@@ -2,8 +2,12 @@
 """bench.py — throughput of the StaticFusion solver hot path on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-For N > 1 it is launched under torch.distributed.run, one rank per GPU (RANK / LOCAL_RANK /
-WORLD_SIZE / MASTER_* from the environment); rank 0 prints ONE JSON line.
+For N > 1 it runs one rank per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* from the environment); rank 0 prints ONE JSON line. Started DIRECTLY with --gpus N > 1
+(no WORLD_SIZE in the environment) it launches those N ranks itself -- it re-executes under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` -- or
+exits non-zero when the node has fewer than N GPUs; a line never claims more GPUs than ranks ran
+(world_size == n_gpus == len(per_rank), one distinct device per rank, asserted before printing).
 
 A "step" is ONE pass of the hot path over ONE batch of synthetic RGB-D pairs that is already
 resident in HBM: the reference drivers' per-frame sequence
@@ -185,6 +189,36 @@ def measured_traffic(workload, batch, variant):
             "variant": t.get("variant"), "ratio_to_algorithmic": None}, None
 
 
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch_if_needed(args):
+    """`python bench.py --gpus N` started directly (WORLD_SIZE unset) with N > 1: one process cannot be N ranks. Re-execute
+    under torch.distributed.run with N ranks on this node, or fail loudly when the node does not have N GPUs.
+    (SF_BENCH_SINGLE_GPU=1, the one-GPU test hook that puts every rank on cuda:0, lifts the device-count check.)"""
+    if "WORLD_SIZE" in os.environ or args.gpus <= 1:
+        return
+    import torch
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus and not os.environ.get("SF_BENCH_SINGLE_GPU"):
+        sys.stderr.write("bench.py: --gpus %d requested but this node exposes %d GPU(s); refusing to print a line for GPUs that did not run\n"
+                         % (args.gpus, have))
+        sys.exit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: launching %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 class Harness:
     """Device selection, process group and the barrier of the contract."""
 
@@ -195,8 +229,10 @@ class Harness:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        if self.world != args.gpus and self.world > 1:
-            args.gpus = self.world
+        if self.world != args.gpus:  # a line must never report GPUs that no rank ran on
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python -m torch.distributed.run "
+                             "--nproc-per-node %d ... bench.py --gpus %d), or run `python bench.py --gpus %d` directly and let it "
+                             "launch the ranks" % (args.gpus, self.world, args.gpus, args.gpus, args.gpus))
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
         # Test hooks (tests/test_gpu_parity_sweep.py runs the N > 1 flow on a one-GPU box): SF_BENCH_BACKEND=gloo does the
@@ -216,6 +252,15 @@ class Harness:
                 dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
             self.dist = dist
         self.reduce_device = torch.device("cuda", self.dev_index) if self.backend == "nccl" else torch.device("cpu")
+        # which physical device every rank sits on (gathered: the line carries it, and main() asserts they are distinct)
+        prop = torch.cuda.get_device_properties(self.dev_index)
+        mine = {"rank": self.rank, "device_index": int(torch.cuda.current_device()), "name": prop.name,
+                "uuid": str(getattr(prop, "uuid", "")), "pci_bus_id": int(getattr(prop, "pci_bus_id", -1)), "host": os.uname().nodename}
+        self.devices = [mine]
+        if self.dist is not None:
+            got = [None] * self.world
+            self.dist.all_gather_object(got, mine)
+            self.devices = got
 
     def barrier(self, solver):
         if self.dist is not None:
@@ -378,21 +423,47 @@ def isolated_passes(solver, B, n0, reps):
     return out
 
 
-def synthetic_sequence_pool(hx, args):
-    """The frames of D synthetic sequences per rank as two HBM-resident [D * F][n0] arrays (column-major images)."""
-    import multiprocessing as mp
-
+def _cached_sequence(seed, F, pool):
+    """One synthetic sequence as (d [F][n0], i [F][n0], T_gt) -- from /tmp when a run on this node has rendered it before (the
+    driver runs N = 1, 2, 4, 8 back to back: rank r's seeds at N recur at 2 N), else rendered and stored (atomic rename)."""
     from staticfusion_amd.synth import make_sequence
 
-    D, F = args.seq_distinct, args.seq_frames
-    with mp.get_context("spawn").Pool(min(len(os.sched_getaffinity(0)), 16)) as pool:
-        seqs = [make_sequence(1000 + hx.rank * D + q, F, sphere=True, pool=pool) for q in range(D)]
+    path = os.path.join(os.environ.get("SF_BENCH_CACHE", "/tmp"), "sf_bench_seq_v1_%d_%d_u%d.npz" % (seed, F, os.getuid()))
+    try:
+        with np.load(path) as z:
+            if z["d"].shape[0] == F:
+                return z["d"], z["i"], list(z["T_gt"])
+    except Exception:
+        pass
+    seq = make_sequence(seed, F, sphere=True, pool=pool)
     col = lambda a: np.ascontiguousarray(np.asarray(a, np.float32).T).ravel()
+    d, i = np.stack([col(f[0]) for f in seq["frames"]]), np.stack([col(f[1]) for f in seq["frames"]])
+    try:
+        tmp = "%s.%d.tmp.npz" % (path, os.getpid())
+        np.savez(tmp, d=d, i=i, T_gt=np.stack(seq["T_gt"]))
+        os.replace(tmp, path)
+    except Exception:
+        pass
+    return d, i, seq["T_gt"]
+
+
+def synthetic_sequence_pool(hx, args):
+    """The frames of D synthetic sequences per rank as two HBM-resident [D * F][n0] arrays (column-major images). The
+    renderer processes of all ranks of the node share the CPUs the container may use (8 ranks x 16 processes on a 16-CPU
+    quota only contend), and a sequence rendered once on this node is read back from /tmp."""
+    import multiprocessing as mp
+
+    D, F = args.seq_distinct, args.seq_frames
+    cap = cgroup_cpu_limit()
+    cpus = len(os.sched_getaffinity(0)) if cap is None else max(1, min(len(os.sched_getaffinity(0)), int(cap)))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(hx.world)))
+    with mp.get_context("spawn").Pool(max(1, min(16, cpus // max(1, local_world)))) as pool:
+        seqs = [_cached_sequence(1000 + hx.rank * D + q, F, pool) for q in range(D)]
     dev = "cuda:%d" % hx.dev_index
     return {
-        "d": hx.torch.from_numpy(np.stack([col(f[0]) for s in seqs for f in s["frames"]])).to(dev),
-        "i": hx.torch.from_numpy(np.stack([col(f[1]) for s in seqs for f in s["frames"]])).to(dev),
-        "D": D, "F": F, "T_gt": [s["T_gt"] for s in seqs], "rows": 240, "cols": 320, "workload": "sequences",
+        "d": hx.torch.from_numpy(np.concatenate([s[0] for s in seqs])).to(dev),
+        "i": hx.torch.from_numpy(np.concatenate([s[1] for s in seqs])).to(dev),
+        "D": D, "F": F, "T_gt": [s[2] for s in seqs], "rows": 240, "cols": 320, "workload": "sequences",
         "what": {"distinct_sequences_per_rank": D, "frames_per_sequence": F, "sequence_seeds": [1000 + hx.rank * D, 1000 + hx.rank * D + D - 1]},
     }
 
@@ -555,6 +626,7 @@ def main():
     args = parse()
     if args.launch_per_frame:
         os.environ["SF_TIMED_LAUNCH_PER_FRAME"] = "1"  # sf_timed_process_frames honours it (the pairs workloads)
+    self_launch_if_needed(args)  # `python bench.py --gpus N` directly: becomes N ranks under torch.distributed.run, or exits 2
     hx = Harness(args)
     want_parity = not args.no_cpu_baseline
     seq_blocks = []
@@ -576,6 +648,10 @@ def main():
         del pool
 
     if hx.rank == 0:
+        # the line reports exactly the ranks that ran: one per GPU asked for, each on its own device
+        assert hx.world == args.gpus == len(blk["per_rank"]) == len(hx.devices), (hx.world, args.gpus, len(blk["per_rank"]), len(hx.devices))
+        dev_keys = {(d["host"], d["uuid"] or d["pci_bus_id"], d["device_index"]) for d in hx.devices}
+        assert len(dev_keys) == hx.world or os.environ.get("SF_BENCH_SINGLE_GPU"), "two ranks share a GPU: %r" % (hx.devices,)
         out = {
             "metric": "solver iterations/s (IRLS loop bodies, reference FrontEnd.cpp:611-684) at QVGA",
             "value": blk["value"],
@@ -596,6 +672,7 @@ def main():
             "pixel_iterations_per_s": blk.get("pixel_iterations_per_s"),
             "pose_delta_vs_cpu": blk["parity"],
             "per_rank": blk["per_rank"],
+            "devices": hx.devices,
             "roofline": blk["roofline"],
             "build": {"head": git_head(), "src_sha": source_sha()},
         }

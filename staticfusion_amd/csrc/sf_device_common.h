@@ -145,6 +145,8 @@ struct KArgs {
     // after `sync_spin_limit` polls (0: SF_SYNC_SPIN_LIMIT)
     int debug_stall_rank;
     unsigned debug_stall_ticks, sync_spin_limit;
+    // reference-order build only (sf_reforder.h; null otherwise): per record slot, RO_LIST_K source-pixel indices per cell
+    int *ro_list;
 };
 
 // The two pyramid buffers of a stream: set 0 = new (depthCurrent and its levels), set 1 = Pred. When consecutive frames
@@ -735,3 +737,9 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
         __syncthreads();  // before the next tile clears the window
     }
 }
+
+// the reference-order build (-DSF_REFORDER=1 -> libsf_hip_reforder.so): a parity instrument, see the header
+#ifndef SF_REFORDER
+#define SF_REFORDER 0
+#endif
+#include "sf_reforder.h"

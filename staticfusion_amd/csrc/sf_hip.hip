@@ -23,6 +23,7 @@ extern "C" __attribute__((visibility("hidden"))) void sf_launch_debug_rows_ntclu
 extern "C" __attribute__((visibility("hidden"))) void sf_variant_geometry_ntcluster(int *, int *);
 extern "C" __attribute__((visibility("hidden"))) void sf_variant_geometry_nt256(int *, int *);
 extern "C" __attribute__((visibility("hidden"))) void sf_variant_geometry_nt1024(int *, int *);
+extern "C" __attribute__((visibility("hidden"))) int sf_variant_flags_nt256(void);
 static const FrameVariant VARIANTS[3] = {
     {SF_VARIANT_THROUGHPUT, "throughput", sf_variant_geometry_nt256, sf_launch_frame_nt256, sf_launch_irls_pass_nt256, sf_launch_debug_rows_nt256},
     {SF_VARIANT_LATENCY, "latency", sf_variant_geometry_nt1024, sf_launch_frame_nt1024, sf_launch_irls_pass_nt1024, sf_launch_debug_rows_nt1024},
@@ -189,7 +190,7 @@ void sf_default_params(sf_params *p) {  // reference StaticFusion-datasets.cpp:7
 }
 
 const char *sf_last_error(void) { return g_err.c_str(); }
-const char *sf_backend(void) { return "hip:gfx950"; }
+const char *sf_backend(void) { return (sf_variant_flags_nt256() & 1) ? "hip:gfx950:reference-order" : "hip:gfx950"; }
 
 static int validate_params(const sf_params *p, int levels) {
     // K-means clusters image level 1 (KMeans.cpp:145): a one-level pyramid is only meaningful without segmentation
@@ -320,6 +321,11 @@ int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, 
     } else {
         h->fv = &VARIANTS[variant == SF_VARIANT_THROUGHPUT ? 0 : (variant == SF_VARIANT_LATENCY ? 1 : 2)];
     }
+    h->reforder = (sf_variant_flags_nt256() & 1) != 0;
+    if (h->reforder && h->fv->id == SF_VARIANT_CLUSTER) {
+        sf_destroy(h);
+        return fail(SF_ERR_ARG, "the reference-order build (libsf_hip_reforder.so) runs one workgroup per stream: no SF_VARIANT_CLUSTER");
+    }
     int wg_threads = 0, wg_per_cu = 0;
     h->fv->geometry(&wg_threads, &wg_per_cu);
     h->max_blocks = prop.multiProcessorCount * wg_per_cu;
@@ -379,6 +385,7 @@ int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, 
     for (int q = 0; q < R_COUNT; q++) TRY_OR_FREE(dev_alloc(h, &k.rec[q], slots * N0));
     TRY_OR_FREE(dev_alloc(h, &k.rec_lab, slots * N0));
     TRY_OR_FREE(dev_alloc(h, &k.rec_null, slots * N0));
+    if (h->reforder) TRY_OR_FREE(dev_alloc(h, &k.ro_list, slots * N0 * RO_LIST_K));  // source indices per cell (sf_reforder.h)
     if (k.cluster_g) TRY_OR_FREE(dev_alloc(h, &k.sync, B * 2 * k.cluster_g * SF_SYNC_WORDS));
     TRY_OR_FREE(dev_alloc(h, &k.hist_d, (size_t)SF_HISTORY * B * N0));
     TRY_OR_FREE(dev_alloc(h, &k.hist_i, (size_t)SF_HISTORY * B * N0));

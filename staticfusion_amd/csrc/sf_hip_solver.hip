@@ -432,6 +432,9 @@ int sf_get_lin_plane(sf_handle *h, int stream, int which, float *out, int *rows,
     if (int e = d2h(h, dw.data(), h->k.rec[R_DW] + o, sizeof(float) * n)) return e;
     auto fetch = [&](int plane, std::vector<float> &v) { v.resize(n); return d2h(h, v.data(), h->k.rec[plane] + o, sizeof(float) * n); };
     std::vector<uint8_t> lab(n);  // validPixels: the sign of the stored warped depth (sf_solver.h, linearise)
+    if (h->reforder) {  // ... or, in the reference-order build, the label plane (the sign there is the warp's own)
+        if (int e = d2h(h, lab.data(), h->k.rec_lab + o, n)) return e;
+    } else
     for (size_t q = 0; q < n; q++) {
         lab[q] = (dw[q] > 0.f) ? 0 : SF_INVALID_LABEL;
         dw[q] = std::fabs(dw[q]);

@@ -39,6 +39,7 @@ struct sf_handle {
     int max_blocks_o5 = 0;  // throughput build: resident workgroups of the 5-per-CU kernel (0: not used)
     const FrameVariant *fv = nullptr;  // set by sf_create_ex
     std::vector<struct sf_map *> maps;  // live maps created from this handle: sf_destroy releases their memory and orphans them
+    bool reforder = false;  // the library's frame kernels are the reference-order build (sf_reforder.h)
     int cluster_grid = 0;  // SF_VARIANT_CLUSTER: blocks per launch (8 XCDs x streams per XCD x workgroups per stream)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;

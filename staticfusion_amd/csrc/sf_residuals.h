@@ -13,8 +13,15 @@ struct ResShared {
     long long lab_sum[SF_NC];
     int lab_cnt[SF_NC];
     double dwork[32];
-    SplatWin win;
-    SplatMarks marks;
+    union {
+        struct {
+            SplatWin win;
+            SplatMarks marks;
+        };
+#if SF_REFORDER
+        RoChunk ro;  // reference-order build: a chunk of the ordered per-cluster sums
+#endif
+    };
 };
 
 __device__ __forceinline__ int level0_label(const KArgs &a, gptr<const uint8_t> labels0, int idx) {
@@ -54,7 +61,11 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
         s.lab_sum[tid] = 0;
         s.lab_cnt[tid] = 0;
     }
+#if SF_REFORDER && SF_RO_SPLAT
+    const bool lazy = true;  // (ro_splat initialises every cell)
+#else
     const bool lazy = splat_lazy_ok(rows, cols, G);  // see solve_warp
+#endif
     if (!lazy)
     for (int idx = tid + rank * SF_NT; idx < n; idx += SF_NT * G) {  // agent-scope stores: see solve_warp
         if (G > 1) {
@@ -92,8 +103,71 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
             return z != 0.f && dc != 0.f;
         }
     } src{dbuf, ibuf, dcur, inv_f_i, g.disp_u_i, g.disp_v_i};
+#if SF_REFORDER && SF_RO_SPLAT
+    {
+        LevelCoord lc0 = level_coord(a, 0);
+        ro_splat(g, lc0, n, src, acc_d, acc_i, as_global(a.ro_list + rb * RO_LIST_K), tid);
+    }
+#else
     tiled_splat(g, rows, cols, src, acc_d, acc_i, s.win, s.marks, tid, rank, G, lazy, &st.prof[PF_SPLAT_REPLAYS]);
+#endif
     cluster_rendezvous(cs, tid);
+
+#if SF_REFORDER
+    // residuals, cluster-wise (:1036-1068), as the reference sums them: one float per cluster, pixels j outer / i inner
+    {
+        const float kph_ro = a.p.k_photometric_res;
+        RoLabelAcc la{0.f, 0, 0, 0};
+        for (int base = 0; base < n; base += RO_CHUNK) {
+            for (int q = tid; q < RO_CHUNK; q += SF_NT) {
+                const int idx = base + q;
+                int lab = SF_INVALID_LABEL;
+                float val = 0.f;
+                if (idx < n) {
+                    const long long sd = gld_agent_i64(acc_d, idx), si = gld_agent_i64(acc_i, idx);
+                    const float dc = gld(dcur, idx), db = gld(dbuf, idx), ic = gld(icur, idx);
+                    const int lb = level0_label(a, labels0, idx);
+                    if (push) {
+                        gst(dpush, idx, dc);
+                        gst(ipush, idx, ic);
+                    }
+                    if (si != 0 && dc != 0.f) {
+                        float dw, iw;
+#if SF_RO_SPLAT
+                        ro_unpack_cell(sd, dw, iw);
+#else
+                        normalise_acc(sd, si, dw, iw);
+#endif
+                        if (dw != 0.f && lb < SF_NC) {
+                            const float idiff = (db != 0.f) ? ic : 0.f;  // intensity_diff (:937,1022)
+                            val = fabsf(dc - dw) + kph_ro * fabsf(idiff - iw);
+                            lab = lb;
+#if !SF_RO_LABSUM
+                            lds_add(&s.lab_sum[lab], to_fix(val, FIX_RES, 1.0e6f));
+#endif
+                        }
+                    }
+                }
+                s.ro.val[q] = val;
+                s.ro.lab[q] = (uint8_t)lab;
+                s.ro.flag[q] = 1;
+            }
+            __syncthreads();
+            ro_label_walk(s.ro, min(RO_CHUNK, n - base), tid, la);
+            __syncthreads();
+        }
+        if (tid < SF_NC && commit_ok(cs)) {
+#if SF_RO_LABSUM
+            const float sum = la.sum;
+#else
+            const float sum = (float)((double)s.lab_sum[tid] * (1.0 / 4294967296.0));
+#endif
+            st.cluster_res[tid] = (la.n_val > 0) ? sum / float(2 * (la.n_val + 1)) : __int_as_float(0x7fc00000);
+        }
+        cluster_barrier(cs, tid);
+        return;
+    }
+#endif
 
     // residuals, cluster-wise (:1036-1068): per-lane running sums per label, flushed to the workgroup bins
     // (integer LDS atomics) when the label changes; SF_LOAD_BATCH pixels per trip with all loads issued first

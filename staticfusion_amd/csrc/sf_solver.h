@@ -23,7 +23,6 @@
 #include "sf_cluster.h"
 #include "sf_device_common.h"
 #include "sf_smallmath.h"
-
 #define TILE_V 64
 #define TILE_U (2 * SF_NT / TILE_V)  // two centre pixels per lane
 #define TILE_LV (TILE_V + 2)
@@ -71,6 +70,9 @@ struct SolveShared {
         SplatWin win;  // end of the solve) is used while neither is, and so are the fp64 sums of pass 1
         double dwork[36 * 3 + 32];
         double p1[27][P1_SETS];
+#if SF_REFORDER
+        RoChunk ro;    // reference-order build: a chunk of the ordered per-cluster sums
+#endif
     };
     // reductions
     double red[SF_NW][28];
@@ -238,7 +240,11 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
     if (tid == 0) inverse4_cm(s.T, s.Tinv, s.dwork);  // T = T_odometry.inverse()  (:800)
     // a cluster's workgroups zero every G-th block. Agent-scope (write-through) stores: the cells are only ever touched by
     // agent-scope atomics and atomic loads after this, so the two hand-overs below need no fence (sf_cluster.h)
+#if SF_REFORDER && SF_RO_SPLAT
+    const bool lazy = true;  // (nothing to zero: ro_splat below initialises every cell)
+#else
     const bool lazy = splat_lazy_ok(rows_i, cols_i, G);  // one workgroup: the splat zeroes the cells itself, window by window
+#endif
     if (!lazy)
     for (int idx = tid + rank * SF_NT; idx < n; idx += SF_NT * G) {
         if (G > 1) {
@@ -274,7 +280,11 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
             return z != 0.f;
         }
     } src{dpred, ipred, level_coord(a, L)};
+#if SF_REFORDER && SF_RO_SPLAT
+    ro_splat(g, level_coord(a, L), n, src, acc_d, acc_i, as_global(a.ro_list + rb * RO_LIST_K), tid);  // the reference's float sums, in its order
+#else
     tiled_splat(g, rows_i, cols_i, src, acc_d, acc_i, s.win, s.marks, tid, rank, G, lazy, &a.state[b].prof[PF_SPLAT_REPLAYS]);
+#endif
     cluster_rendezvous(cs, tid);  // all atomics of the workgroup(s) performed: the linearisation reads the cells with atomic loads
 }
 
@@ -370,7 +380,11 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                     dw = __uint_as_float((unsigned)((unsigned long long)pf_ad[q] & 0xffffffffu));
                     iw = __uint_as_float((unsigned)((unsigned long long)pf_ad[q] >> 32));
                 } else if (pf_ai[q] != 0) {  // normalise the warp accumulators (reference :876-881); touched <=> sum(w) > 0
+#if SF_REFORDER && SF_RO_SPLAT
+                    ro_unpack_cell(pf_ad[q], dw, iw);  // already divided, in the reference's order (ro_splat)
+#else
                     normalise_acc(pf_ad[q], pf_ai[q], dw, iw);
+#endif
                 }
             }
             const bool nul = !(inside && (dn != 0.f) && (dw != 0.f));
@@ -408,7 +422,11 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                 // image gives a negative warped depth, which the reference keeps in validPixels (:816-823 has no depth test);
                 // here such a pixel is left out everywhere (counts, sums, passes), because the sign of the stored warped
                 // depth is what marks membership for the passes. It needs a diverged pose to happen at all.
+#if SF_REFORDER && SF_RO_BEHIND
+                valid = !nul && (u != 0) && (v != 0) && (u != cols_i - 1) && (v != rows_i - 1);  // the reference's rule, :415-427
+#else
                 valid = !nul && (dw > 0.f) && (u != 0) && (v != 0) && (u != cols_i - 1) && (v != rows_i - 1);
+#endif
                 float dcu_ = 0.f, dcv_ = 0.f, ddu_ = 0.f, ddv_ = 0.f;
                 if (valid) {
                     const int eL = e - TILE_LV, eR = e + TILE_LV, eU = e - 1, eD = e + 1;  // (v,u-1) (v,u+1) (v-1,u) (v+1,u)
@@ -440,13 +458,17 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                 // (a point behind the camera that still projects into the image: a diverged pose) stays negative = not valid;
                 // the segmentation prior then sees its magnitude (solve_seg_prior), the one place where this differs from the
                 // reference, which carries such a pixel through with its sign
+#if SF_REFORDER && SF_RO_BEHIND
+                gst(rec[R_DW], idx, dw);  // validPixels rides in the label plane of this build, the sign is the warp's
+#else
                 gst(rec[R_DW], idx, valid ? dw : -fabsf(dw));
+#endif
                 gst(rec[R_DCU], idx, dcu_);
                 gst(rec[R_DCV], idx, dcv_);
                 gst(rec[R_DCT], idx, (valid || dbg) ? dct_ : 0.f);  // 0 outside validPixels: the passes run branch-free over every pixel
                 gst(rec[R_DDU], idx, ddu_);
                 gst(rec[R_DDV], idx, ddv_);
-                if (seg || dbg) gst(rec_lab, idx, valid ? (uint8_t)(seg ? lab : 0) : (uint8_t)SF_INVALID_LABEL);
+                if (seg || dbg || SF_REFORDER) gst(rec_lab, idx, valid ? (uint8_t)(seg ? lab : 0) : (uint8_t)SF_INVALID_LABEL);
                 if (dbg) {
                     float d_i = 0.f, x_i = 0.f, y_i = 0.f, xw = 0.f, yw = 0.f;
                     const LevelCoord lcd = level_coord(a, L);
@@ -679,11 +701,18 @@ __device__ __noinline__ void solve_filter_and_update(const KArgs &a, LDS SolveSh
         {
             const int l = (lane < 36) ? lane : 0, i = l / 6, j = l - 6 * i;
             double sa = (double)s.est_cov[(i >= j) ? i * 6 + j : j * 6 + i], vv;  // the lower triangle, mirrored
+#if SF_REFORDER && SF_RO_JACOBI
+            if (lane < 36) S[lane] = sa;
+            __builtin_amdgcn_wave_barrier();
+            jacobi_eig6_wave(S, V, lane);  // the cyclic order of the oracle ([C5]), element for element
+            (void)vv;
+#else
             jacobi6_lanes(sa, vv, lane);
             if (lane < 36) {
                 S[lane] = sa;  // the diagonal holds the eigenvalues
                 V[lane] = vv;
             }
+#endif
         }
         __builtin_amdgcn_wave_barrier();
         FILTER_MARK(22);
@@ -1196,6 +1225,8 @@ __device__ __noinline__ void irls_pass2(const KArgs &a, int b, int L, LDS SolveS
     if (lane == 0) s.red[wave][27] = sq;
 }
 
+#include "sf_reforder_solver.h"  // (empty unless SF_REFORDER)
+
 // wave 0: build and factorise A_seg^T A_seg once per outer iteration
 // (reference SegmentationBackground.cpp:105-130,143-165)
 __device__ __noinline__ void irls_seg_factor(const KArgs &a, LDS SolveShared &s, int lane) {
@@ -1224,7 +1255,9 @@ __device__ __noinline__ void irls_seg_factor(const KArgs &a, LDS SolveShared &s,
 // wave 0, after pass 2: averages, solveSegmIteration, convergence test (reference :666-683)
 __device__ __noinline__ void irls_iteration_tail(const KArgs &a, LDS SolveShared &s, int N, int k, int lane) {
     const bool seg = a.p.segmentation_enabled != 0;
+#if !(SF_REFORDER && SF_RO_LABSUM)  // (the reference-order build's pass 2 leaves the sequential float sums there itself)
     if (lane < SF_NC) s.aver_res_label[lane] = (float)((double)s.lab_sum[lane] * (1.0 / 4294967296.0));
+#endif
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
         double t = 0.0;
@@ -1320,10 +1353,14 @@ __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level,
 
     // initial aver_res = mean |res| with res = -B (reference :588-590). B = (pre-weight / max) * derivative:
     // the sums of raw pre-weight x |dct|, |ddt| come from the linearisation, so no extra pass over the records
+#if SF_REFORDER && SF_RO_INIT_RES
+    ro_initial_residual(a, b, L, s, tid);  // from the rows' B, as the reference does
+#else
     if (tid == 0) {
         const double t = (double)(s.inv_max_c * a.p.k_photometric_res) * s.init_abs_c + (double)s.inv_max_d * s.init_abs_d;
         s.aver_res = (float)t / float(2 * N);
     }
+#endif
     if (seg && wave == 0) irls_seg_factor(a, s, lane);
     __syncthreads();
     PROF_MARK(s, tid, PF_IRLS_INIT);
@@ -1331,14 +1368,22 @@ __device__ __noinline__ void solve_irls(const KArgs &a, int b, int L, int level,
     int iters_done = 0;
     for (int k = 1; k <= a.p.max_iter_irls; k++) {
         iters_done = k;
+#if SF_REFORDER
+        ro_pass1(a, b, L, s, tid);
+#else
         irls_pass1<0>(a, b, L, s, tid);
+#endif
         __syncthreads();
         irls_reduce_normal(s, cs, tid);
         PROF_MARK(s, tid, PF_PASS1);
         if (wave == 0) irls_solve_normal(s, lane);
         __syncthreads();
         PROF_MARK(s, tid, PF_SOLVE6);
+#if SF_REFORDER
+        ro_pass2(a, b, L, s, tid);
+#else
         irls_pass2<0>(a, b, L, s, tid);
+#endif
         __syncthreads();
         irls_reduce_residuals(s, cs, tid);
         PROF_MARK(s, tid, PF_PASS2);
@@ -1418,14 +1463,23 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, LDS SolveShared 
             if (!first) solve_warp(a, b, L, s, cs, tid);
             PROF_MARK(s, tid, PF_WARP);
             solve_linearise(a, b, L, first, s, cs, tid);
+#if SF_REFORDER
+            if (a.p.segmentation_enabled) ro_seg_prior(a, b, L, s, cs, tid);
+#else
             if (a.p.segmentation_enabled) solve_seg_prior(a, b, L, s, cs, tid);
+#endif
             PROF_MARK(s, tid, PF_LINEARISE);
             solve_irls(a, b, L, i, k, s, cs, tid);
             if (tid == 0) {
                 s.n_outer++;
                 double s2 = 0.0;
+#if SF_REFORDER  // the oracle's reading of twist_level_odometry.norm(): fp64 sum of the FLOAT squares
+                for (int c = 0; c < 6; c++) s2 += (double)(s.twist_level[c] * s.twist_level[c]);
+                const float nrm = (float)sqrt((double)(float)s2);
+#else
                 for (int c = 0; c < 6; c++) s2 += (double)s.twist_level[c] * (double)s.twist_level[c];
                 const float nrm = sqrtf((float)s2);
+#endif
                 s.ctrl = (nrm < 0.04f) ? 1 : 0;  // reference :1130
             }
             __syncthreads();
@@ -1523,7 +1577,12 @@ __device__ __forceinline__ void debug_rows(const KArgs &a, int b, float *out, in
     const float *dnew = pyr_plane(a, b, 0, 0) + a.loff[L];
     for (int idx = gtid; idx < n; idx += gstride) {
         const float dw = a.rec[R_DW][rb + idx];
-        if (!(dw > 0.f)) {
+#if SF_REFORDER && SF_RO_BEHIND
+        const bool in_valid = a.rec_lab[rb + idx] != SF_INVALID_LABEL;  // (this build's records keep the warp's own sign)
+#else
+        const bool in_valid = dw > 0.f;
+#endif
+        if (!in_valid) {
             out[idx] = __int_as_float(0x7fc00000);
             continue;
         }

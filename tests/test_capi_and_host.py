@@ -210,3 +210,19 @@ def test_traffic_evidence_belongs_to_the_sources():
     stale = [os.path.basename(f) for f in files if json.load(open(f)).get("src_sha") != now]
     if stale:
         pytest.skip("PMC traffic evidence is stale for the sources %s (%s): run tools/refresh_evidence.sh on a GPU box" % (now, ", ".join(stale)))
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus 8` started directly must never print a line that claims 8 GPUs from one process: without 8
+    devices it exits non-zero before anything runs (this container has none); with WORLD_SIZE set, a rank count that
+    contradicts --gpus is refused (needs a GPU to get that far: tests/test_gpu_parity_sweep.py)."""
+    import sys
+
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        pytest.skip("this node really has 8 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SF_BENCH_SINGLE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 2 and b"refusing" in r.stderr and not r.stdout.strip()

@@ -250,6 +250,7 @@ def test_bench_two_rank_flow_on_one_gpu(tmp_path):
     fs = d["full_solver"]  # BASELINE configs[2] timed in the same run
     assert fs["value"] > 0 and fs["roofline"]["frac"] > 0 and fs["pose_delta_vs_cpu"]["cluster_labels_identical"]
     assert fs["pose_delta_vs_cpu"]["rot_rad"] < 1e-4 and d["pose_delta_vs_cpu"]["rot_rad"] < 1e-4
+    assert len(d["devices"]) == 2 and [x["rank"] for x in d["devices"]] == [0, 1]
     # the sequences workload through the same two-rank flow
     out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                                    "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "sequences", "--batch", "32",
@@ -261,3 +262,39 @@ def test_bench_two_rank_flow_on_one_gpu(tmp_path):
     assert d["world_size"] == 2 and d["config"]["distinct_sequences_per_rank"] == 2 and d["value"] > 0
     assert abs(d["frames_per_s"] * d["ms_per_step"] * 1e-3 - 2 * 32) < 1e-6 * 64
     assert d["pose_delta_vs_cpu"]["tracking_error_vs_ground_truth"]["trans_m_max"] < 0.02
+
+
+def test_bench_gpus_n_started_directly(tmp_path):
+    """`python bench.py --gpus N` WITHOUT torch.distributed.run around it (what a driver that runs the N = 1 command as plain
+    `python bench.py --gpus 1` will most likely do for N = 8 too): --gpus 2 launches its two ranks itself (both on cuda:0 through
+    the one-GPU test hook) and the line says world_size 2 with two per-rank entries; --gpus 8 on this one-GPU box exits non-zero
+    instead of printing a line with "n_gpus": 8 from one process; a rank count that contradicts --gpus is refused as well."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(SF_BENCH_BACKEND="gloo", SF_BENCH_SINGLE_GPU="1", SF_BENCH_CACHE=str(tmp_path))
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "sequences", "--batch", "32", "--steps", "3",
+                                   "--warmup", "1", "--seq-distinct", "2", "--seq-frames", "16"], env=env, cwd=ROOT, stderr=subprocess.STDOUT,
+                                  timeout=900).decode()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and len(d["per_rank"]) == 2 and len(d["devices"]) == 2
+    assert abs(d["frames_per_s"] * d["ms_per_step"] * 1e-3 - 2 * 32) < 1e-6 * 64
+    assert len(list(tmp_path.glob("sf_bench_seq_v1_*.npz"))) == 4  # two ranks x two sequences, rendered once and cached
+
+    import torch
+
+    if torch.cuda.device_count() < 8:
+        env8 = {k: v for k, v in env.items() if k != "SF_BENCH_SINGLE_GPU"}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env8, cwd=ROOT,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode != 0 and not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+        assert "refusing" in r.stderr.decode()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0 and b"WORLD_SIZE=2" in r.stderr and not r.stdout.strip()

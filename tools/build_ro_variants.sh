@@ -1,0 +1,22 @@
+#!/bin/bash
+# The attribution builds of profiles/PARITY.md (round 4): the reference-order build (sf_reforder.h) with ONE of the product's
+# arithmetic shortcuts switched back on each -> staticfusion_amd/csrc/libsf_hip_ro_<name>.so (git-ignored; they travel to the
+# GPU box with the snapshot). tools/diag/attribution_hunt.py runs them side by side on the same seeds.
+set -e
+cd "$(dirname "$0")/../staticfusion_amd/csrc"
+build() {  # name, make variables...
+    local name=$1; shift
+    make -j8 RO_TAG=ro_$name "$@" libsf_hip_ro_$name.so > /dev/null
+    echo "built libsf_hip_ro_$name.so ($*)"
+}
+build splat_int        RO_FLAGS="-DSF_RO_SPLAT=0"
+build splat_int_fastdiv RO_FLAGS="-DSF_RO_SPLAT=0" RO_FAST_NORMALISE=1
+build rows_fact        RO_FLAGS="-DSF_RO_ROWS=0"
+build rows_fact_fma    RO_FLAGS="-DSF_RO_ROWS=0" RO_ROWS_FMA=1
+build fast_weights     RO_FAST_WEIGHTS=1
+build p1_fp32          RO_FLAGS="-DSF_RO_P1_FP64=0"
+build labsum_int       RO_FLAGS="-DSF_RO_LABSUM=0"
+build jacobi_rr        RO_FLAGS="-DSF_RO_JACOBI=0"
+build init_res         RO_FLAGS="-DSF_RO_INIT_RES=0"
+build behind           RO_FLAGS="-DSF_RO_BEHIND=0"
+build all_shortcuts    RO_FLAGS="-DSF_RO_SPLAT=0 -DSF_RO_ROWS=0 -DSF_RO_P1_FP64=0 -DSF_RO_LABSUM=0 -DSF_RO_JACOBI=0 -DSF_RO_INIT_RES=0 -DSF_RO_BEHIND=0" RO_FAST_WEIGHTS=1 RO_ROWS_FMA=1 RO_FAST_NORMALISE=1

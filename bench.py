@@ -103,24 +103,43 @@ def make_params(api, workload):
     return p
 
 
-def algorithmic_bytes(stats_list, levels_n, n_l1, seg, with_residuals):
-    """SURVEY.md §8(d) per-unit figures x the units one launch processed."""
+# bytes per unit: SURVEY.md §8(d)'s algorithmic figures, and what the kernels of this design really move per unit (DESIGN.md §5,
+# right-hand column; measured per stage group in profiles/*traffic_by_stage*): the IRLS passes stream 2 x 29 B records, the
+# linearisation reads ~29 B and writes 25 B instead of materialising A | B, ...
+ALGORITHMIC_B = {"irls": 60, "linearise": 88, "warp": 32, "pyramid": 48, "kmeans": 20, "segm_image": 8, "residuals": 32}
+MOVED_B = {"irls": 58, "linearise": 54, "warp": 25, "pyramid": 40, "kmeans": 6, "segm_image": 5, "residuals": 72}
+
+
+def algorithmic_bytes(stats_list, levels_n, n_l1, seg, with_residuals, pyramids_per_frame=2.0, per_unit=ALGORITHMIC_B):
+    """Per-unit figures x the units one launch processed. pyramids_per_frame: createImagePyramid calls that
+    really ran per frame of a stream -- 2 (old + new image) unless a launch of sequence frames swapped the pyramid buffers
+    instead of rebuilding the old image's pyramid (sequence_pyramids_per_frame)."""
     total = {"irls": 0, "linearise": 0, "warp": 0, "pyramid": 0, "kmeans": 0, "segm_image": 0, "residuals": 0}
     n_levels = len(levels_n)
     for st in stats_list:
-        total["irls"] += 60 * int(st.pixel_iters)
+        total["irls"] += per_unit["irls"] * int(st.pixel_iters)
         for i in range(st.n_outer):
             L = n_levels - 1 - st.outer[i].level  # image level
-            total["linearise"] += 88 * levels_n[L]
+            total["linearise"] += per_unit["linearise"] * levels_n[L]
             if not (st.outer[i].level == 0 and st.outer[i].k == 0):
-                total["warp"] += 32 * levels_n[L]
-        total["pyramid"] += 2 * 48 * sum(levels_n[1:])
+                total["warp"] += per_unit["warp"] * levels_n[L]
+        total["pyramid"] += pyramids_per_frame * per_unit["pyramid"] * sum(levels_n[1:])
         if seg:
-            total["kmeans"] += 20 * n_l1 * int(st.kmeans_iters)
-        total["segm_image"] += 8 * levels_n[0]
+            total["kmeans"] += per_unit["kmeans"] * n_l1 * int(st.kmeans_iters)
+        total["segm_image"] += per_unit["segm_image"] * levels_n[0]
         if with_residuals:
-            total["residuals"] += 32 * levels_n[0]
+            total["residuals"] += per_unit["residuals"] * levels_n[0]
     return total
+
+
+def sequence_pyramids_per_frame(frames_per_launch):
+    """createImagePyramid calls per frame of a stream in ONE launch of K sequence frames (sf_frame_kernels.hip, `swap`): frame 0
+    builds both pyramids; frames 1 .. K - 2 swap the two pyramid buffers of the stream (the old image's pyramid IS the
+    previous frame's new one) and build one; the last frame swaps only if that returns the buffers to the host's layout
+    (K - 2 odd). Returns (pyramids per frame, frames that swapped)."""
+    K = int(frames_per_launch)
+    swapped = 0 if K < 2 else (K - 2) + ((K - 2) % 2)
+    return (2.0 * K - swapped) / K, swapped
 
 
 def reduce_over_ranks(dist, device, elapsed, iters, frames):
@@ -173,7 +192,7 @@ def git_head():
         return None
 
 
-def measured_traffic(workload, batch, variant):
+def measured_traffic(workload, batch, variant, frames_per_launch=None):
     """HBM bytes per launch from the PMC counters (tools/measure_traffic.sh writes profiles/traffic_*.json together with the
     identity of the sources it measured). A file that belongs to other sources, another batch or another build of the
     kernel is NOT reported: null plus the reason."""
@@ -185,8 +204,12 @@ def measured_traffic(workload, batch, variant):
     now = source_sha()
     if t.get("src_sha") != now or t.get("batch") != batch or t.get("variant", variant) != variant:
         return None, "stale: measured on sources %s (batch %s, %s), running %s" % (t.get("src_sha"), t.get("batch"), t.get("variant"), now)
+    if frames_per_launch is not None and t.get("frames_per_launch", 1) != frames_per_launch:
+        # a launch of K sequence frames skips pyramids and copies a launch per frame does not: only like is compared with like
+        return None, "measured with %d frame(s) per launch, this run has %d (tools/measure_traffic.sh %s %d %s %d)" % (
+            t.get("frames_per_launch", 1), frames_per_launch, workload, batch, variant, frames_per_launch)
     return {"hbm_bytes_per_launch": t["hbm_bytes_per_launch"], "src_sha": t["src_sha"], "head": t.get("head"), "batch": t["batch"],
-            "variant": t.get("variant"), "ratio_to_algorithmic": None}, None
+            "variant": t.get("variant"), "frames_per_launch": t.get("frames_per_launch", 1), "per": t.get("per"), "ratio_to_algorithmic": None}, None
 
 
 def _free_port():
@@ -360,6 +383,7 @@ def run_pairs_workload(hx, args, workload, batch, with_parity):
     per_rank = gather_per_rank(hx.dist, hx.reduce_device, elapsed, iters_total, B * args.steps)
     seg = bool(params.segmentation_enabled)
     per_stream = algorithmic_bytes(stats_last, levels_n, levels_n[1], seg, True)
+    moved_per_stream = algorithmic_bytes(stats_last, levels_n, levels_n[1], seg, True, per_unit=MOVED_B)
     alg_bytes_launch = sum(per_stream.values()) * B / float(len(stats_last))
     achieved = alg_bytes_launch / (k_ms * 1e-3) / 1e9
     traffic, why = measured_traffic(workload, B, variant[0])
@@ -399,6 +423,10 @@ def run_pairs_workload(hx, args, workload, batch, with_parity):
             "kernel_launch_ms": k_ms * (1 if os.environ.get("SF_TIMED_LAUNCH_PER_FRAME") else args.steps),
             "algorithmic_bytes_per_step": alg_bytes_launch,
             "algorithmic_bytes_breakdown_per_stream": {k: v / float(len(stats_last)) for k, v in per_stream.items()},
+            # what the kernels of this design move for the same units (records instead of A | B, 16-byte
+            # accumulator cells out and back, ...); the PMC total above is the measurement these design figures add up to
+            "moved_bytes_breakdown_per_stream": {k: v / float(len(stats_last)) for k, v in moved_per_stream.items()},
+            "bytes_per_unit": {"algorithmic": ALGORITHMIC_B, "moved": MOVED_B},
             "kernel_ms_avg": k_ms,
             # the north star's "residual / Jacobian kernel" on its own: the two streaming passes of one IRLS iteration
             # launched alone (sf_irls_pass_kernel) over the level-0 records of every stream of THIS handle
@@ -577,11 +605,19 @@ def run_sequences_workload(hx, args, B, pool):
 
     t_max, iters_all, frames_all = reduce_over_ranks(hx.dist, hx.reduce_device, elapsed, iters_total, B * args.steps)
     per_rank = gather_per_rank(hx.dist, hx.reduce_device, elapsed, iters_total, B * args.steps)
-    per_stream = algorithmic_bytes(stats_last, levels_n, levels_n[1], True, True)
+    # the timed launch of K sequence frames builds FEWER pyramids than the single-frame launches the unit counts come from:
+    # count what ran (round 3 counted two per frame: 3.8 % too many bytes)
+    pyr_per_frame, swapped = (2.0, 0) if args.launch_per_frame else sequence_pyramids_per_frame(args.steps)
+    per_stream = algorithmic_bytes(stats_last, levels_n, levels_n[1], True, True, pyramids_per_frame=pyr_per_frame)
+    moved_per_stream = algorithmic_bytes(stats_last, levels_n, levels_n[1], True, True, pyramids_per_frame=pyr_per_frame, per_unit=MOVED_B)
     alg_bytes_launch = sum(per_stream.values()) * B / float(len(stats_last))
     kms = float(np.mean(k_ms))
     achieved = alg_bytes_launch / (kms * 1e-3) / 1e9
-    traffic, why = measured_traffic(pool["workload"], B, variant[0])
+    # the in-launch advance (prediction := current, current := pool frame): 8 B read + 8 B written per pixel for a frame that
+    # swapped its pyramid buffers, twice that for one that copied the prediction too. Its own line: no SURVEY figure covers it
+    # and it is NOT part of `achieved`.
+    advance_copy = 0.0 if args.launch_per_frame else n0 * (16.0 * swapped + 32.0 * (args.steps - swapped)) / args.steps
+    traffic, why = measured_traffic(pool["workload"], B, variant[0], frames_per_launch=1 if args.launch_per_frame else args.steps)
     if traffic:
         traffic["ratio_to_algorithmic"] = traffic["hbm_bytes_per_launch"] / alg_bytes_launch
     cfg = {"workload": WORKLOAD_TEXT[pool["workload"]], "streams_per_gpu": B}
@@ -616,6 +652,10 @@ def run_sequences_workload(hx, args, B, pool):
             "kernel_launch_ms": kms * (1 if args.launch_per_frame else args.steps),
             "algorithmic_bytes_per_step": alg_bytes_launch,
             "algorithmic_bytes_breakdown_per_stream": {k: v / float(len(stats_last)) for k, v in per_stream.items()},
+            "moved_bytes_breakdown_per_stream": {k: v / float(len(stats_last)) for k, v in moved_per_stream.items()},
+            "bytes_per_unit": {"algorithmic": ALGORITHMIC_B, "moved": MOVED_B},
+            "pyramids_built_per_frame": pyr_per_frame, "frames_that_swapped_pyramid_buffers": swapped,
+            "advance_copy_bytes_per_stream_frame": advance_copy,  # in the launch and in `traffic`, not in `achieved`
             "kernel_ms_avg": kms,
         },
         "pairs": None,

@@ -85,6 +85,11 @@ class StaticFusionCompat {
     explicit StaticFusionCompat(unsigned int res_factor = 2, int device = 0) {
         rows = height = 480 / res_factor;
         cols = width = 640 / res_factor;
+        {   // the library this binary is linked against must have been built from this header (sf_abi_version, sf.h)
+            int sp = 0, ss = 0, slots = 0;
+            if (sf_abi_version(&sp, &ss, &slots) != SF_ABI_VERSION || sp != int(sizeof(sf_params)) || ss != int(sizeof(sf_frame_stats)))
+                throw std::runtime_error("libsf_hip.so was built from another version of include/sf.h");
+        }
         sf_params p;
         sf_ctor_params(&p);
         check(sf_create(&p, int(rows), int(cols), 1, device, &h_), "sf_create");

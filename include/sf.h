@@ -202,7 +202,10 @@ int SF_FN(advance_sequences_device)(sf_handle *h, const void *pool_depth, const 
  * T_out: NULL, or host memory for n_frames * batch * 16 floats that receives T_odometry (column-major) of every stream
  * after every frame, [frame][stream][16]; with T_out the call returns when the launch has finished, without it the call
  * is asynchronous like sf_process_frame. The getters report the state after the last frame. SF_VARIANT_CLUSTER handles
- * run the frames one launch at a time (their workgroups meet inside a frame). */
+ * run the frames one launch at a time (their workgroups meet inside a frame). 1 <= n_frames <= 4096 (SF_ERR_ARG otherwise).
+ * Device memory beyond the handle's own: 64 * batch * n_frames bytes for the trajectory when T_out is given, nothing else
+ * (the sequence form below adds 4 * batch * n_frames bytes for the index table, on the device and in pinned host memory,
+ * and waits for the previous call's copy of that table before it overwrites the staging block). */
 int SF_FN(process_frames)(sf_handle *h, int im_count0, int n_frames, float *T_out);
 /* The same for sequences resident in HBM: frame k of stream b is preceded by that stream's step of
  * sf_advance_sequences_device (prediction := current, current := pool frame frame_index[k * batch + b]; a negative entry
@@ -457,10 +460,19 @@ int SF_FN(microbench_pass)(sf_handle *h, int which, int variant, int reps, float
  * the sticky flag are reset after the handle's stream has drained; the solver state is left as it is. A no-op for the
  * other builds (no rendezvous). */
 int SF_FN(clear_sync_timeout)(sf_handle *h);
-/* Test support (SF_VARIANT_CLUSTER): from the next launch on, the workgroup of rank `rank` of every stream idles stall_ms
- * before its first stage -- a late workgroup, as a co-running kernel causes -- and every rendezvous gives up after
- * spin_limit polls (0 = the product's bound). rank < 0 switches it off. */
+#ifdef SF_TESTING
+/* Test support, declared only with -DSF_TESTING (SF_VARIANT_CLUSTER): from the next launch on, the workgroup of rank `rank` of
+ * every stream idles stall_ms before its first stage -- a late workgroup, as a co-running kernel causes -- and every
+ * rendezvous gives up after spin_limit polls (0 = the product's bound). rank < 0 switches it off. */
 int SF_FN(debug_stall_rank)(sf_handle *h, int rank, float stall_ms, unsigned spin_limit);
+#endif
+/* The version of this header the LIBRARY was built from, and the sizes it assumes for what callers hand over: a binary built
+ * against another header finds out before it passes a buffer that is too small (sf_get_stage_profile wrote 24 slots before
+ * version 3 and writes 32 since; sf_outer_trace grew by delta_sol_max in version 3; sf_advance_sequences_device gained an
+ * argument). Returns SF_ABI_VERSION; any pointer may be NULL. A caller checks
+ *     sf_abi_version(&a, &b, &c) == SF_ABI_VERSION && a == sizeof(sf_params) && b == sizeof(sf_frame_stats) && c == 32. */
+#define SF_ABI_VERSION 4
+int SF_FN(abi_version)(int *sizeof_params, int *sizeof_frame_stats, int *stage_profile_slots);
 /* Elapsed ms of the most recent solver kernel launch (HIP events around that launch; a launch of sf_process_frames
  * covers all its frames). */
 int SF_FN(last_solver_kernel_ms)(sf_handle *h, float *ms);

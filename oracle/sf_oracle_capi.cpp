@@ -102,6 +102,12 @@ void sfo_default_params(sf_params *p) {  // StaticFusion-datasets.cpp:79-94
 
 const char *sfo_last_error(void) { return g_err.c_str(); }
 const char *sfo_backend(void) { return "cpu-oracle"; }
+int sfo_abi_version(int *sizeof_params, int *sizeof_frame_stats, int *stage_profile_slots) {
+    if (sizeof_params) *sizeof_params = (int)sizeof(sf_params);
+    if (sizeof_frame_stats) *sizeof_frame_stats = (int)sizeof(sf_frame_stats);
+    if (stage_profile_slots) *stage_profile_slots = 32;
+    return SF_ABI_VERSION;
+}
 
 int sfo_create(const sf_params *p, int rows, int cols, int batch, int device, sf_handle **out) {
     (void)device;

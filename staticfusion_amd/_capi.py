@@ -176,6 +176,7 @@ SIGNATURES = {
     "last_solver_kernel_ms": (C.c_int, [_H, _fp]),
     "clear_sync_timeout": (C.c_int, [_H]),
     "debug_stall_rank": (C.c_int, [_H, C.c_int, C.c_float, C.c_uint]),
+    "abi_version": (C.c_int, [_ip, _ip, _ip]),
 }
 
 

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__
     __shared__ FrameShared sh;
     __shared__ ClusterShared cs;
     __shared__ int s_next;
+    __shared__ int s_skip;
     const KArgs &a = *ka;
     const int tid = threadIdx.x;
     const int total = a.batch * fl.n_frames;
@@ -162,16 +163,26 @@ __global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__
                 // agent-scope acquire (this CU's L1 may hold lines of the stream from two frames ago)
                 if (tid == 0) {
                     unsigned spins = 0;
-                    while (__hip_atomic_load(fl.frame_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) {
-                        if (++spins > fl.spin_limit) {  // cannot happen (see above); never hang the device on a bug
+                    int done, skip = 0;
+                    while ((done = __hip_atomic_load(fl.frame_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < k) {
+                        // cannot happen (see above); never hang the device on a bug -- and never run a frame on a stream whose
+                        // previous frame may still be writing: the rest of the stream's frames of this launch are skipped (the
+                        // counter goes negative, so later frames see it at once) and every one of them reports the status
+                        if (done < 0 || ++spins > fl.spin_limit) {
+                            __hip_atomic_store(fl.frame_done + b, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             a.stats[b].status |= SF_STATUS_SYNC_TIMEOUT;
+                            skip = 1;
                             break;
                         }
                         __builtin_amdgcn_s_sleep(8);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    s_skip = skip;
                 }
                 __syncthreads();
+                const int skip_frame = __builtin_amdgcn_readfirstlane(s_skip);
+                __syncthreads();
+                if (skip_frame) continue;  // (the loop body ends with a barrier on this path too: the two above)
             }
             if (fl.seq_index) {
                 const int f = __builtin_amdgcn_readfirstlane(fl.seq_index[(size_t)k * a.batch + b]);
@@ -210,7 +221,8 @@ __global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(fl.frame_done + b, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_load(fl.frame_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0)  // (< 0: a later frame gave up on this stream)
+                    __hip_atomic_store(fl.frame_done + b, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         // NOTE: the loop body must END with a barrier. With a lane-0-only block here the compiler

@@ -190,6 +190,12 @@ void sf_default_params(sf_params *p) {  // reference StaticFusion-datasets.cpp:7
 }
 
 const char *sf_last_error(void) { return g_err.c_str(); }
+int sf_abi_version(int *sizeof_params, int *sizeof_frame_stats, int *stage_profile_slots) {
+    if (sizeof_params) *sizeof_params = (int)sizeof(sf_params);
+    if (sizeof_frame_stats) *sizeof_frame_stats = (int)sizeof(sf_frame_stats);
+    if (stage_profile_slots) *stage_profile_slots = SF_PROF_SLOTS;
+    return SF_ABI_VERSION;
+}
 const char *sf_backend(void) { return (sf_variant_flags_nt256() & 1) ? "hip:gfx950:reference-order" : "hip:gfx950"; }
 
 static int validate_params(const sf_params *p, int levels) {

@@ -197,18 +197,25 @@ static int multi_buffers(sf_handle *h, int n_frames, bool want_index, bool want_
     const size_t B = (size_t)h->k.batch;
     if (!h->d_frame_done)
         if (int e = dev_alloc(h, &h->d_frame_done, B)) return e;
-    if (n_frames > h->multi_capacity) {  // grow: the old buffers may still be in use by a queued launch
+    // Each buffer only when this call needs it, each with its own capacity (at 16 384 streams and 4096 frames the three
+    // together would be 4.3 GB of HBM + 268 MB of pinned memory; sf_process_frames without T_out needs none of them).
+    // Growing: the old block may still be in use by a queued launch.
+    if (want_index && n_frames > h->multi_capacity) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (h->d_multi_index) (void)hipFree(h->d_multi_index);
         if (h->h_multi_index) (void)hipHostFree(h->h_multi_index);
-        if (h->d_traj) (void)hipFree(h->d_traj);
-        h->d_multi_index = nullptr; h->h_multi_index = nullptr; h->d_traj = nullptr; h->multi_capacity = 0;
+        h->d_multi_index = nullptr; h->h_multi_index = nullptr; h->multi_capacity = 0;
         HIP_TRY(hipMalloc((void **)&h->d_multi_index, sizeof(int) * B * n_frames));
         HIP_TRY(hipHostMalloc((void **)&h->h_multi_index, sizeof(int) * B * n_frames, hipHostMallocDefault));
-        HIP_TRY(hipMalloc((void **)&h->d_traj, sizeof(float) * 16 * B * n_frames));
         h->multi_capacity = n_frames;
     }
-    (void)want_index; (void)want_traj;
+    if (want_traj && n_frames > h->traj_capacity) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->d_traj) (void)hipFree(h->d_traj);
+        h->d_traj = nullptr; h->traj_capacity = 0;
+        HIP_TRY(hipMalloc((void **)&h->d_traj, sizeof(float) * 16 * B * n_frames));
+        h->traj_capacity = n_frames;
+    }
     return SF_OK;
 }
 static int process_frames(sf_handle *h, const void *pool_depth, const void *pool_intensity, const int32_t *frame_index, int pool_frames,

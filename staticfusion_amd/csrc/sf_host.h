@@ -91,7 +91,8 @@ struct sf_handle {
     int *d_multi_index = nullptr;    // [capacity frames][batch]
     int *h_multi_index = nullptr;    // pinned staging of the same size
     float *d_traj = nullptr;         // [capacity frames][batch][16]
-    int multi_capacity = 0;          // frames the three buffers hold
+    int multi_capacity = 0;          // frames the two index buffers hold
+    int traj_capacity = 0;           // frames d_traj holds
     int solver_timed_frames = 1;     // frames of the launch evk0 / evk1 bracket
 };
 

@@ -19,7 +19,7 @@ __device__ __forceinline__ float conv_mask(int k) {
 // two pyramids level by level together, one barrier per level for both (what a cluster pays a rendezvous for)
 __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, int which, int tid, LDS ClusterShared &cs) {
     const int G = cl_G(cs), rank = cl_rank(cs);  // a cluster's workgroups take every G-th block of SF_NT pixels of a level
-    const float max_depth_dif = 0.1f;
+    const float gap_max = 0.1f;
 
     for (int L = 0; L < a.levels; L++) {
         const int rows_i = a.lrows[L], cols_i = a.lcols[L], n = a.ln[L];
@@ -72,21 +72,21 @@ __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, int which, int
                     float d0 = db[5], d1 = db[6], d2 = db[9], d3 = db[10];
                     if (d1 < d0) { const float t = d1; d1 = d0; d0 = t; }
                     if (d3 < d2) { const float t = d3; d3 = d2; d2 = t; }
-                    const float dcenter = (d3 < d1) ? std_max(d3, d0) : std_max(d1, d2);
-                    if (dcenter != 0.f) {
-                        float sum_d = 0.f, sum_c = 0.f, weight = 0.f;
+                    const float z_mid = (d3 < d1) ? std_max(d3, d0) : std_max(d1, d2);
+                    if (z_mid != 0.f) {
+                        float acc_z = 0.f, acc_g = 0.f, w_all = 0.f;  // depth, grey value and weight sums of the 16 taps
 #pragma unroll
                         for (int k = 0; k < 16; k++) {
-                            const float abs_dif = fabsf(db[k] - dcenter);
-                            if (abs_dif < max_depth_dif) {
-                                const float aux_w = conv_mask(k) * (max_depth_dif - abs_dif);
-                                weight += aux_w;
-                                sum_d += aux_w * db[k];
-                                sum_c += aux_w * ib[k];
+                            const float gap = fabsf(db[k] - z_mid);
+                            if (gap < gap_max) {
+                                const float tap_w = conv_mask(k) * (gap_max - gap);
+                                w_all += tap_w;
+                                acc_z += tap_w * db[k];
+                                acc_g += tap_w * ib[k];
                             }
                         }
-                        dout = sum_d / weight;
-                        iout = sum_c / weight;
+                        dout = acc_z / w_all;
+                        iout = acc_g / w_all;
                     } else {
                         float lane4[4];
 #pragma unroll
@@ -110,15 +110,15 @@ __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, int which, int
                         ib[q] = b4i[q];
                     }
                     iout = 0.25f * ((ib[0] + ib[2]) + (ib[1] + ib[3]));
-                    float new_d = 0.f;
-                    unsigned cont = 0;
+                    float z_sum = 0.f;
+                    unsigned z_cnt = 0;
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                         if (db[k] != 0.f) {
-                            new_d += db[k];
-                            cont++;
+                            z_sum += db[k];
+                            z_cnt++;
                         }
-                    dout = (cont != 0) ? new_d / float(cont) : 0.f;
+                    dout = (z_cnt != 0) ? z_sum / float(z_cnt) : 0.f;
                 }
                 gst(d_here, idx, dout);
                 gst(i_here, idx, iout);  // xx / yy (:385-386) are recomputed by their consumers: level_coord()

@@ -36,6 +36,15 @@
 #ifndef SF_RO_SPLAT
 #define SF_RO_SPLAT 1   // 0: the product's exact integer splat sums (divided with IEEE division)
 #endif
+// ... or only at some levels of the pyramid: the ordered float splat runs at image levels [SF_RO_SPLAT_MIN_LEVEL, SF_RO_SPLAT_MAX_LEVEL]
+// (0 = full resolution), the product's integer sums (IEEE division) at the others -- which levels carry the sensitivity
+#ifndef SF_RO_SPLAT_MIN_LEVEL
+#define SF_RO_SPLAT_MIN_LEVEL 0
+#endif
+#ifndef SF_RO_SPLAT_MAX_LEVEL
+#define SF_RO_SPLAT_MAX_LEVEL 99
+#endif
+#define RO_SPLAT_AT(L) (SF_RO_SPLAT && (L) >= SF_RO_SPLAT_MIN_LEVEL && (L) <= SF_RO_SPLAT_MAX_LEVEL)
 #ifndef SF_RO_ROWS
 #define SF_RO_ROWS 1    // 0: the product's factored rows / three dot products (with SF_ROWS_FMA as given)
 #endif

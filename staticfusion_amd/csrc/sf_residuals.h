@@ -62,7 +62,7 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
         s.lab_cnt[tid] = 0;
     }
 #if SF_REFORDER && SF_RO_SPLAT
-    const bool lazy = true;  // (ro_splat initialises every cell)
+    const bool lazy = RO_SPLAT_AT(0) || splat_lazy_ok(rows, cols, G);  // (ro_splat initialises every cell)
 #else
     const bool lazy = splat_lazy_ok(rows, cols, G);  // see solve_warp
 #endif
@@ -104,13 +104,12 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
         }
     } src{dbuf, ibuf, dcur, inv_f_i, g.disp_u_i, g.disp_v_i};
 #if SF_REFORDER && SF_RO_SPLAT
-    {
+    if (RO_SPLAT_AT(0)) {
         LevelCoord lc0 = level_coord(a, 0);
         ro_splat(g, lc0, n, src, acc_d, acc_i, as_global(a.ro_list + rb * RO_LIST_K), tid);
-    }
-#else
-    tiled_splat(g, rows, cols, src, acc_d, acc_i, s.win, s.marks, tid, rank, G, lazy, &st.prof[PF_SPLAT_REPLAYS]);
+    } else
 #endif
+        tiled_splat(g, rows, cols, src, acc_d, acc_i, s.win, s.marks, tid, rank, G, lazy, &st.prof[PF_SPLAT_REPLAYS]);
     cluster_rendezvous(cs, tid);
 
 #if SF_REFORDER
@@ -133,11 +132,10 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
                     }
                     if (si != 0 && dc != 0.f) {
                         float dw, iw;
-#if SF_RO_SPLAT
-                        ro_unpack_cell(sd, dw, iw);
-#else
-                        normalise_acc(sd, si, dw, iw);
-#endif
+                        if (RO_SPLAT_AT(0))
+                            ro_unpack_cell(sd, dw, iw);
+                        else
+                            normalise_acc(sd, si, dw, iw);
                         if (dw != 0.f && lb < SF_NC) {
                             const float idiff = (db != 0.f) ? ic : 0.f;  // intensity_diff (:937,1022)
                             val = fabsf(dc - dw) + kph_ro * fabsf(idiff - iw);

@@ -241,7 +241,8 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
     // a cluster's workgroups zero every G-th block. Agent-scope (write-through) stores: the cells are only ever touched by
     // agent-scope atomics and atomic loads after this, so the two hand-overs below need no fence (sf_cluster.h)
 #if SF_REFORDER && SF_RO_SPLAT
-    const bool lazy = true;  // (nothing to zero: ro_splat below initialises every cell)
+    const bool ordered = RO_SPLAT_AT(L);
+    const bool lazy = ordered || splat_lazy_ok(rows_i, cols_i, G);  // (ordered: nothing to zero, ro_splat initialises every cell)
 #else
     const bool lazy = splat_lazy_ok(rows_i, cols_i, G);  // one workgroup: the splat zeroes the cells itself, window by window
 #endif
@@ -281,10 +282,11 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
         }
     } src{dpred, ipred, level_coord(a, L)};
 #if SF_REFORDER && SF_RO_SPLAT
-    ro_splat(g, level_coord(a, L), n, src, acc_d, acc_i, as_global(a.ro_list + rb * RO_LIST_K), tid);  // the reference's float sums, in its order
-#else
-    tiled_splat(g, rows_i, cols_i, src, acc_d, acc_i, s.win, s.marks, tid, rank, G, lazy, &a.state[b].prof[PF_SPLAT_REPLAYS]);
+    if (ordered)
+        ro_splat(g, level_coord(a, L), n, src, acc_d, acc_i, as_global(a.ro_list + rb * RO_LIST_K), tid);  // the reference's float sums, in its order
+    else
 #endif
+        tiled_splat(g, rows_i, cols_i, src, acc_d, acc_i, s.win, s.marks, tid, rank, G, lazy, &a.state[b].prof[PF_SPLAT_REPLAYS]);
     cluster_rendezvous(cs, tid);  // all atomics of the workgroup(s) performed: the linearisation reads the cells with atomic loads
 }
 
@@ -381,10 +383,11 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                     iw = __uint_as_float((unsigned)((unsigned long long)pf_ad[q] >> 32));
                 } else if (pf_ai[q] != 0) {  // normalise the warp accumulators (reference :876-881); touched <=> sum(w) > 0
 #if SF_REFORDER && SF_RO_SPLAT
-                    ro_unpack_cell(pf_ad[q], dw, iw);  // already divided, in the reference's order (ro_splat)
-#else
-                    normalise_acc(pf_ad[q], pf_ai[q], dw, iw);
+                    if (RO_SPLAT_AT(L))
+                        ro_unpack_cell(pf_ad[q], dw, iw);  // already divided, in the reference's order (ro_splat)
+                    else
 #endif
+                        normalise_acc(pf_ad[q], pf_ai[q], dw, iw);
                 }
             }
             const bool nul = !(inside && (dn != 0.f) && (dw != 0.f));

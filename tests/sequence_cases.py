@@ -70,8 +70,8 @@ def run_case(api, case, variant=None, prepare=None):
 def compare_frames(ref, got, thr):
     """One record per frame: pose distance, discrete mismatches, b distances, and -- when the IRLS counts differ -- whether
     it is a STOPPING-THRESHOLD FLIP: one level whose IRLS count differs while the `delta_sol_max` that passed the stopping
-    test (reference FrontEnd.cpp:676-679) on the side that stopped first lies within 5 % of irls_delta_threshold -- or a
-    LEVEL-EXIT tie (classify_flip)."""
+    test (reference FrontEnd.cpp:676-679) on the side that stopped first lies within TIE_REL_MARGIN (2 %) of
+    irls_delta_threshold -- or a LEVEL-EXIT tie (classify_flip)."""
     recs = []
     for k, (a, b) in enumerate(zip(ref, got)):
         rot, trans = pose_delta(a["T"], b["T"])
@@ -89,7 +89,12 @@ def compare_frames(ref, got, thr):
     return recs
 
 
-def classify_flip(outer_ref, outer_got, thr, rel_margin=0.05):
+# Every tie observed on the 600 QVGA / 5000 160 x 120 hunt sequences lies within 1.2 % of its threshold (8.5e-6 ... 1.17e-2; round 3's
+# test allowed 5 %)
+TIE_REL_MARGIN = 0.02
+
+
+def classify_flip(outer_ref, outer_got, thr, rel_margin=TIE_REL_MARGIN):
     """The first outer iteration whose IRLS count differs, and how close to the threshold the deciding delta was. The path has
     a second discontinuity of the same kind: a level is left when the norm of its twist falls below 0.04 (reference
     FrontEnd.cpp:1130); when the two runs disagree on THAT, their sequences of (level, k) differ from the next entry on."""

@@ -143,6 +143,13 @@ def test_bench_algorithmic_bytes():
     assert out["linearise"] == 88 * (100 + 400) and out["warp"] == 32 * 400
     assert out["pyramid"] == 2 * 48 * 100 and out["kmeans"] == 20 * 100 * 3
     assert out["segm_image"] == 8 * 400 and out["residuals"] == 32 * 400
+    # a launch of K sequence frames builds the old image's pyramid only where the buffers did not swap (sf_frame_kernels.hip)
+    assert bench.sequence_pyramids_per_frame(20) == (1.1, 18) and bench.sequence_pyramids_per_frame(2) == (2.0, 0)
+    assert bench.sequence_pyramids_per_frame(3) == (4.0 / 3.0, 2) and bench.sequence_pyramids_per_frame(1) == (2.0, 0)
+    one = bench.algorithmic_bytes([st], levels_n, 100, True, True, pyramids_per_frame=1.1)
+    assert one["pyramid"] == pytest.approx(1.1 * 48 * 100) and one["irls"] == out["irls"]
+    moved = bench.algorithmic_bytes([st], levels_n, 100, True, True, per_unit=bench.MOVED_B)
+    assert moved["irls"] == 58 * 1000 and moved["residuals"] == 72 * 400 and moved["linearise"] == 54 * 500
 
 
 def test_frames_in_one_call_on_the_oracle(ora):
@@ -226,3 +233,23 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 2 and b"refusing" in r.stderr and not r.stdout.strip()
+
+
+def test_abi_version_and_struct_sizes(ora):
+    """sf_abi_version: the library's header version and the sizes it assumes for the structs and the stage-profile array callers
+    hand over (three silent ABI changes -- 24 -> 32 profile slots, a trace field, an argument). Oracle and product
+    implement it; the ctypes mirrors of this package must agree with both."""
+    import staticfusion_amd as sf
+    from staticfusion_amd import capi
+
+    hdr = open(os.path.join(ROOT, "include", "sf.h")).read()
+    version = int(re.search(r"#define SF_ABI_VERSION (\d+)", hdr).group(1))
+    libs = [ora.lib.sfo_abi_version]
+    if os.path.exists(sf.LIB):
+        libs.append(ctypes.CDLL(sf.LIB).sf_abi_version)
+    for fn in libs:
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        fn.restype = ctypes.c_int
+        assert fn(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == version
+        assert a.value == ctypes.sizeof(capi.SfParams) and b.value == ctypes.sizeof(capi.SfFrameStats) and c.value == 32
+        assert fn(None, None, None) == version

@@ -17,8 +17,12 @@ determine, moves the result more than the HIP path differs from the oracle.
 What is asserted here, on every build of the frame kernel:
   * cluster labels and the (b > 0.5) decision of every pixel identical in every frame, flip or not;
   * pose within 1e-4 rad / 1e-4 m of the oracle in every frame that is not a stopping-threshold flip or downstream of one;
-  * a frame whose IRLS count differs IS a threshold flip: one level, one iteration, the deciding delta within 5 % of the
-    threshold (the trace carries it: sf_outer_trace::delta_sol_max);
+  * a frame whose IRLS count differs IS a threshold flip: one level, one iteration, the deciding delta within 2 % of the
+    threshold (the trace carries it: sf_outer_trace::delta_sol_max); the frames at and after it stay within 1e-3;
+  * (round 4) the REFERENCE-ORDER build (libsf_hip_reforder.so, sf_reforder.h) is bit-identical to the oracle -- pose, b, b image,
+    counts -- on 100 QVGA sequences: what is left of the product's distance is the product's arithmetic, shortcut by shortcut
+    (profiles/PARITY.md), and on the same 100 sequences the product's excursion counts stay within twice those of the oracle
+    against its own `gemm2` reading (tests/golden/hunt_control_gemm2_qvga_s8250_n100.json);
   * 40 fresh QVGA sequences (320 frames at the product resolution): all of the above, no flip tolerated silently.
 """
 import multiprocessing as mp
@@ -32,9 +36,11 @@ from test_gpu_parity import POSE_TOL
 
 pytestmark = pytest.mark.gpu
 
+POSE_TOL_AFTER_TIE = 1e-3
+
 NAMED_SEEDS = (5211, 20115, 20527)
 QVGA_SEEDS = range(31000, 31040)
-# the 600-sequence QVGA hunt on round 3's final sources (profiles/r03o_hunt_qvga_s8000_n600.json): every sequence in which a build left
+# the 600-sequence QVGA hunt on round 3's final sources (profiles/r03o_hunt_qvga_s8000_n600.json.gz): every sequence in which a build left
 # the pose bar. 8163, 8328, 8340: stopping-threshold ties (the oracle against its own gemm2 / gemm1 / fp64-warp readings leaves the
 # bar on the same three sequences, profiles/r03o_control_*). 8171: no tie -- see test_qvga_sequence_with_an_ill_conditioned_frame
 QVGA_NAMED_SEEDS = (8163, 8328, 8340)
@@ -72,14 +78,17 @@ def _check_run(hip, case, ref, thr, allow_flip):
         flip = r.get("flip")
         if flip and not after_flip:
             assert allow_flip, (where, flip)
-            # one level, one iteration, the deciding delta at the threshold -- or the level-exit test (norm of the level's twist
-            # against 0.04, FrontEnd.cpp:1130) decided in the last digit
+            # one level, one iteration, the deciding delta within 2 % of the threshold (sequence_cases.TIE_REL_MARGIN; the ties
+            # observed lie within 1.2 %) -- or the level-exit test (norm of the level's twist against 0.04, FrontEnd.cpp:1130)
             assert flip["kind"] in ("threshold", "level-exit"), (where, flip)
+            print("tie %s: %s, relative margin %.2e" % (where, flip["kind"], flip["rel_margin"]))
             flips.append((r["frame"], flip))
             after_flip = True
         if not after_flip:
             assert r["rot"] <= POSE_TOL and r["trans"] <= POSE_TOL, (where, r["rot"], r["trans"])
             assert r["counts"] == r["counts_ref"], where
+        else:  # at or after a tie the carried state differs: the frames stay within 1e-3 (worst observed 7.1e-4 m, seed 8328)
+            assert r["rot"] <= POSE_TOL_AFTER_TIE and r["trans"] <= POSE_TOL_AFTER_TIE, (where, r["rot"], r["trans"])
     return recs, flips
 
 
@@ -136,6 +145,61 @@ def test_fresh_qvga_sequences(hip, ora):
     # measured on 200 fresh QVGA sequences (profiles/r03h_hunt_qvga_s9000_n200.json): 9 flips in 4800 frames; here 320 frames per build
     assert flips <= 2, flips
     print("fresh QVGA sequences on %s: worst pose distance %.2e, flips %d" % (hip.default_variant, worst, flips))
+
+
+STAT_SEEDS = range(8250, 8350)  # a window of the 600-sequence hunt with ties on both sides (HIP: 8328, 8340; gemm2: 8256, 8296, 8328)
+
+
+def test_excursion_rates_against_the_gemm2_control(hip, ora):
+    """100 QVGA sequences x 8 frames: the build's counts of frames past the pose bar, of iteration-count mismatches and of b images
+    that differ by more than 1e-4 / 1e-3 must not exceed TWICE what the oracle shows against its own `gemm2` reading (an Eigen-style
+    float GEMM for AtA / AtB: the one order the reference's source leaves open) on the same seeds -- computed once on the CPU and
+    kept as a fixture. Labels and decisions: identical, always."""
+    import json
+
+    from conftest import GOLDEN
+
+    ctl = json.load(open(os.path.join(GOLDEN, "hunt_control_gemm2_qvga_s8250_n100.json")))
+    assert ctl["first_seed"] == STAT_SEEDS[0] and ctl["count"] == len(STAT_SEEDS)
+    thr = float(ora.default_params_struct().irls_delta_threshold)
+    got = {"count_mismatch_frames": 0, "pose_over_1e-4_frames": 0, "b_img_over_1e-4_frames": 0, "b_img_over_1e-3_frames": 0}
+    frames = 0
+    for case, ref in _cases([(s, 640, 480) for s in STAT_SEEDS]):
+        for r in compare_frames(ref, run_case(hip, case), thr):
+            frames += 1
+            assert r["label_px"] == 0 and r["decision_px"] == 0, (case["seed"], r["frame"])
+            got["count_mismatch_frames"] += "flip" in r
+            got["pose_over_1e-4_frames"] += max(r["rot"], r["trans"]) > 1e-4
+            got["b_img_over_1e-4_frames"] += r["b_img"] > 1e-4
+            got["b_img_over_1e-3_frames"] += r["b_img"] > 1e-3
+    assert frames == ctl["frames"]
+    print("%s: %s; control %s" % (hip.default_variant, got, {k: ctl[k] for k in got}))
+    for k, v in got.items():
+        assert v <= 2 * ctl[k], (k, v, ctl[k])
+
+
+def test_reference_order_build_is_bit_identical_to_the_oracle(ora):
+    """libsf_hip_reforder.so (sf_reforder.h): the frame kernel with every float operation sequence that the reference's source
+    fixes put back in the reference's order -- warp / residual scatter per target cell in source order, the Jacobian rows in the
+    source's expression order, IEEE weights, per-cluster float sums in pixel order, AtA / AtB as the oracle's [C1], cyclic Jacobi.
+    On the same 100 QVGA sequences: pose, b, the b image, labels and iteration counts of all 800 frames equal the oracle's BIT FOR
+    BIT. The product's distance from the oracle is therefore the sum of its arithmetic shortcuts (profiles/PARITY.md has it
+    shortcut by shortcut), not a misreading of the algorithm."""
+    import staticfusion_amd as sf
+
+    lib = os.path.join(os.path.dirname(sf.LIB), "libsf_hip_reforder.so")
+    api = sf.Api(lib, "sf_").with_variant("throughput")
+    assert api.backend_name().endswith("reference-order")
+    frames = 0
+    for case, ref in _cases([(s, 640, 480) for s in STAT_SEEDS]):
+        got = run_case(api, case)
+        for k, (a, b) in enumerate(zip(ref, got)):
+            where = (case["seed"], k + 1)
+            assert a["counts"] == b["counts"] and a["outer"] == b["outer"], where
+            assert np.array_equal(a["labels"], b["labels"]), where
+            assert np.array_equal(a["T"], b["T"]) and np.array_equal(a["b"], b["b"]) and np.array_equal(a["b_img"], b["b_img"]), where
+            frames += 1
+    assert frames == 800
 
 
 @pytest.mark.parametrize("case", (63, 185))

@@ -11,6 +11,8 @@ build() {  # name, make variables...
 }
 build splat_int        RO_FLAGS="-DSF_RO_SPLAT=0"
 build splat_int_fastdiv RO_FLAGS="-DSF_RO_SPLAT=0" RO_FAST_NORMALISE=1
+build splat_int_fine   RO_FLAGS="-DSF_RO_SPLAT_MIN_LEVEL=2"   # integer sums at image levels 0, 1 only (ordered floats at the coarse levels)
+build splat_int_coarse RO_FLAGS="-DSF_RO_SPLAT_MAX_LEVEL=1"   # integer sums at image levels >= 2 only
 build rows_fact        RO_FLAGS="-DSF_RO_ROWS=0"
 build rows_fact_fma    RO_FLAGS="-DSF_RO_ROWS=0" RO_ROWS_FMA=1
 build fast_weights     RO_FAST_WEIGHTS=1

@@ -32,6 +32,36 @@ def new_summary():
             "worst": {"rot": 0.0, "trans": 0.0, "b24": 0.0, "b_img": 0.0}, "pose_over_1e-4_not_flip": 0, "seconds_gpu": 0.0}
 
 
+_LIBS = None
+
+
+def _seed_worker(job):
+    """One seed in one process: the case, the oracle's frames, then every library on the GPU (this process's own HIP context:
+    the synchronous copies of the getters serialise the streams of ONE process, so the parallelism is across processes)."""
+    seed, W, H, seg, lib_items, build, thr = job
+    global _LIBS
+    import staticfusion_amd as sf
+    from oracle import binding
+    from sequence_cases import compare_frames, make_case, run_case
+
+    if _LIBS is None:
+        _LIBS = [(name, sf.Api(path, "sf_").with_variant(build)) for name, path in lib_items]
+    ora = binding.load()
+    case = make_case(seed, W, H, seg)
+    ref = run_case(ora, case)
+    out = []
+    for name, api in _LIBS:
+        tg = time.time()
+        got = run_case(api, case)
+        dt = time.time() - tg
+        recs = compare_frames(ref, got, thr)
+        for k, rec in enumerate(recs):
+            rec["bit_identical"] = bool(np.array_equal(ref[k]["T"], got[k]["T"]) and np.array_equal(ref[k]["b"], got[k]["b"])
+                                        and np.array_equal(ref[k]["b_img"], got[k]["b_img"]) and ref[k]["counts"] == got[k]["counts"])
+        out.append((name, dt, recs))
+    return seed, case["scale"], out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--first", type=int, default=8000)
@@ -41,7 +71,6 @@ def main():
     ap.add_argument("--build", default="throughput", help="frame-kernel build every library runs (sf_create_ex)")
     ap.add_argument("--libs", required=True, help="name=path[,name=path...]")
     ap.add_argument("--procs", type=int, default=0)
-    ap.add_argument("--threads", type=int, default=16, help="(seed, library) runs in flight on the GPU")
     ap.add_argument("--json", default=None)
     ap.add_argument("--keep-pose", type=float, default=1e-5)
     ap.add_argument("--keep-b", type=float, default=1e-3)
@@ -49,91 +78,72 @@ def main():
     W, H = (int(x) for x in a.size.split("x"))
     import staticfusion_amd as sf
     from oracle import binding
-    from sequence_cases import compare_frames, run_case
-    from sequence_hunt import _worker
 
     binding.build()
     thr = float(binding.load().default_params_struct().irls_delta_threshold)
-    libs = []
+    lib_items = []
     for item in a.libs.split(","):
         name, path = item.split("=", 1)
-        libs.append((name, sf.Api(os.path.join(ROOT, path) if not os.path.isabs(path) else path, "sf_").with_variant(a.build)))
+        lib_items.append((name, os.path.join(ROOT, path) if not os.path.isabs(path) else path))
     cap = None
     try:
         q, p = open("/sys/fs/cgroup/cpu.max").read().split()
         cap = None if q == "max" else int(float(q) / float(p))
     except Exception:
         pass
-    procs = a.procs or max(1, min(len(os.sched_getaffinity(0)), cap or 64) - 1)
+    procs = a.procs or max(1, min(len(os.sched_getaffinity(0)), cap or 64))
 
-    summ = {name: new_summary() for name, _ in libs}
+    summ = {name: new_summary() for name, _ in lib_items}
     kept = []
     t0 = time.time()
-    jobs = [(s, W, H, not a.no_seg, None) for s in range(a.first, a.first + a.count)]
-    # Every (seed, library) run is one 256-thread workgroup on a GPU with 256 CUs: the runs of a seed go to a pool of
-    # threads (one handle each: handles are independent, the library calls release the GIL), a few seeds in flight.
-    import threading
-    from concurrent.futures import ThreadPoolExecutor
-
-    lock = threading.Lock()
-
-    def one_run(seed, case, ref, name, api):
-        tg = time.time()
-        got = run_case(api, case)
-        dt = time.time() - tg
-        recs = compare_frames(ref, got, thr)
-        with lock:
-            sm = summ[name]
-            sm["seconds_gpu"] += dt
-            sm["runs"] += 1
-            after_flip = False
-            for k, rec in enumerate(recs):
-                sm["frames"] += 1
-                pose = max(rec["rot"], rec["trans"])
-                same = (np.array_equal(ref[k]["T"], got[k]["T"]) and np.array_equal(ref[k]["b"], got[k]["b"])
-                        and np.array_equal(ref[k]["b_img"], got[k]["b_img"]) and ref[k]["counts"] == got[k]["counts"])
-                sm["bit_identical_frames"] += bool(same)
-                rec["bit_identical"] = bool(same)
-                for t in sm["pose_over"]:
-                    sm["pose_over"][t] += pose > float(t)
-                for t in sm["b24_over"]:
-                    sm["b24_over"][t] += rec["b24"] > float(t)
-                    sm["b_img_over"][t] += rec["b_img"] > float(t)
-                for q in ("rot", "trans", "b24", "b_img"):
-                    sm["worst"][q] = max(sm["worst"][q], rec[q])
-                sm["label_mismatch_frames"] += rec["label_px"] > 0
-                sm["decision_mismatch_frames"] += rec["decision_px"] > 0
-                flip = rec.get("flip")
-                if flip:
-                    sm["count_mismatch_frames"] += 1
-                    if not after_flip:
-                        sm["threshold_flips" if flip["kind"] in ("threshold", "level-exit") else "other_count_mismatches"] += 1
-                rec["after_flip"] = after_flip
-                if pose > 1e-4 and not (flip or after_flip):
-                    sm["pose_over_1e-4_not_flip"] += 1
-                if flip:
-                    after_flip = True
-                if rec["label_px"] or rec["decision_px"] or flip or pose > a.keep_pose or rec["b24"] > a.keep_b:
-                    rec.update(seed=seed, lib=name, motion_scale=case["scale"])
-                    kept.append(rec)
-                    if rec["label_px"] or rec["decision_px"] or flip or pose > 1e-4:
-                        print("seed %d %s frame %d: rot %.2e trans %.2e labels %d px decisions %d px counts %s vs %s %s" % (
-                            seed, name, rec["frame"], rec["rot"], rec["trans"], rec["label_px"], rec["decision_px"], rec["counts"],
-                            rec["counts_ref"], (flip or {}).get("kind", "")), flush=True)
-
-    with mp.get_context("spawn").Pool(procs) as pool, ThreadPoolExecutor(max_workers=a.threads) as tp:
-        pending = []
-        for seed, case, ref, _ in pool.imap(_worker, jobs, chunksize=1):
-            pending += [tp.submit(one_run, seed, case, ref, name, api) for name, api in libs]
-            while len(pending) > 4 * a.threads:
-                pending.pop(0).result()
-        for f in pending:
-            f.result()
+    jobs = [(s, W, H, not a.no_seg, lib_items, a.build, thr) for s in range(a.first, a.first + a.count)]
+    with mp.get_context("spawn").Pool(procs) as pool:
+        done = 0
+        for seed, scale, out in pool.imap_unordered(_seed_worker, jobs, chunksize=1):
+            done += 1
+            if a.json and done % 100 == 0:  # a checkpoint: a run that is cut off still leaves what it had
+                with open(a.json + ".partial", "w") as f:
+                    json.dump({"seeds_done": done, "summary": summ, "frames": kept}, f)
+            for name, dt, recs in out:
+                sm = summ[name]
+                sm["seconds_gpu"] += dt
+                sm["runs"] += 1
+                after_flip = False
+                for rec in recs:
+                    sm["frames"] += 1
+                    pose = max(rec["rot"], rec["trans"])
+                    sm["bit_identical_frames"] += rec["bit_identical"]
+                    for t in sm["pose_over"]:
+                        sm["pose_over"][t] += pose > float(t)
+                    for t in sm["b24_over"]:
+                        sm["b24_over"][t] += rec["b24"] > float(t)
+                        sm["b_img_over"][t] += rec["b_img"] > float(t)
+                    for q in ("rot", "trans", "b24", "b_img"):
+                        sm["worst"][q] = max(sm["worst"][q], rec[q])
+                    sm["label_mismatch_frames"] += rec["label_px"] > 0
+                    sm["decision_mismatch_frames"] += rec["decision_px"] > 0
+                    flip = rec.get("flip")
+                    if flip:
+                        sm["count_mismatch_frames"] += 1
+                        if not after_flip:
+                            sm["threshold_flips" if flip["kind"] in ("threshold", "level-exit") else "other_count_mismatches"] += 1
+                    rec["after_flip"] = after_flip
+                    if pose > 1e-4 and not (flip or after_flip):
+                        sm["pose_over_1e-4_not_flip"] += 1
+                    if flip:
+                        after_flip = True
+                    if rec["label_px"] or rec["decision_px"] or flip or pose > a.keep_pose or rec["b24"] > a.keep_b:
+                        rec.update(seed=seed, lib=name, motion_scale=scale)
+                        kept.append(rec)
+                        if rec["label_px"] or rec["decision_px"] or flip or pose > 1e-4:
+                            print("seed %d %s frame %d: rot %.2e trans %.2e labels %d px decisions %d px counts %s vs %s %s" % (
+                                seed, name, rec["frame"], rec["rot"], rec["trans"], rec["label_px"], rec["decision_px"], rec["counts"],
+                                rec["counts_ref"], (flip or {}).get("kind", "")), flush=True)
     from bench import git_head, source_sha
 
     meta = {"first_seed": a.first, "count": a.count, "solver_size": "%dx%d" % (W // 2, H // 2), "segmentation": not a.no_seg,
             "build": a.build, "irls_delta_threshold": thr, "seconds": round(time.time() - t0, 1), "head": git_head(), "src_sha": source_sha(),
-            "libs": {name: api.backend_name() for name, api in libs}}
+            "libs": {name: sf.Api(path, "sf_").backend_name() for name, path in lib_items}}
     for name, sm in summ.items():
         sm["seconds_gpu"] = round(sm["seconds_gpu"], 1)
         print(name, json.dumps(sm))

@@ -19,7 +19,7 @@ api = sf.load()
 p = bench.make_params(api, a.workload)
 s = sf.Solver(api, 240, 320, a.batch, p)
 if a.workload == "sequences":
-    D, F = 2, 12 + a.steps
+    D, F = 2, 12 + max(a.steps, int(os.environ.get("SF_PROF_ONE_LAUNCH", "0")))
     # no process pool here: rocprofv3 follows every child process, and a pool of spawned workers under it never came back
     # (round 3: the orphans kept the GPU busy for everything that ran after them)
     seqs = [make_sequence(1000 + q, F, sphere=True) for q in range(D)]
@@ -38,6 +38,13 @@ if a.workload == "sequences":
     for step in range(1, 7):
         s.advance_sequences_device(ptrs[0], ptrs[1], idx(step), D * F); s.process_frame(step)
     s.synchronize()
+    K = int(os.environ.get("SF_PROF_ONE_LAUNCH", "0"))
+    if K:  # the bench's own shape: K frames of every stream in ONE launch (sf_process_sequence_frames_device) -- the LAST dispatch
+        assert F >= 7 + K
+        s.process_sequence_frames_device(ptrs[0], ptrs[1], np.stack([idx(7 + q) for q in range(K)]), D * F, 7)
+        s.synchronize()
+        print("one launch of %d frames, batch %d: %.3f ms per frame" % (K, a.batch, s.last_solver_kernel_ms() / K))
+        sys.exit(0)
     ms = 0.0
     for step in range(7, 7 + a.steps):  # the advance is its own (small) kernel here; the frame kernel is what the counters are read for
         s.advance_sequences_device(ptrs[0], ptrs[1], idx(step), D * F); s.process_frame(step); s.synchronize()

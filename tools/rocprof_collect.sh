@@ -7,6 +7,7 @@ TAG=$1; WL=$2; B=$3
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 export SF_TIMED_LAUNCH_PER_FRAME=1  # bytes per FRAME of every stream: one launch per frame under the counters
+# (sequences with SF_PROF_ONE_LAUNCH=K in the environment: ONE launch of K frames, the bench's own shape -- tools/measure_traffic.sh)
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 CMD="python tools/prof_run.py --workload $WL --batch $B --steps 3"

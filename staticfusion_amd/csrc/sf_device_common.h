@@ -147,6 +147,7 @@ struct KArgs {
     unsigned debug_stall_ticks, sync_spin_limit;
     // reference-order build only (sf_reforder.h; null otherwise): per record slot, RO_LIST_K source-pixel indices per cell
     int *ro_list;
+    int ro_blocks;  // product builds: blocks of SF_ORDERED_SPLAT_MAX_PIXELS * RO_LIST_K indices in ro_list (sf_reforder.h: ro_list_of)
 };
 
 // The two pyramid buffers of a stream: set 0 = new (depthCurrent and its levels), set 1 = Pred. When consecutive frames

@@ -391,7 +391,15 @@ int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, 
     for (int q = 0; q < R_COUNT; q++) TRY_OR_FREE(dev_alloc(h, &k.rec[q], slots * N0));
     TRY_OR_FREE(dev_alloc(h, &k.rec_lab, slots * N0));
     TRY_OR_FREE(dev_alloc(h, &k.rec_null, slots * N0));
-    if (h->reforder) TRY_OR_FREE(dev_alloc(h, &k.ro_list, slots * N0 * RO_LIST_K));  // source indices per cell (sf_reforder.h)
+    if (h->reforder) {
+        TRY_OR_FREE(dev_alloc(h, &k.ro_list, slots * N0 * RO_LIST_K));  // source indices per cell of every record slot (sf_reforder.h)
+    } else {
+        // the ordered float splat of the coarse levels (sf_reforder.h): source lists per RESIDENT WORKGROUP, 1 MB each
+        // (one per stream while that is fewer: sf_reforder.h, ro_list_of)
+        const size_t wgs = h->cluster_grid ? (size_t)h->cluster_grid : std::min<size_t>(B, (size_t)std::max(h->max_blocks, h->max_blocks_o5));
+        TRY_OR_FREE(dev_alloc(h, &k.ro_list, wgs * SF_ORDERED_SPLAT_MAX_PIXELS * RO_LIST_K));
+        k.ro_blocks = (int)wgs;
+    }
     if (k.cluster_g) TRY_OR_FREE(dev_alloc(h, &k.sync, B * 2 * k.cluster_g * SF_SYNC_WORDS));
     TRY_OR_FREE(dev_alloc(h, &k.hist_d, (size_t)SF_HISTORY * B * N0));
     TRY_OR_FREE(dev_alloc(h, &k.hist_i, (size_t)SF_HISTORY * B * N0));

@@ -138,63 +138,6 @@ __device__ __forceinline__ void km_search_n(const LDS KmShared &s, const int (&l
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-//  Lloyd pass, version 2 (SF_KM_V2): a lane owns FOUR CONSECUTIVE pixels of the level.
-//
-//  The pruned walk of the reference (KMeans.cpp:196-212) returns the nearest centre in float arithmetic, ties to the walk
-//  order: every centre closer to the pixel than the start centre passes the `4 d` test by the triangle inequality. The
-//  nearest centre does not depend on where a walk starts, so the four neighbouring pixels of a lane walk ONE row of the
-//  candidate table -- the row of the first valid pixel's label L0, up to the largest of their four limits 4 d(p, c_L0)^2 --
-//  and every candidate the lane reads is evaluated for all four: one centre + one candidate read per trip instead of four +
-//  four, no per-pixel limit test. What keeps the labels BIT-exact: the walk also tracks the second smallest distance; a pixel
-//  whose two smallest distances lie within KM_TIE_SCALE of each other (a near tie: the only case in which the reference's
-//  own start point and walk order could decide, or rounding could put the winner just outside the reference's limit) is
-//  searched again with the reference's own walk from its own label (km_search). That happens for a few pixels per
-//  thousand frames; the cost of the check is five instructions per evaluated candidate.
-// ---------------------------------------------------------------------------------------------
-#ifndef SF_KM_V2
-#define SF_KM_V2 1
-#endif
-#define KM_LIM_SCALE 4.0001f   // the reference's 4, inflated past the rounding of the squared distances on either side
-#define KM_TIE_SCALE 1.00001f  // relative distance of the two smallest SQUARED distances below which the reference's walk decides
-
-template <int N>
-__device__ __forceinline__ void km_search_shared(const LDS KmShared &s, int L0, const float (&pz)[N], const float (&px)[N],
-                                                 const float (&py)[N], const bool (&valid)[N], int (&best)[N], bool (&tie)[N]) {
-    const vfloat4 c0 = s.cent4[L0];
-    float bd[N], m2[N], lim = -1.f;
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-        best[k] = L0;
-        bd[k] = sqdist3(c0.x, c0.y, c0.z, pz[k], px[k], py[k]);
-        m2[k] = 3.0e38f;
-        lim = valid[k] ? fmaxf(lim, bd[k]) : lim;
-    }
-    lim *= KM_LIM_SCALE;  // (no valid pixel: negative, nothing passes)
-    vfloat2 cd = s.cand[L0 * SF_NC + 1];
-    for (int li = 1; li < SF_NC; li++) {
-        const bool act = !(cd.x > lim);
-        if (!__any(act)) break;
-        const int nxt = min(li + 1, SF_NC - 1);
-        const int c = __float_as_int(cd.y);
-        const vfloat4 cc = s.cent4[c];
-        const vfloat2 cdn = s.cand[L0 * SF_NC + nxt];  // both reads of the trip in flight before either is used
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < N; k++) {
-            const float d = sqdist3(cc.x, cc.y, cc.z, pz[k], px[k], py[k]);
-            const float dl = act ? d : 3.0e38f;  // a lane past its limit rides along without effect
-            m2[k] = fminf(m2[k], fmaxf(dl, bd[k]));
-            const bool upd = dl < bd[k];
-            bd[k] = upd ? dl : bd[k];
-            best[k] = upd ? c : best[k];
-        }
-        cd = cdn;
-    }
-#pragma unroll
-    for (int k = 0; k < N; k++) tie[k] = valid[k] && !(m2[k] > bd[k] * KM_TIE_SCALE);
-}
-
 __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const size_t sb = (size_t)b * a.n_tot;
@@ -325,8 +268,6 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
     // pixel index steps as (column, row) steps: + 64 between a lane's pixels, + KM_CHUNK - 64 SF_LOAD_BATCH to the next chunk
     const int step64_u = 64 / rows_km, step64_v = 64 - step64_u * rows_km;
     const int stepc = KM_CHUNK - 64 * SF_LOAD_BATCH, stepc_u = stepc / rows_km, stepc_v = stepc - stepc_u * rows_km;
-    const int stepc4_u = KM_CHUNK / rows_km, stepc4_v = KM_CHUNK - stepc4_u * rows_km;  // SF_KM_V2: + KM_CHUNK pixels as (columns, rows)
-    (void)step64_u; (void)step64_v; (void)stepc_u; (void)stepc_v; (void)stepc4_u; (void)stepc4_v;
     int iters = 0;
     for (int it = 0; it < 9; it++) {
         iters++;
@@ -334,128 +275,6 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
         KM_MARK(PF_KM_SORT);
         float acc = 0.f;   // lane (c, r) = tid < 72: running sum of coordinate r over the members of cluster c
         int total = 0;     // lane l < 24 of wave 0: members of cluster l so far
-#if SF_KM_V2
-        static_assert(SF_LOAD_BATCH == 4, "a lane owns four consecutive pixels");
-        typedef __attribute__((address_space(1))) const char gcc_;
-        // lane `lane` of wave w owns pixels [4 lane, 4 lane + 4) of the wave's 256 of the chunk: one 16-byte depth load and
-        // one 4-byte label load per chunk, the next chunk's in flight during this one
-        vfloat4 nz4;
-        unsigned nlab4;
-        {
-            const int idx0 = min(wave * 256 + 4 * lane, n1 - 4);
-            nz4 = *(gptr<const vfloat4>)((gcc_ *)depth + (unsigned)(o1 + idx0) * 4u);
-            nlab4 = *(gptr<const unsigned>)((gcc_ *)labels + (unsigned)(o1 + idx0));
-        }
-        int cu, cv;  // column / row of the lane's first pixel of the chunk
-        split_uv(lc1, wave * 256 + 4 * lane, cu, cv);
-        for (int ch = 0; ch < n_chunks; ch++) {
-            const int idx0 = ch * KM_CHUNK + wave * 256 + 4 * lane;
-            const vfloat4 z4 = nz4;
-            const unsigned lab4 = nlab4;
-            if (ch + 1 < n_chunks) {
-                const int nidx = min(idx0 + KM_CHUNK, n1 - 4);
-                nz4 = *(gptr<const vfloat4>)((gcc_ *)depth + (unsigned)(o1 + nidx) * 4u);
-                nlab4 = *(gptr<const unsigned>)((gcc_ *)labels + (unsigned)(o1 + nidx));
-            }
-            const float pz[4] = {z4.x, z4.y, z4.z, z4.w};
-            float px[4], py[4];
-            bool valid[4], tie[4];
-            int old[4], best[4];
-            const bool in = idx0 < n1;  // (level sizes are multiples of 4: a lane's four pixels are inside or outside together)
-            // (inv_f (u - disp_u)) z and (inv_f (v - disp_v)) z (coord_x / coord_y: the same operations, the column factor shared)
-            const float fxa = lc1.inv_f_i * (float(cu) - lc1.disp_u_i), fxb = lc1.inv_f_i * (float(cu + 1) - lc1.disp_u_i);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const bool wrap = cv + k >= rows_km;  // the four pixels may straddle a column end
-                const int v = wrap ? cv + k - rows_km : cv + k;
-                px[k] = (wrap ? fxb : fxa) * pz[k];
-                py[k] = (lc1.inv_f_i * (float(v) - lc1.disp_v_i)) * pz[k];
-                valid[k] = in && pz[k] != 0.f;
-                old[k] = (int)((lab4 >> (8 * k)) & 255u);
-            }
-            cv += stepc4_v;  // on to the lane's first pixel of the next chunk (+ KM_CHUNK pixels)
-            cu += stepc4_u;
-            if (cv >= rows_km) {
-                cv -= rows_km;
-                cu++;
-            }
-            const int L0 = valid[0] ? old[0] : (valid[1] ? old[1] : (valid[2] ? old[2] : (valid[3] ? old[3] : 0)));
-            km_search_shared<4>(s, L0, pz, px, py, valid, best, tie);
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (__any(tie[k])) {  // a near tie: the reference's own walk from the pixel's own label decides (rare)
-                    if (tie[k]) best[k] = km_search(s, old[k], pz[k], px[k], py[k]);
-                }
-            KM_FINE(PF_KM_ASSIGN);
-            if (in) {
-                unsigned out = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) out |= (unsigned)(valid[k] ? best[k] : old[k]) << (8 * k);
-                *(gptr<unsigned>)((__attribute__((address_space(1))) char *)labels + (unsigned)(o1 + idx0)) = out;
-            }
-            // stable partition: the rank of a pixel among the wave's members of its cluster in pixel order (lane-major, then
-            // k) = members in lower lanes + members among the lane's earlier pixels. One trip per cluster present in the wave
-            // (a 24-bit presence mask, OR-reduced on the DPP network): four ballots, their prefix counts chained through mbcnt
-            int present = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) present |= valid[k] ? (1 << best[k]) : 0;
-            SF_DPP_REDUCE(present, dpp_i32, sf_op_ori)
-            int cnt = 0;
-            int rank[4] = {0, 0, 0, 0};
-            for (unsigned rem = (unsigned)__builtin_amdgcn_readlane(present, 63); rem; rem &= rem - 1) {
-                const int l = __builtin_ctz(rem);
-                bool e[4];
-                unsigned long long m[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    e[k] = valid[k] && best[k] == l;
-                    m[k] = __ballot(e[k]);
-                }
-                unsigned before = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    before = __builtin_amdgcn_mbcnt_hi((unsigned)(m[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[k], before));
-                const int total_l = __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
-                int r = (int)before;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    rank[k] = e[k] ? r : rank[k];
-                    r += e[k] ? 1 : 0;
-                }
-                cnt = (lane == l) ? total_l : cnt;
-            }
-            if (lane < SF_NC) s.wcnt[wave][lane] = cnt;
-            __syncthreads();  // also: the previous chunk's sums have consumed s.chunk
-            int before = 0, members = 0;
-            if (lane < SF_NC) {
-                int c[SF_NW];
-#pragma unroll
-                for (int w = 0; w < SF_NW; w++) c[w] = s.wcnt[w][lane];
-#pragma unroll
-                for (int w = 0; w < SF_NW; w++) {
-                    before += (w < wave) ? c[w] : 0;
-                    members += c[w];
-                }
-            }
-            int incl = members;  // lanes >= 24 hold 0: the scan over the first two rows is the scan over the labels
-            incl += dpp_i32<0x111, 0xf>(incl);
-            incl += dpp_i32<0x112, 0xf>(incl);
-            incl += dpp_i32<0x114, 0xf>(incl);
-            incl += dpp_i32<0x118, 0xf>(incl);
-            incl += dpp_i32<0x142, 0xa>(incl);
-            const int run_start = incl - members;
-            const int my_base = run_start + before;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int base_k = __builtin_amdgcn_ds_bpermute(best[k] << 2, my_base);
-                if (valid[k]) {
-                    const int pos = base_k + rank[k];
-                    s.chunk[0][pos] = pz[k];
-                    s.chunk[1][pos] = px[k];
-                    s.chunk[2][pos] = py[k];
-                }
-            }
-#else
         float pz[SF_LOAD_BATCH], nz[SF_LOAD_BATCH];
         int old[SF_LOAD_BATCH], nold[SF_LOAD_BATCH];
 #pragma unroll
@@ -570,7 +389,6 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
                     s.chunk[2][pos] = py[k];
                 }
             }
-#endif
             const int sum_c = (tid < 3 * SF_NC) ? tid / 3 : 0;  // lane (c, r) of the ordered sums: its cluster's run
             const int sum_n = __builtin_amdgcn_ds_bpermute(sum_c << 2, members);
             const int sum_o = __builtin_amdgcn_ds_bpermute(sum_c << 2, run_start);

@@ -30,69 +30,20 @@
 
 #define RO_LIST_K 32     // source pixels remembered per target cell; a cell with more is summed by a scan over the level
 
-#if SF_REFORDER
-
-// ONE product shortcut back on at a time (attribution builds, tools/build_variant.sh):
-#ifndef SF_RO_SPLAT
-#define SF_RO_SPLAT 1   // 0: the product's exact integer splat sums (divided with IEEE division)
-#endif
-// ... or only at some levels of the pyramid: the ordered float splat runs at image levels [SF_RO_SPLAT_MIN_LEVEL, SF_RO_SPLAT_MAX_LEVEL]
-// (0 = full resolution), the product's integer sums (IEEE division) at the others -- which levels carry the sensitivity
-#ifndef SF_RO_SPLAT_MIN_LEVEL
-#define SF_RO_SPLAT_MIN_LEVEL 0
-#endif
-#ifndef SF_RO_SPLAT_MAX_LEVEL
-#define SF_RO_SPLAT_MAX_LEVEL 99
-#endif
-#define RO_SPLAT_AT(L) (SF_RO_SPLAT && (L) >= SF_RO_SPLAT_MIN_LEVEL && (L) <= SF_RO_SPLAT_MAX_LEVEL)
-#ifndef SF_RO_ROWS
-#define SF_RO_ROWS 1    // 0: the product's factored rows / three dot products (with SF_ROWS_FMA as given)
-#endif
-#ifndef SF_RO_P1_FP64
-#define SF_RO_P1_FP64 1 // 0: the product's fp32 lane sums, flushed into fp64 every SF_P1_FLUSH pixel pairs
-#endif
-#ifndef SF_RO_LABSUM
-#define SF_RO_LABSUM 1  // 0: the product's exact Q32.32 per-cluster sums
-#endif
-#ifndef SF_RO_JACOBI
-#define SF_RO_JACOBI 1  // 0: the product's round-robin Jacobi
-#endif
-#ifndef SF_RO_INIT_RES
-#define SF_RO_INIT_RES 1  // 0: the product's initial mean |res| from the linearisation's scaled sums
-#endif
-#ifndef SF_RO_BEHIND
-#define SF_RO_BEHIND 1  // 0: the product's rule for points warped behind the camera
-#endif
-
-#define RO_CHUNK 1024    // pixels per trip of the ordered per-cluster sums
-
-struct RoChunk {
-    float val[RO_CHUNK];
-    uint8_t lab[RO_CHUNK];   // cluster of the entry, SF_INVALID_LABEL: no entry
-    uint8_t flag[RO_CHUNK];  // bit 0: counts as non-Null / contributes `val`; bit 1: in validPixels
-};
-
 // ---------------------------------------------------------------------------------------------
-//  sequential per-cluster float sums in pixel order: 24 lanes, one per cluster, walk the chunk front to back
+//  ALL builds: the ordered float splat for the COARSE levels of the product (round 4). The attribution of
+//  profiles/PARITY.md says where the product's pose excursions come from: with everything else as in the product, the
+//  reference's ordered float sums at the coarse levels alone take 42 % of the frames past the pose bar and 44 % of the
+//  iteration-count mismatches away (5000 sequences at 160 x 120: 38 -> 22 frames, 25 -> 14) -- those levels hold 6 % of the
+//  pixels, so an order per cell is affordable there. Levels of at most SF_ORDERED_SPLAT_MAX_PIXELS pixels (QVGA: image levels
+//  2, 3, 4) take ro_splat below in every build of the product; larger levels keep the exact integer sums (sf_device_common.h).
+//  The per-cell source lists are scratch of the WORKGROUP that runs the warp (KArgs::ro_list: one block per resident
+//  workgroup, 1 MB), not of the stream.
 // ---------------------------------------------------------------------------------------------
-struct RoLabelAcc {
-    float sum;
-    int n_all, n_val, n_valid;  // entries of the cluster, entries with bit 0, entries with bit 1
-};
-__device__ __forceinline__ void ro_label_walk(const LDS RoChunk &c, int m, int tid, RoLabelAcc &a) {
-    if (tid < SF_NC) {
-        for (int q = 0; q < m; q++) {
-            if ((int)c.lab[q] != tid) continue;
-            const int f = c.flag[q];
-            a.n_all++;
-            if (f & 1) {
-                a.n_val++;
-                a.sum += c.val[q];  // the reference's `+=` on a float, in the reference's pixel order
-            }
-            if (f & 2) a.n_valid++;
-        }
-    }
-}
+#ifndef SF_ORDERED_COARSE_SPLAT
+#define SF_ORDERED_COARSE_SPLAT 1
+#endif
+#define SF_ORDERED_SPLAT_MAX_PIXELS 8192  // (= SF_CLUSTER_SOLO_PIXELS: a cluster's workgroups run such levels each on its own)
 
 // ---------------------------------------------------------------------------------------------
 //  the splat of warpImagesAccurateInverse / computeResidualsAgainstPreviousImage in the reference's order
@@ -100,6 +51,7 @@ __device__ __forceinline__ void ro_label_walk(const LDS RoChunk &c, int m, int t
 struct RoTaps {
     int n;          // 0: rejected, 1: within 5 centi-pixels of a pixel centre (weight 200), 4: bilinear
     int cell[4];    // flat index of the target cells, taps in the reference's order ur, ul, dr, dl (:846-867)
+    int tv[4], tu[4];  // ... and their (row, column)
     int w[4];
     float depth_w, inten_w;
 };
@@ -123,15 +75,18 @@ __device__ __forceinline__ void ro_project(const SplatGeom &g, const Src &src, c
     t.inten_w = iw;
     if (min(delta_r, delta_l) + min(delta_u, delta_d) < 5) {
         t.n = 1;
-        t.cell[0] = (delta_u > delta_d ? qv : qv + 1) + (delta_r > delta_l ? qu : qu + 1) * g.rows_i;
+        t.tv[0] = delta_u > delta_d ? qv : qv + 1;
+        t.tu[0] = delta_r > delta_l ? qu : qu + 1;
         t.w[0] = 200;
     } else {
         t.n = 4;
-        t.cell[0] = (qv + 1) + (qu + 1) * g.rows_i;  t.w[0] = delta_l + delta_d;
-        t.cell[1] = (qv + 1) + qu * g.rows_i;        t.w[1] = delta_r + delta_d;
-        t.cell[2] = qv + (qu + 1) * g.rows_i;        t.w[2] = delta_l + delta_u;
-        t.cell[3] = qv + qu * g.rows_i;              t.w[3] = delta_r + delta_u;
+        t.tv[0] = qv + 1;  t.tu[0] = qu + 1;  t.w[0] = delta_l + delta_d;
+        t.tv[1] = qv + 1;  t.tu[1] = qu;      t.w[1] = delta_r + delta_d;
+        t.tv[2] = qv;      t.tu[2] = qu + 1;  t.w[2] = delta_l + delta_u;
+        t.tv[3] = qv;      t.tu[3] = qu;      t.w[3] = delta_r + delta_u;
     }
+#pragma unroll
+    for (int k = 0; k < 4; k++) t.cell[k] = t.tv[k] + t.tu[k] * g.rows_i;  // (taps beyond t.n are not read)
 }
 
 // After the call cell idx of the level holds: acc_i[idx] != 0 <=> some source pixel reached it (wacu != 0), and then
@@ -197,4 +152,261 @@ __device__ __forceinline__ void ro_unpack_cell(long long sd, float &dw, float &i
     iw = __uint_as_float((unsigned)((unsigned long long)sd >> 32));
 }
 
+// The same sums for a level of at most SPLAT_TV rows, WITHOUT lists in memory: such a level is walked in tiles of SPLAT_TU
+// whole columns, i.e. in the reference's source order; a tile's targets lie in a window of the warped image that is kept in
+// LDS as three running float sums per cell. The window is LOADED from the cells (the running sums of earlier tiles), the
+// tile's taps are added in ascending source index per cell, and the window is stored back. The order inside a tile comes
+// from rounds: every pending tap posts its source index to its cell with ds_min, the tap whose index the cell then holds is
+// the cell's next contribution in the reference's order -- it is added (a plain read-modify-write: a cell has one owner per
+// round) and the cell is released; as many rounds as the most contested cell of the tile has taps (4 - 8). A tap outside its
+// tile's window (the window is the tile's size + SPLAT_MARGIN: strong local stretch) ends the attempt: the caller then takes
+// ro_splat above for the whole level. Returns (uniformly) whether the cells hold the result, in ro_splat's format.
+template <class Src>
+__device__ __forceinline__ bool ordered_tile_splat(const SplatGeom &g, const LevelCoord &lc, int rows_i, int cols_i, const Src &src,
+                                                   gptr<long long> acc_d, gptr<long long> acc_i, LDS SplatWin &win, int tid) {
+    const int lane = tid & 63, n = rows_i * cols_i;
+    LDS vfloat2 *sums = (LDS vfloat2 *)win.d;  // {sum w depth, sum w intensity} of a window cell
+    LDS float *wsum = (LDS float *)win.i;      // [2 c]: sum w; [2 c + 1] (as unsigned): the smallest pending source index
+    LDS unsigned *owner = (LDS unsigned *)win.i;
+    for (int idx = tid; idx < n; idx += SF_NT) {
+        gst(acc_d, idx, 0ll);
+        gst(acc_i, idx, 0ll);
+    }
+    __syncthreads();
+    const int tiles = (cols_i + SPLAT_TU - 1) / SPLAT_TU;
+    for (int t = 0; t < tiles; t++) {
+        const int tu0 = t * SPLAT_TU;
+        RoTaps tp[SPLAT_PX];
+        unsigned sidx[SPLAT_PX];
+        int vtop = 0, utop = 0;
+        if (tid == 0) {
+            win.vmin = 0x7fffffff;
+            win.umin = 0x7fffffff;
+            win.ovf[0] = win.ovf[1] = win.ovf[2] = 0;  // workgroup-wide flags of this tile (set with ds_or, read behind a barrier)
+        }
+#pragma unroll
+        for (int k = 0; k < SPLAT_PX; k++) {
+            const int v = lane, u = tu0 + (tid >> 6) + k * (SF_NT / 64);
+            tp[k].n = 0;
+            sidx[k] = (unsigned)(v + u * rows_i);
+            if (v < rows_i && u < cols_i) ro_project(g, src, lc, (int)sidx[k], tp[k]);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (q < tp[k].n) {
+                    vtop = max(vtop, 0x7fffffff - tp[k].tv[q]);
+                    utop = max(utop, 0x7fffffff - tp[k].tu[q]);
+                }
+        }
+        SF_DPP_REDUCE(vtop, dpp_i32, sf_op_maxi)
+        SF_DPP_REDUCE(utop, dpp_i32, sf_op_maxi)
+        // (read lane 63 HERE, by every lane: inside the lane-0 block below the compiler sinks the last v_max of the
+        // reduction into that block, where lane 63 does not execute it -- umin came out as "no tap" for levels of < 64 rows)
+        const int vmin = 0x7fffffff - __builtin_amdgcn_readlane(vtop, 63), umin = 0x7fffffff - __builtin_amdgcn_readlane(utop, 63);
+        __syncthreads();  // origin initialised; the previous tile's window stored
+        if (lane == 0) {
+            lds_min(&win.vmin, vmin);
+            lds_min(&win.umin, umin);
+        }
+        __syncthreads();
+        const int wv0 = uniform_i(win.vmin), wu0 = uniform_i(win.umin);
+        if (wu0 == 0x7fffffff) continue;  // no source pixel of the tile reaches the image
+        // the running sums of the window's cells
+        for (int q = tid; q < WIN_CELLS; q += SF_NT) {
+            const int du = q / WIN_V, dv = q - du * WIN_V;
+            const int v = wv0 + dv, u = wu0 + du;
+            vfloat2 s2 = {0.f, 0.f};
+            float w = 0.f;
+            if (v < rows_i && u < cols_i) {
+                const long long sd = gld_agent_i64(acc_d, v + u * rows_i), si = gld_agent_i64(acc_i, v + u * rows_i);
+                float sx, sy;
+                ro_unpack_cell(sd, sx, sy);
+                s2.x = sx;
+                s2.y = sy;
+                w = __uint_as_float((unsigned)((unsigned long long)si & 0xffffffffu));
+            }
+            sums[q] = s2;
+            wsum[2 * q] = w;
+            owner[2 * q + 1] = 0xffffffffu;
+        }
+        // window-local cell of every tap
+        int cell[SPLAT_PX][4];
+        unsigned pend = 0;
+        bool outside = false;
+#pragma unroll
+        for (int k = 0; k < SPLAT_PX; k++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                cell[k][q] = 0;
+                if (q < tp[k].n) {
+                    const int dv = tp[k].tv[q] - wv0, du = tp[k].tu[q] - wu0;  // >= 0: the origin is the tile's minimum
+                    if (dv < WIN_V && du < WIN_U) {
+                        cell[k][q] = dv + du * WIN_V;
+                        pend |= 1u << (4 * k + q);
+                    } else {
+                        outside = true;
+                    }
+                }
+            }
+        if (outside) lds_or(&win.ovf[2], 1u);
+        __syncthreads();  // the window is loaded, the flag complete
+        if (uniform_i((int)win.ovf[2]) != 0) return false;
+        for (int round = 0;; round++) {
+#pragma unroll
+            for (int k = 0; k < SPLAT_PX; k++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (pend & (1u << (4 * k + q))) lds_min(&owner[2 * cell[k][q] + 1], sidx[k]);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < SPLAT_PX; k++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if ((pend & (1u << (4 * k + q))) && owner[2 * cell[k][q] + 1] == sidx[k]) {
+                        const int c = cell[k][q];
+                        const float wf = (float)tp[k].w[q];
+                        vfloat2 s2 = sums[c];
+                        s2.x += wf * tp[k].depth_w;
+                        s2.y += wf * tp[k].inten_w;
+                        sums[c] = s2;
+                        wsum[2 * c] += wf;
+                        owner[2 * c + 1] = 0xffffffffu;  // (a lane that still reads it sees the winner's index or this: not its own)
+                        pend &= ~(1u << (4 * k + q));
+                    }
+            // anybody left? Two flags take turns: the one of the next round is cleared while nobody reads or sets it
+            if (pend != 0) lds_or(&win.ovf[round & 1], 1u);
+            if (tid == 0) win.ovf[(round + 1) & 1] = 0;
+            __syncthreads();
+            if (uniform_i((int)win.ovf[round & 1]) == 0) break;
+            if (round >= 4 * SPLAT_TV * SPLAT_TU) return false;  // (cannot happen: a round retires a tap of every contested cell; never spin on a bug)
+        }
+        for (int q = tid; q < WIN_CELLS; q += SF_NT) {
+            const int du = q / WIN_V, dv = q - du * WIN_V;
+            const int v = wv0 + dv, u = wu0 + du;
+            if (v < rows_i && u < cols_i) {
+                const vfloat2 s2 = sums[q];
+                gst(acc_d, v + u * rows_i, (long long)(((unsigned long long)__float_as_uint(s2.y) << 32) | __float_as_uint(s2.x)));
+                gst(acc_i, v + u * rows_i, (long long)(unsigned long long)__float_as_uint(wsum[2 * q]));
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n; idx += SF_NT) {  // the quotients (:876-880); untouched cells keep acc_i == 0
+        const long long si = gld_agent_i64(acc_i, idx);
+        const float w = __uint_as_float((unsigned)((unsigned long long)si & 0xffffffffu));
+        if (w != 0.f) {
+            float ds, is;
+            ro_unpack_cell(gld_agent_i64(acc_d, idx), ds, is);
+            const float iw = is / w, dw = ds / w;
+            gst(acc_d, idx, (long long)(((unsigned long long)__float_as_uint(iw) << 32) | __float_as_uint(dw)));
+            gst(acc_i, idx, 1ll);
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
+// the ordered float splat of a level: in LDS tiles when the level is at most one tile high, else (or when a tile's targets
+// do not fit its window) through the per-cell lists
+template <class Src>
+__device__ __forceinline__ void ordered_splat(const KArgs &a, const SplatGeom &g, const LevelCoord &lc, int rows_i, int cols_i,
+                                              const Src &src, gptr<long long> acc_d, gptr<long long> acc_i, gptr<int> list,
+                                              LDS SplatWin &win, int tid) {
+    if (rows_i <= SPLAT_TV && ordered_tile_splat(g, lc, rows_i, cols_i, src, acc_d, acc_i, win, tid)) return;
+    ro_splat(g, lc, rows_i * cols_i, src, acc_d, acc_i, list, tid);
+}
+
+#if SF_REFORDER
+
+// ONE product shortcut back on at a time (attribution builds, tools/build_variant.sh):
+#ifndef SF_RO_SPLAT
+#define SF_RO_SPLAT 1   // 0: the product's exact integer splat sums (divided with IEEE division)
+#endif
+// ... or only at some levels of the pyramid: the ordered float splat runs at image levels [SF_RO_SPLAT_MIN_LEVEL, SF_RO_SPLAT_MAX_LEVEL]
+// (0 = full resolution), the product's integer sums (IEEE division) at the others -- which levels carry the sensitivity
+#ifndef SF_RO_SPLAT_MIN_LEVEL
+#define SF_RO_SPLAT_MIN_LEVEL 0
+#endif
+#ifndef SF_RO_SPLAT_MAX_LEVEL
+#define SF_RO_SPLAT_MAX_LEVEL 99
+#endif
+#define RO_SPLAT_AT(L) (SF_RO_SPLAT && (L) >= SF_RO_SPLAT_MIN_LEVEL && (L) <= SF_RO_SPLAT_MAX_LEVEL)
+#ifndef SF_RO_ROWS
+#define SF_RO_ROWS 1    // 0: the product's factored rows / three dot products (with SF_ROWS_FMA as given)
+#endif
+#ifndef SF_RO_P1_FP64
+#define SF_RO_P1_FP64 1 // 0: the product's fp32 lane sums, flushed into fp64 every SF_P1_FLUSH pixel pairs
+#endif
+#ifndef SF_RO_LABSUM
+#define SF_RO_LABSUM 1  // 0: the product's exact Q32.32 per-cluster sums
+#endif
+#ifndef SF_RO_JACOBI
+#define SF_RO_JACOBI 1  // 0: the product's round-robin Jacobi
+#endif
+#ifndef SF_RO_INIT_RES
+#define SF_RO_INIT_RES 1  // 0: the product's initial mean |res| from the linearisation's scaled sums
+#endif
+#ifndef SF_RO_BEHIND
+#define SF_RO_BEHIND 1  // 0: the product's rule for points warped behind the camera
+#endif
+
+#define RO_CHUNK 1024    // pixels per trip of the ordered per-cluster sums
+
+struct RoChunk {
+    float val[RO_CHUNK];
+    uint8_t lab[RO_CHUNK];   // cluster of the entry, SF_INVALID_LABEL: no entry
+    uint8_t flag[RO_CHUNK];  // bit 0: counts as non-Null / contributes `val`; bit 1: in validPixels
+};
+
+// ---------------------------------------------------------------------------------------------
+//  sequential per-cluster float sums in pixel order: 24 lanes, one per cluster, walk the chunk front to back
+// ---------------------------------------------------------------------------------------------
+struct RoLabelAcc {
+    float sum;
+    int n_all, n_val, n_valid;  // entries of the cluster, entries with bit 0, entries with bit 1
+};
+__device__ __forceinline__ void ro_label_walk(const LDS RoChunk &c, int m, int tid, RoLabelAcc &a) {
+    if (tid < SF_NC) {
+        for (int q = 0; q < m; q++) {
+            if ((int)c.lab[q] != tid) continue;
+            const int f = c.flag[q];
+            a.n_all++;
+            if (f & 1) {
+                a.n_val++;
+                a.sum += c.val[q];  // the reference's `+=` on a float, in the reference's pixel order
+            }
+            if (f & 2) a.n_valid++;
+        }
+    }
+}
+
 #endif  // SF_REFORDER
+
+#if SF_REFORDER
+#define RO_SPLAT_AT_(L) RO_SPLAT_AT(L)
+#else
+#define RO_SPLAT_AT_(L) false
+#endif
+// does level L (n pixels) of this launch take the ordered float splat? G: workgroups that share the level right now
+__device__ __forceinline__ bool splat_ordered(int L, int n, int G) {
+#if SF_REFORDER
+    (void)n; (void)G;
+    return RO_SPLAT_AT_(L);
+#else
+    (void)L;
+    return SF_ORDERED_COARSE_SPLAT && G == 1 && n <= SF_ORDERED_SPLAT_MAX_PIXELS;
+#endif
+}
+// the source lists this workgroup uses: the record slot's (reference-order build: every level, any size) or the workgroup's own block
+__device__ __forceinline__ gptr<int> ro_list_of(const KArgs &a, size_t rb, int b) {
+#if SF_REFORDER
+    (void)b;
+    return as_global(a.ro_list + rb * RO_LIST_K);
+#else
+    // a block per stream when the handle has one for each (two frames of a stream never run at the same time), else a block
+    // per workgroup of the launch (the grid never exceeds KArgs::ro_blocks then); a cluster's workgroups each take their own
+    (void)rb;
+    const size_t blk = (a.cluster_g == 0 && a.batch <= a.ro_blocks) ? (size_t)b : (size_t)blockIdx.x;
+    return as_global(a.ro_list + blk * SF_ORDERED_SPLAT_MAX_PIXELS * RO_LIST_K);
+#endif
+}
+

@@ -61,11 +61,8 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
         s.lab_sum[tid] = 0;
         s.lab_cnt[tid] = 0;
     }
-#if SF_REFORDER && SF_RO_SPLAT
-    const bool lazy = RO_SPLAT_AT(0) || splat_lazy_ok(rows, cols, G);  // (ro_splat initialises every cell)
-#else
-    const bool lazy = splat_lazy_ok(rows, cols, G);  // see solve_warp
-#endif
+    const bool ordered = splat_ordered(0, n, G);  // full resolution: the reference-order build, or an image of at most 8192 pixels
+    const bool lazy = ordered || splat_lazy_ok(rows, cols, G);  // see solve_warp
     if (!lazy)
     for (int idx = tid + rank * SF_NT; idx < n; idx += SF_NT * G) {  // agent-scope stores: see solve_warp
         if (G > 1) {
@@ -103,12 +100,10 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
             return z != 0.f && dc != 0.f;
         }
     } src{dbuf, ibuf, dcur, inv_f_i, g.disp_u_i, g.disp_v_i};
-#if SF_REFORDER && SF_RO_SPLAT
-    if (RO_SPLAT_AT(0)) {
+    if (ordered) {
         LevelCoord lc0 = level_coord(a, 0);
-        ro_splat(g, lc0, n, src, acc_d, acc_i, as_global(a.ro_list + rb * RO_LIST_K), tid);
+        ordered_splat(a, g, lc0, rows, cols, src, acc_d, acc_i, ro_list_of(a, rb, b), s.win, tid);
     } else
-#endif
         tiled_splat(g, rows, cols, src, acc_d, acc_i, s.win, s.marks, tid, rank, G, lazy, &st.prof[PF_SPLAT_REPLAYS]);
     cluster_rendezvous(cs, tid);
 
@@ -132,7 +127,7 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
                     }
                     if (si != 0 && dc != 0.f) {
                         float dw, iw;
-                        if (RO_SPLAT_AT(0))
+                        if (ordered)
                             ro_unpack_cell(sd, dw, iw);
                         else
                             normalise_acc(sd, si, dw, iw);
@@ -202,7 +197,10 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
         for (int k = 0; k < SF_LOAD_BATCH; k++) {
             if (!(base + k * SF_NT < px_end && si[k] != 0 && dc[k] != 0.f)) continue;
             float dw, iw;
-            normalise_acc(sd[k], si[k], dw, iw);
+            if (ordered)
+                ro_unpack_cell(sd[k], dw, iw);
+            else
+                normalise_acc(sd[k], si[k], dw, iw);
             if (dw == 0.f || lb[k] >= SF_NC) continue;
             // intensity_diff is intensityCurrent where both depths are valid, else 0 (:937,1022)
             const float idiff = (db[k] != 0.f) ? ic[k] : 0.f;

@@ -240,12 +240,9 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
     if (tid == 0) inverse4_cm(s.T, s.Tinv, s.dwork);  // T = T_odometry.inverse()  (:800)
     // a cluster's workgroups zero every G-th block. Agent-scope (write-through) stores: the cells are only ever touched by
     // agent-scope atomics and atomic loads after this, so the two hand-overs below need no fence (sf_cluster.h)
-#if SF_REFORDER && SF_RO_SPLAT
-    const bool ordered = RO_SPLAT_AT(L);
-    const bool lazy = ordered || splat_lazy_ok(rows_i, cols_i, G);  // (ordered: nothing to zero, ro_splat initialises every cell)
-#else
-    const bool lazy = splat_lazy_ok(rows_i, cols_i, G);  // one workgroup: the splat zeroes the cells itself, window by window
-#endif
+    // coarse levels (and every level of the reference-order build): the reference's float sums in the reference's order
+    const bool ordered = splat_ordered(L, n, G);
+    const bool lazy = ordered || splat_lazy_ok(rows_i, cols_i, G);  // one workgroup: the splat zeroes / initialises the cells itself
     if (!lazy)
     for (int idx = tid + rank * SF_NT; idx < n; idx += SF_NT * G) {
         if (G > 1) {
@@ -281,11 +278,9 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
             return z != 0.f;
         }
     } src{dpred, ipred, level_coord(a, L)};
-#if SF_REFORDER && SF_RO_SPLAT
     if (ordered)
-        ro_splat(g, level_coord(a, L), n, src, acc_d, acc_i, as_global(a.ro_list + rb * RO_LIST_K), tid);  // the reference's float sums, in its order
+        ordered_splat(a, g, level_coord(a, L), rows_i, cols_i, src, acc_d, acc_i, ro_list_of(a, rb, b), s.win, tid);
     else
-#endif
         tiled_splat(g, rows_i, cols_i, src, acc_d, acc_i, s.win, s.marks, tid, rank, G, lazy, &a.state[b].prof[PF_SPLAT_REPLAYS]);
     cluster_rendezvous(cs, tid);  // all atomics of the workgroup(s) performed: the linearisation reads the cells with atomic loads
 }
@@ -314,6 +309,7 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
     const auto rec_lab = as_global(a.rec_lab + rb);
     const bool seg = a.p.segmentation_enabled != 0;
     const bool dbg = a.p.debug_planes != 0;
+    const bool ordered = splat_ordered(L, a.ln[L], G);  // what solve_warp left in the accumulator cells of this level
     if (tid == 0) s.first = first ? 1 : 0;
 
     const float f = float(cols_i) / (2.f * a.tan_half_fovh);
@@ -382,11 +378,9 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
                     dw = __uint_as_float((unsigned)((unsigned long long)pf_ad[q] & 0xffffffffu));
                     iw = __uint_as_float((unsigned)((unsigned long long)pf_ad[q] >> 32));
                 } else if (pf_ai[q] != 0) {  // normalise the warp accumulators (reference :876-881); touched <=> sum(w) > 0
-#if SF_REFORDER && SF_RO_SPLAT
-                    if (RO_SPLAT_AT(L))
+                    if (ordered)
                         ro_unpack_cell(pf_ad[q], dw, iw);  // already divided, in the reference's order (ro_splat)
                     else
-#endif
                         normalise_acc(pf_ad[q], pf_ai[q], dw, iw);
                 }
             }

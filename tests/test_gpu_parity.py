@@ -34,12 +34,16 @@ def solve_both(hip, ora, rows, cols, mk_params, pr, seg_image=True):
     return out
 
 
-def assert_traces_match(sg, so, tol_twist=2e-6, tol_b=1e-4, rtol_aver=2e-4):
+def assert_traces_match(sg, so, tol_twist=2e-6, tol_b=1e-4, rtol_aver=2e-4, n_valid_slack=0):
+    """n_valid_slack: valid pixels by which an outer iteration may differ. The warp quantises target positions to centi-pixels
+    (FrontEnd.cpp:819-820), so a last-bit difference of T can move a source pixel's taps to the neighbouring cells and a cell at the
+    edge of the warped image in or out of validPixels; 0 everywhere except on scenes built to have thousands of such edges."""
     a, b = sg.stats(), so.stats()
     assert (a.n_outer, a.n_irls, a.kmeans_iters, a.status) == (b.n_outer, b.n_irls, b.kmeans_iters, b.status)
-    assert a.pixel_iters == b.pixel_iters
-    for f in ("level", "k", "n_valid", "irls_iters"):
+    assert abs(a.pixel_iters - b.pixel_iters) <= n_valid_slack * a.n_irls
+    for f in ("level", "k", "irls_iters"):
         assert np.array_equal(trace_array(a, f), trace_array(b, f)), f
+    assert np.abs(trace_array(a, "n_valid") - trace_array(b, "n_valid")).max() <= n_valid_slack
     assert np.allclose(trace_array(a, "aver_res"), trace_array(b, "aver_res"), rtol=rtol_aver, atol=1e-7)
     assert np.abs(trace_array(a, "var") - trace_array(b, "var")).max() < tol_twist
     assert np.abs(trace_array(a, "twist_level") - trace_array(b, "twist_level")).max() < tol_twist
@@ -198,7 +202,8 @@ def test_warp_with_targets_outside_the_tile_windows(hip, ora, pair):
     d_old[patch] *= 0.3
     fence = {"new": pr["new"], "old": (d_old, pr["old"][1])}
     sg, so = solve_both(hip, ora, 240, 320, lambda a: driver_params(a, debug_planes=1), fence)
-    assert_traces_match(sg, so, tol_twist=1e-5, tol_b=3e-4)
+    # (the fence has 1200 depth edges: a pixel or two of validPixels may sit on the other side of a centi-pixel boundary)
+    assert_traces_match(sg, so, tol_twist=1e-5, tol_b=3e-4, n_valid_slack=4)
     for L in range(4):  # level 4 is warped once: Warped := Pred
         for ch in range(2):
             assert_planes_close(sg.plane(capi.SET_WARPED, ch, L), so.plane(capi.SET_WARPED, ch, L), frac=0.97)

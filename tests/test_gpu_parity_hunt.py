@@ -175,7 +175,9 @@ def test_excursion_rates_against_the_gemm2_control(hip, ora):
     assert frames == ctl["frames"]
     print("%s: %s; control %s" % (hip.default_variant, got, {k: ctl[k] for k in got}))
     for k, v in got.items():
-        assert v <= 2 * ctl[k], (k, v, ctl[k])
+        # twice the control's count; for counts of one or two a factor of two is not a statistical statement (a Poisson count
+        # with mean 2 reaches 5 in one sample of twenty): control + 3 then
+        assert v <= max(2 * ctl[k], ctl[k] + 3), (k, v, ctl[k])
 
 
 def test_reference_order_build_is_bit_identical_to_the_oracle(ora):

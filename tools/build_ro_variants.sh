@@ -22,3 +22,6 @@ build jacobi_rr        RO_FLAGS="-DSF_RO_JACOBI=0"
 build init_res         RO_FLAGS="-DSF_RO_INIT_RES=0"
 build behind           RO_FLAGS="-DSF_RO_BEHIND=0"
 build all_shortcuts    RO_FLAGS="-DSF_RO_SPLAT=0 -DSF_RO_ROWS=0 -DSF_RO_P1_FP64=0 -DSF_RO_LABSUM=0 -DSF_RO_JACOBI=0 -DSF_RO_INIT_RES=0 -DSF_RO_BEHIND=0" RO_FAST_WEIGHTS=1 RO_ROWS_FMA=1 RO_FAST_NORMALISE=1
+# the product's arithmetic everywhere EXCEPT the warp / residual splat of the coarse levels (image levels >= 2: 6 300 of 102 300 pixels at
+# QVGA), which adds the reference's floats in the reference's order: what an ordered coarse splat in the product would buy
+build all_but_coarse_splat RO_FLAGS="-DSF_RO_SPLAT_MIN_LEVEL=2 -DSF_RO_ROWS=0 -DSF_RO_P1_FP64=0 -DSF_RO_LABSUM=0 -DSF_RO_JACOBI=0 -DSF_RO_INIT_RES=0 -DSF_RO_BEHIND=0" RO_FAST_WEIGHTS=1 RO_ROWS_FMA=1 RO_FAST_NORMALISE=1

@@ -34,16 +34,18 @@
 //  ALL builds: the ordered float splat for the COARSE levels of the product (round 4). The attribution of
 //  profiles/PARITY.md says where the product's pose excursions come from: with everything else as in the product, the
 //  reference's ordered float sums at the coarse levels alone take 42 % of the frames past the pose bar and 44 % of the
-//  iteration-count mismatches away (5000 sequences at 160 x 120: 38 -> 22 frames, 25 -> 14) -- those levels hold 6 % of the
-//  pixels, so an order per cell is affordable there. Levels of at most SF_ORDERED_SPLAT_MAX_PIXELS pixels (QVGA: image levels
-//  2, 3, 4) take ro_splat below in every build of the product; larger levels keep the exact integer sums (sf_device_common.h).
-//  The per-cell source lists are scratch of the WORKGROUP that runs the warp (KArgs::ro_list: one block per resident
-//  workgroup, 1 MB), not of the stream.
+//  iteration-count mismatches away (5000 sequences at 160 x 120: 38 -> 22 frames, 25 -> 14). Levels of at most
+//  SF_ORDERED_SPLAT_MAX_PIXELS pixels (QVGA: image levels 3 and 4, 1.5 % of the pyramid's pixels; with 8192 -- level 2 as well --
+//  the excursions were the same within their noise and the cost double) take the ordered splat below in every build of the
+//  product; larger levels keep the exact integer sums (sf_device_common.h). The per-cell source lists of the fall-back are
+//  scratch of the WORKGROUP that runs the warp (KArgs::ro_list: one block of 256 KB per stream or resident workgroup).
 // ---------------------------------------------------------------------------------------------
 #ifndef SF_ORDERED_COARSE_SPLAT
 #define SF_ORDERED_COARSE_SPLAT 1
 #endif
-#define SF_ORDERED_SPLAT_MAX_PIXELS 8192  // (= SF_CLUSTER_SOLO_PIXELS: a cluster's workgroups run such levels each on its own)
+#ifndef SF_ORDERED_SPLAT_MAX_PIXELS
+#define SF_ORDERED_SPLAT_MAX_PIXELS 2048  // (<= SF_CLUSTER_SOLO_PIXELS: a cluster's workgroups run such levels each on its own)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 //  the splat of warpImagesAccurateInverse / computeResidualsAgainstPreviousImage in the reference's order
@@ -311,7 +313,10 @@ template <class Src>
 __device__ __forceinline__ void ordered_splat(const KArgs &a, const SplatGeom &g, const LevelCoord &lc, int rows_i, int cols_i,
                                               const Src &src, gptr<long long> acc_d, gptr<long long> acc_i, gptr<int> list,
                                               LDS SplatWin &win, int tid) {
-    if (rows_i <= SPLAT_TV && ordered_tile_splat(g, lc, rows_i, cols_i, src, acc_d, acc_i, win, tid)) return;
+#ifndef SF_ORDERED_TILE_SPLAT
+#define SF_ORDERED_TILE_SPLAT 1  // 0: always the lists (A/B and bisection builds)
+#endif
+    if (SF_ORDERED_TILE_SPLAT && rows_i <= SPLAT_TV && ordered_tile_splat(g, lc, rows_i, cols_i, src, acc_d, acc_i, win, tid)) return;
     ro_splat(g, lc, rows_i * cols_i, src, acc_d, acc_i, list, tid);
 }
 

@@ -102,7 +102,7 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
     } src{dbuf, ibuf, dcur, inv_f_i, g.disp_u_i, g.disp_v_i};
     if (ordered) {
         LevelCoord lc0 = level_coord(a, 0);
-        ordered_splat(a, g, lc0, rows, cols, src, acc_d, acc_i, ro_list_of(a, rb, b), s.win, tid);
+        ro_splat(g, lc0, n, src, acc_d, acc_i, ro_list_of(a, rb, b), tid);  // (full resolution: the per-cell lists; the LDS tiles serve the solver's coarse levels)
     } else
         tiled_splat(g, rows, cols, src, acc_d, acc_i, s.win, s.marks, tid, rank, G, lazy, &st.prof[PF_SPLAT_REPLAYS]);
     cluster_rendezvous(cs, tid);

@@ -182,3 +182,17 @@ def test_cluster_variant_is_refused(ro):
 
     with pytest.raises(sf.SfError, match="reference-order"):
         sf.Solver(ro, 120, 160, 1, ro.default_params_struct(), variant="cluster")
+
+
+def test_ordered_tile_splat_equals_the_list_splat(tmp_path):
+    """The product's ordered float splat of the coarse levels (`ordered_tile_splat`: LDS-resident tiles, rounds of ds_min) against
+    the per-cell source lists of the reference-order build (`ro_splat`), in isolation: one workgroup, synthetic levels from 8 x 8 to 64 x 100 pixels (odd sizes included) with holes under a rigid warp -- every cell bit for bit (tools/micro/ordered_splat_check.hip)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ordered_splat_check")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+                           "-Wno-unused-function", "-Wno-unused-value", "-I", os.path.join(root, "staticfusion_amd", "csrc"), "-o", exe,
+                           os.path.join(root, "tools", "micro", "ordered_splat_check.hip")], timeout=600)
+    out = subprocess.check_output([exe], timeout=120).decode()
+    assert out.strip().endswith("OK") and out.count("differing cells 0") == 7, out

@@ -34,8 +34,9 @@ __global__ __launch_bounds__(SF_NT) void k(const float *d, const float *in, int 
 
 int main() {
     int bad_total = 0;
-    for (int rows : {15, 30, 60}) {
-        const int cols = rows * 4 / 3, n = rows * cols;
+    const int sizes[][2] = {{15, 20}, {30, 40}, {60, 80}, {50, 66}, {37, 51}, {64, 100}, {8, 8}};
+    for (auto &sz : sizes) {
+        const int rows = sz[0], cols = sz[1], n = rows * cols;
         std::vector<float> d(n), in(n);
         for (int u = 0; u < cols; u++)
             for (int v = 0; v < rows; v++) {

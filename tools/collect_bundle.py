@@ -19,9 +19,16 @@ def cp(src, dst=None):
 
 for f in ("bench_default.json", "bench_under_rocprof.json", "rocprofv3_stats_bench.csv", "stage_profiles.txt",
           "traffic_by_stage_sphere.txt", "traffic_by_stage_static.txt", "pass_microbench_b512.txt", "parity_report.md", "parity_report.json",
-          "b_summary.txt", "hunt_160x120_s5000_n240.json", "hunt_160x120_s20000_n1000.json", "hunt_qvga_s7000_n60.json",
-          "hunt_qvga_noseg_s7000_n60.json"):
+          "b_summary.txt"):
     cp("%s_%s" % (T, f))
+# the hunts: per-frame records compressed, the summaries beside them
+import gzip
+for f in sorted(os.listdir(G)):
+    if f.startswith("%s_hunt_" % T) and f.endswith(".json"):
+        dd = json.load(open(os.path.join(G, f)))
+        with gzip.open(os.path.join(P, f + ".gz"), "wt", compresslevel=9) as g:
+            json.dump(dd, g)
+        json.dump({k: dd[k] for k in ("meta", "summary") if k in dd}, open(os.path.join(P, f.replace(".json", "_summary.json")), "w"), indent=1)
 cp("%s_gputest.log" % T, "%s_gputest_three_variants.log" % T)
 for f in os.listdir(G):
     if f.startswith("traffic_") and f.endswith(".json") and "summary" not in f:

@@ -353,6 +353,9 @@ __device__ __forceinline__ void ordered_splat(const KArgs &a, const SplatGeom &g
 #ifndef SF_RO_BEHIND
 #define SF_RO_BEHIND 1  // 0: the product's rule for points warped behind the camera
 #endif
+#ifndef SF_RO_SEQ64
+#define SF_RO_SEQ64 1   // 0: the fp64 sums ([C1]: AtA / AtB, sum |res|, ||res||^2) as per-lane partial sums + a tree, not row by row
+#endif
 
 #define RO_CHUNK 1024    // pixels per trip of the ordered per-cluster sums
 
@@ -360,6 +363,19 @@ struct RoChunk {
     float val[RO_CHUNK];
     uint8_t lab[RO_CHUNK];   // cluster of the entry, SF_INVALID_LABEL: no entry
     uint8_t flag[RO_CHUNK];  // bit 0: counts as non-Null / contributes `val`; bit 1: in validPixels
+};
+
+// the [C1] sums of the oracle are fp64 sums of float terms, row after row. Partial sums per lane round differently in the
+// 16th digit, and once in some ten million sums that moves the float the sum is converted to (hunt seed 61826, frame 6):
+// the reference-order build walks them row by row too -- a chunk's terms go to LDS, one lane per sum adds them front to back
+struct RoChunk2 {  // sum |res| and ||res||^2: two float terms per pixel next to the per-cluster chunk
+    RoChunk c;
+    float rc[RO_CHUNK], rd[RO_CHUNK];
+};
+#define RO_ROWS_CHUNK 256
+struct RoRows {  // pass 1: the two weighted rows of a pixel, [entry][pixel]; entries 0..5 + 6 (Bw): colour row, 7..12 + 13: depth row
+    float aw[14][RO_ROWS_CHUNK];
+    uint8_t ok[RO_ROWS_CHUNK];
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -237,6 +237,38 @@ __device__ __noinline__ void ro_initial_residual(const KArgs &a, int b, int L, L
     const RoPlanes pl = ro_planes(a, b, L, s);
     const int lane = tid & 63, wave = tid >> 6;
     double t = 0.0;
+#if SF_RO_SEQ64
+    for (int base = c.begin; base < c.n; base += RO_CHUNK) {
+        for (int q = tid; q < RO_CHUNK; q += SF_NT) {
+            const int idx = base + q;
+            int lab = SF_INVALID_LABEL;
+            if (idx < c.n) {
+                RoRec r;
+                ro_load(pl, idx, r);
+                if (r.lab != SF_INVALID_LABEL) {
+                    RoPixel px;
+                    ro_pixel(c.g, idx, r, px);
+                    float ac, ad;
+                    ro_abs_b(px, ac, ad);
+                    s.ro2.rc[q] = ac;
+                    s.ro2.rd[q] = ad;
+                    lab = r.lab;
+                }
+            }
+            s.ro2.c.lab[q] = (uint8_t)lab;
+        }
+        __syncthreads();
+        if (tid == 0) {  // res.cwiseAbs().sumAll(): row after row ([C1])
+            const int m = min(RO_CHUNK, c.n - base);
+            for (int q = 0; q < m; q++) {
+                if (s.ro2.c.lab[q] == SF_INVALID_LABEL) continue;
+                t += (double)s.ro2.rc[q];
+                t += (double)s.ro2.rd[q];
+            }
+        }
+        __syncthreads();
+    }
+#else
     for (int idx = c.begin + tid; idx < c.n; idx += SF_NT) {
         RoRec r;
         ro_load(pl, idx, r);
@@ -248,7 +280,8 @@ __device__ __noinline__ void ro_initial_residual(const KArgs &a, int b, int L, L
         t += (double)ac;
         t += (double)ad;
     }
-    t = wave_sum_f64(t);
+#endif
+    t = wave_sum_f64(t);  // (row-by-row sums: lane 0 of wave 0 holds the sum, every other lane 0.0)
     if (lane == 0) s.red[wave][0] = t;
     __syncthreads();
     if (tid == 0) {
@@ -270,6 +303,61 @@ __device__ __noinline__ void ro_pass1(const KArgs &a, int b, int L, LDS SolveSha
     float Vr[6];
 #pragma unroll
     for (int q = 0; q < 6; q++) Vr[q] = uniform_f(s.Var[q]);
+#if SF_RO_SEQ64 && SF_RO_P1_FP64
+    // AtA / AtB row by row ([C1]): the weighted rows of a chunk of pixels go to LDS, lane q < 27 owns sum q and adds the products
+    // of the colour row, then of the depth row, pixel after pixel
+    int ei = 0, ej = 6;  // the two row entries whose product this lane sums (21 + i: entry i times Bw)
+    if (tid < 21) {
+        int q = 0;
+        for (int i = 0; i < 6; i++)
+            for (int j = i; j < 6; j++, q++)
+                if (q == tid) { ei = i; ej = j; }
+    } else if (tid < 27) {
+        ei = tid - 21;
+    }
+    double sum = 0.0;
+    for (int base = c.begin; base < c.n; base += RO_ROWS_CHUNK) {
+        for (int q = tid; q < RO_ROWS_CHUNK; q += SF_NT) {
+            const int idx = base + q;
+            bool ok = false;
+            if (idx < c.n) {
+                RoRec r;
+                ro_load(pl, idx, r);
+                if (r.lab != SF_INVALID_LABEL) {
+                    RoPixel px;
+                    ro_pixel(c.g, idx, r, px);
+                    float res_c, res_d;
+                    ro_residuals(px, Vr, res_c, res_d);  // the residuals of the previous iteration's solution (-B for the first)
+                    const float b_weight = std_max(0.f, std_min(1.f, s.b_segm[r.lab]));
+                    const float w_c = b_weight * vrsq(1.f + sqf(res_c * inv_c_Cauchy));
+                    const float w_d = b_weight * vrsq(1.f + sqf(res_d * inv_c_Cauchy));
+                    float awc[7], awd[7];
+                    ro_weighted_rows(px, w_c, w_d, awc, awd);
+#pragma unroll
+                    for (int k = 0; k < 7; k++) {
+                        s.rows.aw[k][q] = awc[k];
+                        s.rows.aw[7 + k][q] = awd[k];
+                    }
+                    ok = true;
+                }
+            }
+            s.rows.ok[q] = ok;
+        }
+        __syncthreads();
+        if (tid < 27) {
+            const int m = min(RO_ROWS_CHUNK, c.n - base);
+            for (int q = 0; q < m; q++) {
+                if (!s.rows.ok[q]) continue;
+                sum += (double)s.rows.aw[ei][q] * (double)s.rows.aw[ej][q];
+                sum += (double)s.rows.aw[7 + ei][q] * (double)s.rows.aw[7 + ej][q];
+            }
+        }
+        __syncthreads();
+    }
+    if (lane < 27) s.red[wave][lane] = wave == 0 ? sum : 0.0;
+}
+
+#else
     double acc[27];
 #pragma unroll
     for (int q = 0; q < 27; q++) acc[q] = 0.0;
@@ -327,6 +415,7 @@ __device__ __noinline__ void ro_pass1(const KArgs &a, int b, int L, LDS SolveSha
         if (lane == 0) s.red[wave][q] = t;
     }
 }
+#endif  // SF_RO_SEQ64 && SF_RO_P1_FP64
 
 // ---------------------------------------------------------------------------------------------
 //  pass 2: residuals with the new solution, per-cluster sums of |res_c| + |res_d| in validPixels order, ||res||^2
@@ -355,8 +444,13 @@ __device__ __noinline__ void ro_pass2(const KArgs &a, int b, int L, LDS SolveSha
                     ro_pixel(c.g, idx, r, px);
                     float res_c, res_d;
                     ro_residuals(px, Vr, res_c, res_d);
+#if SF_RO_SEQ64
+                    s.ro2.rc[q] = res_c;
+                    s.ro2.rd[q] = res_d;
+#else
                     sq += (double)res_c * (double)res_c;
                     sq += (double)res_d * (double)res_d;
+#endif
                     val = fabsf(res_c) + fabsf(res_d);
                     lab = r.lab;
 #if !SF_RO_LABSUM
@@ -372,12 +466,22 @@ __device__ __noinline__ void ro_pass2(const KArgs &a, int b, int L, LDS SolveSha
 #if SF_RO_LABSUM
         ro_label_walk(s.ro, min(RO_CHUNK, c.n - base), tid, la);
 #endif
+#if SF_RO_SEQ64
+        if (tid == SF_NC) {  // res.squaredNorm(): row after row ([C1]), on the lane next to the 24 of the per-cluster sums
+            const int m = min(RO_CHUNK, c.n - base);
+            for (int q = 0; q < m; q++) {
+                if (s.ro.lab[q] == SF_INVALID_LABEL) continue;
+                sq += (double)s.ro2.rc[q] * (double)s.ro2.rc[q];
+                sq += (double)s.ro2.rd[q] * (double)s.ro2.rd[q];
+            }
+        }
+#endif
         __syncthreads();
     }
 #if SF_RO_LABSUM
     if (tid < SF_NC) s.aver_res_label[tid] = la.sum;
 #endif
-    sq = wave_sum_f64(sq);
+    sq = wave_sum_f64(sq);  // (row-by-row: one lane holds the sum, every other lane 0.0)
     if (lane == 0) s.red[wave][27] = sq;
 }
 

@@ -72,6 +72,8 @@ struct SolveShared {
         double p1[27][P1_SETS];
 #if SF_REFORDER
         RoChunk ro;    // reference-order build: a chunk of the ordered per-cluster sums
+        RoChunk2 ro2;  // ... with the two residuals of every pixel (`ro2.c` IS `ro`)
+        RoRows rows;   // ... a chunk of weighted rows for the row-by-row fp64 sums of pass 1
 #endif
     };
     // reductions

@@ -206,7 +206,8 @@ def test_warp_with_targets_outside_the_tile_windows(hip, ora, pair):
     # (a pixel more or less of validPixels moves the mean residual by 1e-3 and the unclamped b of the cluster it belongs to by
     # up to 1e-2 -- 1.924 against 1.921 here, both far above the clamp at 1 of the b image, whose decisions are compared exactly)
     assert_traces_match(sg, so, tol_twist=1e-5, tol_b=1e-2, n_valid_slack=4, rtol_aver=3e-3)
-    assert np.array_equal(sg.b_image() > 0.5, so.b_image() > 0.5) and np.abs(sg.b_image() - so.b_image()).max() < 3e-4
+    # (the b image is the clamped b of each pixel's cluster: the same bound; 6.9e-3 measured in the cluster build, < 3e-4 in the others)
+    assert np.array_equal(sg.b_image() > 0.5, so.b_image() > 0.5) and np.abs(sg.b_image() - so.b_image()).max() < 1e-2
     for L in range(4):  # level 4 is warped once: Warped := Pred
         for ch in range(2):
             assert_planes_close(sg.plane(capi.SET_WARPED, ch, L), so.plane(capi.SET_WARPED, ch, L), frac=0.97)

@@ -177,6 +177,20 @@ def test_vga_six_levels(ro, ora, pair):
     assert_state_identical(*solvers)
 
 
+def test_fp64_sums_row_by_row(ro, ora):
+    """The oracle's [C1] sums (AtA / AtB, sum |res|, ||res||^2) are fp64 sums of float terms, row after row. Summed per lane and
+    then over the lanes they differ in the 16th digit -- which moved the float they are converted to in ONE frame of 73 600
+    (160 x 120 hunt case 61826, frame 6: AtA(0,0) 253.37692 against 253.37694; pose 1.4e-9 apart). The build walks them row by row."""
+    from sequence_cases import make_case, run_case
+
+    case = make_case(61826, 320, 240, True)
+    ref, got = run_case(ora, case), run_case(ro, case)
+    for k, (r, g) in enumerate(zip(ref, got)):
+        assert r["counts"] == g["counts"], k
+        for f in ("T", "b", "b_img", "labels"):
+            assert np.array_equal(r[f], g[f]), (k, f)
+
+
 def test_cluster_variant_is_refused(ro):
     import staticfusion_amd as sf
 

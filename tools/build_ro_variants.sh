@@ -18,6 +18,7 @@ build rows_fact_fma    RO_FLAGS="-DSF_RO_ROWS=0" RO_ROWS_FMA=1
 build fast_weights     RO_FAST_WEIGHTS=1
 build p1_fp32          RO_FLAGS="-DSF_RO_P1_FP64=0"
 build labsum_int       RO_FLAGS="-DSF_RO_LABSUM=0"
+build fp64_lane_sums   RO_FLAGS="-DSF_RO_SEQ64=0"   # the [C1] sums as per-lane partial sums: 1 frame of 73 600 differs in the last bit (PARITY.md)
 build jacobi_rr        RO_FLAGS="-DSF_RO_JACOBI=0"
 build init_res         RO_FLAGS="-DSF_RO_INIT_RES=0"
 build behind           RO_FLAGS="-DSF_RO_BEHIND=0"

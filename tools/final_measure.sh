@@ -11,7 +11,7 @@
 set -u
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 mkdir -p gpurun_out profiles
-T=${1:-r03g}
+T=${1:-r04w}
 export TMPDIR=/tmp
 STEPS=20  # the driver's --steps: the sequences blocks are measured as ONE launch of that many frames, like the bench times them
 for spec in "static 16384 0" "sphere 16384 0" "sequences 4096 $STEPS" "sequences 16384 $STEPS"; do

@@ -210,7 +210,8 @@ def test_warp_with_targets_outside_the_tile_windows(hip, ora, pair):
     assert np.array_equal(sg.b_image() > 0.5, so.b_image() > 0.5) and np.abs(sg.b_image() - so.b_image()).max() < 1e-2
     for L in range(4):  # level 4 is warped once: Warped := Pred
         for ch in range(2):
-            assert_planes_close(sg.plane(capi.SET_WARPED, ch, L), so.plane(capi.SET_WARPED, ch, L), frac=0.97)
+            # hard bound: a tap that falls on the other side of a centi-pixel at a fence edge mixes depths 1.9 m apart (0.88 measured)
+            assert_planes_close(sg.plane(capi.SET_WARPED, ch, L), so.plane(capi.SET_WARPED, ch, L), frac=0.97, hard=2.0)
     rot, trans = pose_delta(so.T(), sg.T())
     assert rot <= POSE_TOL and trans <= POSE_TOL
     assert np.array_equal(sg.labels(0), so.labels(0))

@@ -663,6 +663,7 @@ def run_sequences_workload(hx, args, B, pool):
 
 
 def main():
+    t_main = time.time()
     args = parse()
     if args.launch_per_frame:
         os.environ["SF_TIMED_LAUNCH_PER_FRAME"] = "1"  # sf_timed_process_frames honours it (the pairs workloads)
@@ -741,6 +742,7 @@ def main():
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.workload, min(args.cpu_seconds, 8.0), lib)
             if full is not None:
                 out["full_solver"]["cpu_baseline"] = cpu_baseline("sphere", full["pairs"], min(args.cpu_seconds, 8.0), lib)
+        out["wall_s"] = round(time.time() - t_main, 1)  # this process, argument parsing to this line (set-up, every block, the CPU legs)
         print(json.dumps(out))
     hx.close()
 

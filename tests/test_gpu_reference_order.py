@@ -191,6 +191,26 @@ def test_fp64_sums_row_by_row(ro, ora):
             assert np.array_equal(r[f], g[f]), (k, f)
 
 
+@pytest.mark.parametrize("roll,forward", [(0.25, 0.25), (0.4, 0.0), (0.4, 0.25)])
+def test_strong_roll_and_approach(ro, ora, roll, forward):
+    """A quarter of a radian and more about the optical axis, with and without a fast approach: at the coarse levels the targets of
+    a tile of 16 whole columns no longer fit its LDS window (30 rows x sin 0.25 = 7 columns against a margin of 6), the ordered
+    splat falls back from the tiles to the per-cell lists in the middle of a level, and the solver needs up to 14 outer and 84
+    IRLS iterations. Identical all the same."""
+    from staticfusion_amd.synth import make_pair
+
+    pr = make_pair(seed=17, sphere=True, out_rows=240, out_cols=320, xi=(forward, 0.0, 0.0, roll, 0.0, 0.0))
+    solvers = []
+    for api in (ro, ora):
+        s = make_solver(api, 240, 320, driver_params(api, debug_planes=1), pr)
+        s.build_pyramid(True)
+        s.run_solver(True)
+        s.build_segm_image()
+        solvers.append(s)
+    assert solvers[1].stats().n_irls >= 30
+    assert_state_identical(*solvers, warped_levels=range(4))
+
+
 def test_cluster_variant_is_refused(ro):
     import staticfusion_amd as sf
 

@@ -220,7 +220,8 @@ def test_cluster_variant_is_refused(ro):
 
 def test_ordered_tile_splat_equals_the_list_splat(tmp_path):
     """The product's ordered float splat of the coarse levels (`ordered_tile_splat`: LDS-resident tiles, rounds of ds_min) against
-    the per-cell source lists of the reference-order build (`ro_splat`), in isolation: one workgroup, synthetic levels from 8 x 8 to 64 x 100 pixels (odd sizes included) with holes under a rigid warp -- every cell bit for bit (tools/micro/ordered_splat_check.hip)."""
+    the per-cell source lists of the reference-order build (`ro_splat`), in isolation: one workgroup, synthetic levels from 8 x 8 to 64 x 100 pixels (odd sizes included) with holes under a rigid warp -- every cell bit for bit
+    (tools/micro/ordered_splat_check.hip) -- and, under a strong roll, the fall-back of `ordered_splat` from the tiles to the lists."""
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -229,4 +230,5 @@ def test_ordered_tile_splat_equals_the_list_splat(tmp_path):
                            "-Wno-unused-function", "-Wno-unused-value", "-I", os.path.join(root, "staticfusion_amd", "csrc"), "-o", exe,
                            os.path.join(root, "tools", "micro", "ordered_splat_check.hip")], timeout=600)
     out = subprocess.check_output([exe], timeout=120).decode()
-    assert out.strip().endswith("OK") and out.count("differing cells 0") == 7, out
+    # seven levels the tiles serve, three under a roll of 0.3 - 0.5 rad that they give up on (the lists then run over what they left)
+    assert out.strip().endswith("OK") and out.count("differing cells 0") == 10 and out.count("(tiles returned 1)") == 7 and out.count("(tiles returned 0)") == 3, out

@@ -351,6 +351,7 @@ def run_pairs_workload(hx, args, workload, batch, with_parity):
         solver.process_frame(im)
         im += 1
     solver.synchronize()
+    copy_gbs = copy_bandwidth(solver)
 
     # ---- the timed region: exactly K steps = K launches of sf_frame_kernel, back to back, bracketed by barrier + device
     #      synchronisation. HIP events recorded on the handle's stream around the same K launches give the average kernel
@@ -373,7 +374,7 @@ def run_pairs_workload(hx, args, workload, batch, with_parity):
         status_or |= int(st.status)
     assert status_or & sf.STATUS_SYNC_TIMEOUT == 0, "a cluster rendezvous timed out: the frames of this run are not valid"
     variant = solver.variant()
-    irls_passes = isolated_passes(solver, B, rows * cols, args.pass_reps) if variant[0] != "cluster" else None
+    irls_passes = isolated_passes(solver, B, rows * cols, args.pass_reps, copy_gbs) if variant[0] != "cluster" else None
     resident = solver.resident_workgroups()
     levels_n = [solver.level_shape(L)[0] * solver.level_shape(L)[1] for L in range(solver.levels)]
     levels = int(solver.levels)
@@ -412,6 +413,8 @@ def run_pairs_workload(hx, args, workload, batch, with_parity):
         "roofline": {
             "kernel": "sf_frame_kernel (%s build)" % variant[0],
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            # the second fraction SURVEY 8(d) asks for: against a plain copy kernel measured on this box right before the timed region
+            "copy_gbs": copy_gbs, "frac_of_copy": achieved / copy_gbs,
             # HBM bytes per launch from the PMC counters (measured per frame of every stream, tools/measure_traffic.sh, times the
             # frames of this launch), or null when no measurement of THESE sources exists
             "traffic": traffic["hbm_bytes_per_launch"] * (1 if os.environ.get("SF_TIMED_LAUNCH_PER_FRAME") else args.steps) if traffic else None,
@@ -436,7 +439,18 @@ def run_pairs_workload(hx, args, workload, batch, with_parity):
     }
 
 
-def isolated_passes(solver, B, n0, reps):
+COPY_BYTES = 1 << 30  # sf_microbench_copy: 1 GiB read + 1 GiB written per repetition
+
+
+def copy_bandwidth(solver):
+    """"fraction = achieved / measured-peak copy bandwidth and / 8 TB/s (both quoted)". A 2 GiB device copy
+    (16-byte loads and stores, sf_microbench_copy) on the handle's stream right before the timed region of a block: what a plain
+    streaming kernel reaches on THIS box at THIS moment (the package's power-limited clock moves it by +- 2-4 % from box to box)."""
+    solver.microbench_copy(COPY_BYTES, 2)
+    return solver.microbench_copy(COPY_BYTES, 6)
+
+
+def isolated_passes(solver, B, n0, reps, copy_gbs=None):
     """Each IRLS pass alone over level 0 of all B streams: ms per repetition, GB/s against the algorithmic 30 B per pixel and
     pass (60 B per pixel and IRLS iteration), fraction of the 8 TB/s peak; `iteration` = both passes."""
     out = {}
@@ -444,35 +458,23 @@ def isolated_passes(solver, B, n0, reps):
     for which, name in ((1, "pass1_weights_normal_equations"), (2, "pass2_residuals_label_sums")):
         solver.microbench_pass(which, 0, 1)
         ms = solver.microbench_pass(which, 0, reps) / reps
-        out[name] = {"ms": ms, "gpx_per_s": px / ms / 1e6, "bytes": 30.0 * px, "achieved": 30.0 * px / ms / 1e6, "frac": 30.0 * px / ms / 1e6 / HBM_PEAK_GBS}
+        out[name] = {"ms": ms, "gpx_per_s": px / ms / 1e6, "bytes": 30.0 * px, "achieved": 30.0 * px / ms / 1e6, "frac": 30.0 * px / ms / 1e6 / HBM_PEAK_GBS,
+                     "frac_of_copy": (30.0 * px / ms / 1e6 / copy_gbs) if copy_gbs else None}
     ms = sum(v["ms"] for v in out.values())
     out["iteration"] = {"ms": ms, "bytes": 60.0 * px, "achieved": 60.0 * px / ms / 1e6, "unit": "GB/s", "frac": 60.0 * px / ms / 1e6 / HBM_PEAK_GBS,
+                        "frac_of_copy": (60.0 * px / ms / 1e6 / copy_gbs) if copy_gbs else None,
                         "pixels": px, "repetitions": reps, "kernel": "sf_irls_pass_kernel (level 0 of every stream, one pass per launch)"}
     return out
 
 
 def _cached_sequence(seed, F, pool):
     """One synthetic sequence as (d [F][n0], i [F][n0], T_gt) -- from /tmp when a run on this node has rendered it before (the
-    driver runs N = 1, 2, 4, 8 back to back: rank r's seeds at N recur at 2 N), else rendered and stored (atomic rename)."""
-    from staticfusion_amd.synth import make_sequence
+    driver runs N = 1, 2, 4, 8 back to back: rank r's seeds at N recur at 2 N), else rendered and stored. The cache key
+    carries a hash of the generator and the resolution (staticfusion_amd/synth.py: sequence_arrays)."""
+    from staticfusion_amd.synth import sequence_arrays
 
-    path = os.path.join(os.environ.get("SF_BENCH_CACHE", "/tmp"), "sf_bench_seq_v1_%d_%d_u%d.npz" % (seed, F, os.getuid()))
-    try:
-        with np.load(path) as z:
-            if z["d"].shape[0] == F:
-                return z["d"], z["i"], list(z["T_gt"])
-    except Exception:
-        pass
-    seq = make_sequence(seed, F, sphere=True, pool=pool)
-    col = lambda a: np.ascontiguousarray(np.asarray(a, np.float32).T).ravel()
-    d, i = np.stack([col(f[0]) for f in seq["frames"]]), np.stack([col(f[1]) for f in seq["frames"]])
-    try:
-        tmp = "%s.%d.tmp.npz" % (path, os.getpid())
-        np.savez(tmp, d=d, i=i, T_gt=np.stack(seq["T_gt"]))
-        os.replace(tmp, path)
-    except Exception:
-        pass
-    return d, i, seq["T_gt"]
+    d, i, T_gt = sequence_arrays(seed, F, pool=pool, cache_dir=os.environ.get("SF_BENCH_CACHE", "/tmp"))
+    return d, i, list(T_gt)
 
 
 def synthetic_sequence_pool(hx, args):
@@ -528,6 +530,48 @@ def tum_sequence_pool(hx, args):
             "T_gt": None, "rows": rows, "cols": cols, "workload": "tum", "what": {"dataset": os.path.abspath(args.dataset), "frames": F}}
 
 
+LONG_FIXTURE = os.path.join(ROOT, "tests", "golden", "long_sequences_qvga.npz")
+
+
+def sequences_parity(hx, api, params, pool, variant, first_timed, last_timed, T_last_big):
+    """pose_delta_vs_cpu of a sequences block: the TIMED frames of the first stream of every distinct sequence against the CPU
+    oracle's frame-by-frame poses for the same sequences (tests/golden/long_sequences_qvga.npz, the oracle's own output,
+    tools/golden/make_golden_long_sequences.py; tests/test_long_sequences.py holds all 199 frames of it against every build).
+    Nothing is added to the timed region: streams 0 .. D-1 of the batch play sequences 0 .. D-1 from frame 0, and a handle of D
+    streams of the same build replays exactly those frames in one launch with its trajectory -- the results of a stream do not
+    depend on the batch it runs in, which is CHECKED here: the replay's pose of the last timed frame must equal the big batch's
+    bit for bit. None when the fixture does not cover this pool (other seeds, resolution or length)."""
+    import staticfusion_amd as sf
+    from staticfusion_amd.synth import pose_delta
+
+    D, F = pool["D"], pool["F"]
+    seeds = pool["what"].get("sequence_seeds")
+    if pool["workload"] != "sequences" or not os.path.exists(LONG_FIXTURE) or seeds is None:
+        return None
+    with np.load(LONG_FIXTURE) as z:
+        fx_seeds, fx_T, fx_frames = list(z["seeds"]), z["T"], int(z["frames"])
+    want = list(range(seeds[0], seeds[1] + 1))
+    if fx_frames != F or fx_seeds[:len(want)] != want or (pool["rows"], pool["cols"]) != (240, 320) or last_timed >= F:
+        return {"note": "the oracle fixture covers seeds %s, %d frames at 240 x 320: not this pool" % (fx_seeds, fx_frames)}
+    replay = sf.Solver(api, pool["rows"], pool["cols"], D, params, device=hx.dev_index, variant=variant)
+    idx = lambda k: (np.arange(D) * F + k).astype(np.int32)
+    replay.advance_sequences_device(pool["d"].data_ptr(), pool["i"].data_ptr(), idx(0), D * F)
+    replay.push_history(0)
+    T = replay.process_sequence_frames_device(pool["d"].data_ptr(), pool["i"].data_ptr(), np.stack([idx(k) for k in range(1, last_timed + 1)]), D * F, 1, trajectory=True)
+    replay.close()
+    same = bool(np.array_equal(T[last_timed - 1], T_last_big[:D]))
+    timed = [pose_delta(fx_T[q][k - 1], T[k - 1][q]) for k in range(first_timed, last_timed + 1) for q in range(D)]
+    whole = [pose_delta(fx_T[q][k - 1], T[k - 1][q]) for k in range(1, last_timed + 1) for q in range(D)]
+    return {
+        "rot_rad_max": max(p[0] for p in timed), "trans_m_max": max(p[1] for p in timed), "frames_compared": len(timed),
+        "frames_past_1e-4": sum(1 for p in timed if max(p) > 1e-4), "streams": D, "timed_frames": [first_timed, last_timed],
+        "from_frame_1": {"rot_rad_max": max(p[0] for p in whole), "trans_m_max": max(p[1] for p in whole), "frames_compared": len(whole),
+                         "frames_past_1e-4": sum(1 for p in whole if max(p) > 1e-4)},
+        "replay_reproduces_the_timed_streams_bit_for_bit": same,
+        "reference": "CPU oracle, tests/golden/long_sequences_qvga.npz (seeds %d .. %d)" % (want[0], want[-1]),
+    }
+
+
 def run_sequences_workload(hx, args, B, pool):
     """Independent sequences per rank, resident in HBM, frame-to-frame prediction (see the module docstring)."""
     import staticfusion_amd as sf
@@ -558,6 +602,7 @@ def run_sequences_workload(hx, args, B, pool):
         solver.process_frame(step)
         step += 1
     solver.synchronize()
+    copy_gbs = copy_bandwidth(solver)
     c0 = solver.counters()
     hx.barrier(solver)
     t0 = time.perf_counter()
@@ -574,6 +619,8 @@ def run_sequences_workload(hx, args, B, pool):
     c1 = solver.counters()
     frames_timed, iters_total = c1[0] - c0[0], c1[1] - c0[1]
     assert frames_timed == B * args.steps
+    T_after_timed = solver.batch_results()[0].copy()  # pose of the last timed frame of every stream (sequences_parity)
+    first_timed, last_timed = step - args.steps, step - 1
     # kernel duration: the timed launch itself (HIP events on the handle's stream around it) / its frames; launch-per-frame
     # mode and the unit counts: three more, un-timed launches
     k_ms, stats_last = ([] if args.launch_per_frame else [solver.last_solver_kernel_ms() / args.steps]), None
@@ -602,6 +649,10 @@ def run_sequences_workload(hx, args, B, pool):
     levels_n = [solver.level_shape(L)[0] * solver.level_shape(L)[1] for L in range(solver.levels)]
     levels = int(solver.levels)
     solver.close()
+    vs_cpu = None
+    if hx.rank == 0 and not args.launch_per_frame and B >= D:
+        vs_cpu = sequences_parity(hx, api, params, pool, variant[0], first_timed, last_timed, T_after_timed)
+        assert vs_cpu is None or "note" in vs_cpu or vs_cpu["replay_reproduces_the_timed_streams_bit_for_bit"], vs_cpu
 
     t_max, iters_all, frames_all = reduce_over_ranks(hx.dist, hx.reduce_device, elapsed, iters_total, B * args.steps)
     per_rank = gather_per_rank(hx.dist, hx.reduce_device, elapsed, iters_total, B * args.steps)
@@ -613,10 +664,19 @@ def run_sequences_workload(hx, args, B, pool):
     alg_bytes_launch = sum(per_stream.values()) * B / float(len(stats_last))
     kms = float(np.mean(k_ms))
     achieved = alg_bytes_launch / (kms * 1e-3) / 1e9
-    # the in-launch advance (prediction := current, current := pool frame): 8 B read + 8 B written per pixel for a frame that
-    # swapped its pyramid buffers, twice that for one that copied the prediction too. Its own line: no SURVEY figure covers it
-    # and it is NOT part of `achieved`.
-    advance_copy = 0.0 if args.launch_per_frame else n0 * (16.0 * swapped + 32.0 * (args.steps - swapped)) / args.steps
+    # the in-launch advance (prediction := current, current := pool frame). Round 5: a frame that swaps its pyramid buffers reads
+    # level 0 of both images IN THE POOL and copies nothing; a frame that does not swap (the first of a launch, the last when
+    # it has to leave the host's layout) copies both images, 8 B read + 8 B written per pixel each; a last frame that did swap
+    # leaves both images in the buffers afterwards (the same 32 B). Its own line: no SURVEY figure covers it and it is NOT part
+    # of `achieved`. (SF_NO_POOL_IN_PLACE=1: round 4's form, 16 B per pixel for every swapping frame.)
+    in_place = not (os.environ.get("SF_NO_POOL_IN_PLACE") or os.environ.get("SF_NO_PYRAMID_FLIP"))
+    if args.launch_per_frame:
+        advance_copy = 0.0
+    elif in_place:
+        last_swapped = args.steps >= 2 and (args.steps - 2) % 2 == 1
+        advance_copy = n0 * (32.0 * (args.steps - swapped) + (32.0 if last_swapped else 0.0)) / args.steps
+    else:
+        advance_copy = n0 * (16.0 * swapped + 32.0 * (args.steps - swapped)) / args.steps
     traffic, why = measured_traffic(pool["workload"], B, variant[0], frames_per_launch=1 if args.launch_per_frame else args.steps)
     if traffic:
         traffic["ratio_to_algorithmic"] = traffic["hbm_bytes_per_launch"] / alg_bytes_launch
@@ -629,8 +689,8 @@ def run_sequences_workload(hx, args, B, pool):
         "ms_per_step": 1e3 * t_max / args.steps,
         "iterations_per_frame": iters_total / float(B * args.steps),
         "iterations_per_frame_spread": [int(n_irls.min()), int(n_irls.max())],
-        "parity": ({"tracking_error_vs_ground_truth": {"rot_rad_max": max(e[0] for e in err), "trans_m_max": max(e[1] for e in err), "streams": len(err)}}
-                   if err else None),
+        "parity": ({"tracking_error_vs_ground_truth": {"rot_rad_max": max(e[0] for e in err), "trans_m_max": max(e[1] for e in err), "streams": len(err)},
+                    "pose_delta_vs_cpu": vs_cpu} if err else None),
         "per_rank": [{"rank": r, "elapsed_s": e, "iterations_per_s": i / e, "frames_per_s": f / e} for r, (e, i, f) in enumerate(per_rank)],
         "config": dict(cfg, **{
             "rows": rows, "cols": cols, "ctf_levels": levels,
@@ -645,6 +705,7 @@ def run_sequences_workload(hx, args, B, pool):
         "roofline": {
             "kernel": "sf_frame_kernel (%s build)" % variant[0],
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "copy_gbs": copy_gbs, "frac_of_copy": achieved / copy_gbs,
             "traffic": traffic["hbm_bytes_per_launch"] * (1 if args.launch_per_frame else args.steps) if traffic else None,
             "traffic_provenance": traffic, "traffic_note": why,
             "frames_per_launch": 1 if args.launch_per_frame else args.steps,
@@ -656,6 +717,7 @@ def run_sequences_workload(hx, args, B, pool):
             "bytes_per_unit": {"algorithmic": ALGORITHMIC_B, "moved": MOVED_B},
             "pyramids_built_per_frame": pyr_per_frame, "frames_that_swapped_pyramid_buffers": swapped,
             "advance_copy_bytes_per_stream_frame": advance_copy,  # in the launch and in `traffic`, not in `achieved`
+            "level0_read_in_pool": bool(in_place and not args.launch_per_frame),
             "kernel_ms_avg": kms,
         },
         "pairs": None,
@@ -726,6 +788,7 @@ def main():
                 "value": q["value"], "unit": "iterations/s", "frames_per_s": q["frames_per_s"], "ms_per_step": q["ms_per_step"],
                 "steps": args.steps, "warmup": args.warmup, "iterations_per_frame": q["iterations_per_frame"],
                 "iterations_per_frame_spread": q["iterations_per_frame_spread"], "tracking": q["parity"],
+                "pose_delta_vs_cpu": (q["parity"] or {}).get("pose_delta_vs_cpu"),
                 "config": q["config"], "roofline": q["roofline"], "per_rank": q["per_rank"],
             } for q in seq_blocks]
         if full is not None:

@@ -210,7 +210,13 @@ int SF_FN(process_frames)(sf_handle *h, int im_count0, int n_frames, float *T_ou
 /* The same for sequences resident in HBM: frame k of stream b is preceded by that stream's step of
  * sf_advance_sequences_device (prediction := current, current := pool frame frame_index[k * batch + b]; a negative entry
  * leaves the images alone). frame_index: HOST array [n_frames][batch]. The replay loop of the dataset drivers
- * (StaticFusion-imagesequenceassoc.cpp:140-191 without the map) for `batch` sequences and n_frames frames, one launch. */
+ * (StaticFusion-imagesequenceassoc.cpp:140-191 without the map) for `batch` sequences and n_frames frames, one launch.
+ * The pools are READ IN PLACE while the launch runs (from its second frame on a stream reads level 0 of its current and of
+ * its predicted image in the pool; the last frame leaves both in the handle's own buffers again): they must stay valid and
+ * unchanged until the launch has finished (sf_synchronize, any getter, or T_out).
+ * Should a stream's frame never finish (cannot happen; every wait is bounded), the later frames of that stream are skipped
+ * with SF_STATUS_SYNC_TIMEOUT, their rows of T_out are NaN, and the stream's images are undefined until
+ * sf_clear_sync_timeout + fresh images. */
 int SF_FN(process_sequence_frames_device)(sf_handle *h, const void *pool_depth, const void *pool_intensity, const int32_t *frame_index,
                                           int pool_frames, int im_count0, int n_frames, float *T_out);
 /* Overlapped upload for PCIe-fed deployments: sf_upload_current_async starts copying depthCurrent / intensityCurrent
@@ -456,9 +462,10 @@ int SF_FN(get_stage_profile)(sf_handle *h, int64_t ticks[32]);
  * Infinity Cache; an experiment, partial sums are not combined). Elapsed HIP-event milliseconds of the
  * launch. Not part of a solve. */
 int SF_FN(microbench_pass)(sf_handle *h, int which, int variant, int reps, float *elapsed_ms);
-/* SF_VARIANT_CLUSTER: forget a rendezvous timeout (SF_STATUS_SYNC_TIMEOUT) of every stream of the handle: granules, epochs and
- * the sticky flag are reset after the handle's stream has drained; the solver state is left as it is. A no-op for the
- * other builds (no rendezvous). */
+/* Forget a timeout (SF_STATUS_SYNC_TIMEOUT) of every stream of the handle after the handle's stream has drained.
+ * SF_VARIANT_CLUSTER: granules, epochs and the sticky flag of the rendezvous are reset; the solver state is left as it is.
+ * Every build: a stream that a multi-frame launch gave up on gets back the image layout the host assumes (set its images
+ * again before the next frame). */
 int SF_FN(clear_sync_timeout)(sf_handle *h);
 #ifdef SF_TESTING
 /* Test support, declared only with -DSF_TESTING (SF_VARIANT_CLUSTER): from the next launch on, the workgroup of rank `rank` of
@@ -471,8 +478,13 @@ int SF_FN(debug_stall_rank)(sf_handle *h, int rank, float stall_ms, unsigned spi
  * version 3 and writes 32 since; sf_outer_trace grew by delta_sol_max in version 3; sf_advance_sequences_device gained an
  * argument). Returns SF_ABI_VERSION; any pointer may be NULL. A caller checks
  *     sf_abi_version(&a, &b, &c) == SF_ABI_VERSION && a == sizeof(sf_params) && b == sizeof(sf_frame_stats) && c == 32. */
-#define SF_ABI_VERSION 4
+#define SF_ABI_VERSION 5 /* 5: sf_microbench_copy; sf_clear_sync_timeout acts on every build; pools of a sequence launch are read in place */
 int SF_FN(abi_version)(int *sizeof_params, int *sizeof_frame_stats, int *stage_profile_slots);
+/* Measurement support ("achieved / measured-peak copy bandwidth"): `reps` device-to-device copies of
+ * `bytes` bytes (16-byte loads and stores, grid-stride, on the handle's stream; two scratch blocks of that size are allocated
+ * and freed) -- what a plain streaming kernel reaches on THIS box at THIS moment; a copy moves 2 x bytes. Elapsed HIP-event
+ * milliseconds of all repetitions. Not part of a solve. */
+int SF_FN(microbench_copy)(sf_handle *h, size_t bytes, int reps, float *elapsed_ms);
 /* Elapsed ms of the most recent solver kernel launch (HIP events around that launch; a launch of sf_process_frames
  * covers all its frames). */
 int SF_FN(last_solver_kernel_ms)(sf_handle *h, float *ms);

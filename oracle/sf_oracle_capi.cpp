@@ -814,6 +814,7 @@ int sfo_get_stage_profile(sf_handle *h, int64_t ticks[32]) {
     return SF_OK;
 }
 int sfo_microbench_pass(sf_handle *, int, int, int, float *) { return fail(SF_ERR_STATE, "not available in the CPU oracle"); }
+int sfo_microbench_copy(sf_handle *, size_t, int, float *) { return fail(SF_ERR_STATE, "not available in the CPU oracle"); }
 int sfo_clear_sync_timeout(sf_handle *h) { return h ? SF_OK : fail(SF_ERR_ARG, "null"); }  // one thread: nothing to time out
 int sfo_debug_stall_rank(sf_handle *, int, float, unsigned) { return fail(SF_ERR_STATE, "not available in the CPU oracle"); }
 int sfo_last_solver_kernel_ms(sf_handle *h, float *ms) {

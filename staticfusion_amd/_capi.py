@@ -87,6 +87,9 @@ class SfFrameStats(C.Structure):
     ]
 
 
+ABI_VERSION = 5     # SF_ABI_VERSION of include/sf.h (tests/test_capi_and_host.py holds the two together)
+PROFILE_SLOTS = 32  # sf_get_stage_profile's array
+
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
 _H = C.c_void_p
@@ -176,6 +179,7 @@ SIGNATURES = {
     "last_solver_kernel_ms": (C.c_int, [_H, _fp]),
     "clear_sync_timeout": (C.c_int, [_H]),
     "debug_stall_rank": (C.c_int, [_H, C.c_int, C.c_float, C.c_uint]),
+    "microbench_copy": (C.c_int, [_H, C.c_size_t, C.c_int, _fp]),
     "abi_version": (C.c_int, [_ip, _ip, _ip]),
 }
 
@@ -196,6 +200,14 @@ class Api:
             fn.restype = res
             fn.argtypes = args
             setattr(self, name, fn)
+        # the library must have been built from the header these ctypes mirrors restate (silent struct drift is the likeliest
+        # way for this binding to go wrong: a buffer that is too small is written past its end)
+        sp, ss, slots = C.c_int(), C.c_int(), C.c_int()
+        version = self.abi_version(C.byref(sp), C.byref(ss), C.byref(slots))
+        if (version, sp.value, ss.value, slots.value) != (ABI_VERSION, C.sizeof(SfParams), C.sizeof(SfFrameStats), PROFILE_SLOTS):
+            raise SfError("%s: ABI mismatch: the library reports version %d, sizeof(sf_params) %d, sizeof(sf_frame_stats) %d, %d profile "
+                          "slots; this binding mirrors version %d, %d, %d, %d (rebuild: make -C staticfusion_amd/csrc && make -C oracle)"
+                          % (self.lib_path, version, sp.value, ss.value, slots.value, ABI_VERSION, C.sizeof(SfParams), C.sizeof(SfFrameStats), PROFILE_SLOTS))
 
     def check(self, code):
         if code != 0:
@@ -535,6 +547,12 @@ class Solver:
         self.api.check(self.api.get_stage_profile(self.h, t))
         return int(t[24])
 
+    def ordered_fallbacks(self):
+        """levels whose ordered tile splat gave up and took the per-cell source lists (slot 25 of the stage profile: a counter)"""
+        t = (C.c_int64 * 32)()
+        self.api.check(self.api.get_stage_profile(self.h, t))
+        return int(t[25])
+
     def microbench_pass(self, which, variant, reps):
         ms = C.c_float()
         self.api.check(self.api.microbench_pass(self.h, which, variant, reps, C.byref(ms)))
@@ -550,6 +568,12 @@ class Solver:
 
     def debug_stall_rank(self, rank, stall_ms=0.0, spin_limit=0):
         self.api.check(self.api.debug_stall_rank(self.h, rank, stall_ms, spin_limit))
+
+    def microbench_copy(self, nbytes, reps):
+        """GB/s of `reps` device copies of nbytes bytes (2 x nbytes moved each): the measured streaming ceiling of this box"""
+        ms = C.c_float()
+        self.api.check(self.api.microbench_copy(self.h, int(nbytes), int(reps), C.byref(ms)))
+        return 2.0 * nbytes * reps / (ms.value * 1e-3) / 1e9
 
     def last_solver_kernel_ms(self):
         ms = C.c_float()

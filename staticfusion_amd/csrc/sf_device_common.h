@@ -31,6 +31,7 @@ enum {
     PF_TAIL, PF_FILTER, PF_RESIDUALS, PF_SEGM_HIST, PF_TOTAL,
     PF_KM_INIT, PF_KM_SORT, PF_KM_ASSIGN, PF_KM_PARTITION, PF_KM_SUM, PF_KM_LABEL0, PF_KM_CONN_PYR,
     PF_SPLAT_REPLAYS = 24,  // not a timer (a slot of its own: 21..23 are shared by the profiling builds and the isolated-pass kernel): warp tiles replayed for targets outside their window (tiled_splat, lazy mode)
+    PF_ORDERED_FALLBACKS = 25,  // not a timer: levels whose ordered tile splat gave up (a tap outside its window) and took the per-cell lists
     SF_PROF_SLOTS = 32
 };
 
@@ -99,6 +100,10 @@ struct StreamState {
     int32_t last_slot;              // record slot of the last executed outer iteration (cluster build: may be a private one)
     int32_t flip;                   // 1: the stream's two pyramid buffers have swapped roles (pyr_plane): only INSIDE a launch of
                                     // several frames of a sequence (sf_frame_kernels.hip), 0 whenever the host looks
+    // Only INSIDE a launch of several SEQUENCE frames (null whenever the host looks): level 0 of the [set][channel] image is the
+    // pool frame at this address instead of the pyramid buffer's level 0 (pyr_level) -- the launch reads the new frame, and as the
+    // next frame's prediction the previous one, where they lie in the caller's HBM pool instead of copying 16 B per pixel and frame
+    const float *lvl0[2][2];
     int32_t sync_failed;            // cluster build, sticky: a rendezvous of this stream timed out (sf_cluster.h: cluster_fail). Its frames
                                     // report SF_STATUS_SYNC_TIMEOUT and leave the state untouched until sf_clear_sync_timeout
     float inv_max_c, inv_max_d;     // 1/max of the raw pre-weights of that iteration
@@ -159,6 +164,17 @@ __device__ __forceinline__ float *pyr_plane(const KArgs &a, int b, int set, int 
     const int f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.state[b].flip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     float *const *tab = ((set ^ f) & 1) ? a.pyr_pred : a.pyr_new;
     return tab[ch] + (size_t)b * a.n_tot;
+}
+// Level L of the [set][ch] image for READING: the pyramid buffer's, or -- level 0 inside a launch of sequence frames -- the pool
+// frame the stream's StreamState::lvl0 names (read like `flip`: a vector-memory load, uniform, moved to SGPRs by as_global)
+__device__ __forceinline__ const float *pyr_level(const KArgs &a, int b, int set, int ch, int L) {
+    const float *p = pyr_plane(a, b, set, ch) + a.loff[L];
+    if (L == 0) {
+        const unsigned long long o = __hip_atomic_load((const unsigned long long *)&a.state[b].lvl0[set][ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)o), hi = __builtin_amdgcn_readfirstlane((unsigned)(o >> 32));
+        if (lo | hi) p = (const float *)(((unsigned long long)hi << 32) | lo);
+    }
+    return p;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -98,26 +98,64 @@ __device__ __forceinline__ void run_stages(const KArgs &a, int b, int stage_mask
 
 #ifndef SF_CLUSTER
 // prediction := current, current := pool frame f of stream b (what sf_advance_kernel does between two launches), by the
-// workgroup that is about to solve the frame. copy_pred = false: the pyramid buffers have just swapped roles (the old
-// current pyramid IS the prediction pyramid now), only the new frame is copied in.
-__device__ __forceinline__ void advance_stream(const KArgs &a, int b, const float *pool_d, const float *pool_i, int f, bool copy_pred, int tid) {
+// workgroup that is about to solve the frame: the copying form -- the first frame of a launch, or a frame that does not swap
+// its pyramid buffers. Level 0 of the current image is read where it lies (pyr_level: an earlier frame of this launch may have
+// left it in the pool); both images end in the pyramid buffers, the stream's pool references are dropped.
+__device__ __forceinline__ void advance_stream(const KArgs &a, int b, const float *pool_d, const float *pool_i, int f, int tid) {
     typedef float __attribute__((ext_vector_type(4))) f4;
     typedef __attribute__((address_space(1))) const f4 gcf4;
     typedef __attribute__((address_space(1))) f4 gf4;
     const size_t po = (size_t)f * a.n0;
+    const auto src_d = as_global(pyr_level(a, b, 0, 0, 0)), src_i = as_global(pyr_level(a, b, 0, 1, 0));
     const auto cur_d = as_global(pyr_plane(a, b, 0, 0)), cur_i = as_global(pyr_plane(a, b, 0, 1));
     const auto pred_d = as_global(pyr_plane(a, b, 1, 0)), pred_i = as_global(pyr_plane(a, b, 1, 1));
     const auto nd = as_global(pool_d + po), ni = as_global(pool_i + po);
     for (int q = tid * 4; q < a.n0; q += SF_NT * 4) {
         const f4 d = *(gcf4 *)(nd + q), i = *(gcf4 *)(ni + q);
-        if (copy_pred) {
-            const f4 cd = *(gcf4 *)(cur_d + q), ci = *(gcf4 *)(cur_i + q);
-            *(gf4 *)(pred_d + q) = cd;
-            *(gf4 *)(pred_i + q) = ci;
-        }
+        const f4 cd = *(gcf4 *)(src_d + q), ci = *(gcf4 *)(src_i + q);
+        *(gf4 *)(pred_d + q) = cd;
+        *(gf4 *)(pred_i + q) = ci;
         *(gf4 *)(cur_d + q) = d;
         *(gf4 *)(cur_i + q) = i;
     }
+    __syncthreads();
+    if (tid < 4) ((const float **)a.state[b].lvl0)[tid] = nullptr;
+}
+// The swapping form (from the second frame of a launch on): the pyramid the previous frame built for ITS current image is this
+// frame's prediction pyramid -- the two buffers swap roles -- and level 0 of both images is READ IN PLACE: the previous frame's
+// level 0 becomes the prediction's (wherever it lies), the new frame's is its pool frame. Nothing is copied (round 5; the launch
+// used to copy the new frame into the buffer: 16 B per pixel and frame).
+__device__ __forceinline__ void advance_stream_in_place(const KArgs &a, int b, const float *pool_d, const float *pool_i, int f, int flip, int tid) {
+    __syncthreads();
+    if (tid == 0) {
+        StreamState &st = a.state[b];
+        st.flip = flip ^ 1;
+        st.lvl0[1][0] = st.lvl0[0][0];
+        st.lvl0[1][1] = st.lvl0[0][1];
+        st.lvl0[0][0] = pool_d + (size_t)f * a.n0;
+        st.lvl0[0][1] = pool_i + (size_t)f * a.n0;
+    }
+    __syncthreads();
+}
+// End of a launch: level 0 of an image that is still read from the pool goes into its pyramid buffer (the host, and the next
+// launch, find every image where they always were), then the references are dropped.
+__device__ __forceinline__ void materialise_level0(const KArgs &a, int b, int tid) {
+    typedef float __attribute__((ext_vector_type(4))) f4;
+    typedef __attribute__((address_space(1))) const f4 gcf4;
+    typedef __attribute__((address_space(1))) f4 gf4;
+    __syncthreads();
+    for (int set = 0; set < 2; set++)
+        for (int ch = 0; ch < 2; ch++) {
+            const float *src = pyr_level(a, b, set, ch, 0);
+            float *dst = pyr_plane(a, b, set, ch);
+            if (src == dst) continue;  // (uniform)
+            const auto gs = as_global(src);
+            const auto gd = as_global(dst);
+            for (int q = tid * 4; q < a.n0; q += SF_NT * 4) *(gf4 *)(gd + q) = *(gcf4 *)(gs + q);
+        }
+    __syncthreads();
+    if (tid < 4) ((const float **)a.state[b].lvl0)[tid] = nullptr;
+    __syncthreads();
 }
 // both pyramids of stream b, every level: exchange the contents of the two buffers (a stream left with flip = 1 at the
 // end of a launch -- a frame_index < 0 broke the alternation -- goes back to the layout the host expects)
@@ -194,12 +232,25 @@ __global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__
                     const int flip = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.state[b].flip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                     const bool swap = fl.flip_ok && k > 0 && (flip == 1 || k < fl.n_frames - 1);
                     if (swap) {
-                        __syncthreads();
-                        if (tid == 0) a.state[b].flip = flip ^ 1;
-                        __syncthreads();
                         mask &= ~ST_PYR_OLD;
+                        if (fl.flip_ok > 1) {
+                            advance_stream_in_place(a, b, fl.pool_d, fl.pool_i, f, flip, tid);
+                        } else {  // (-> SF_NO_POOL_IN_PLACE: round 4's form, the new frame copied into the buffer; A/B and bisection)
+                            __syncthreads();
+                            if (tid == 0) a.state[b].flip = flip ^ 1;
+                            __syncthreads();
+                            const auto cur_d = as_global(pyr_plane(a, b, 0, 0)), cur_i = as_global(pyr_plane(a, b, 0, 1));
+                            const auto nd = as_global(fl.pool_d + (size_t)f * a.n0), ni = as_global(fl.pool_i + (size_t)f * a.n0);
+                            typedef float __attribute__((ext_vector_type(4))) f4;
+                            for (int q = tid * 4; q < a.n0; q += SF_NT * 4) {
+                                const f4 d = *(__attribute__((address_space(1))) const f4 *)(nd + q), i = *(__attribute__((address_space(1))) const f4 *)(ni + q);
+                                *(__attribute__((address_space(1))) f4 *)(cur_d + q) = d;
+                                *(__attribute__((address_space(1))) f4 *)(cur_i + q) = i;
+                            }
+                        }
+                    } else {
+                        advance_stream(a, b, fl.pool_d, fl.pool_i, f, tid);
                     }
-                    advance_stream(a, b, fl.pool_d, fl.pool_i, f, !swap, tid);
                 }
                 __syncthreads();
             }
@@ -208,11 +259,14 @@ __global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__
         run_stages(a, b, mask, fl.im_count + k, *(LDS FrameShared *)&sh, *(LDS ClusterShared *)&cs, tid);
         if (fl.frame_done) {
             if (fl.traj && tid < 16) fl.traj[((size_t)k * a.batch + b) * 16 + tid] = a.state[b].T[tid];
-            if (k == fl.n_frames - 1 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.state[b].flip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
-                __syncthreads();
-                unflip_stream(a, b, tid);
-                __syncthreads();
-                if (tid == 0) a.state[b].flip = 0;
+            if (k == fl.n_frames - 1) {
+                if (fl.seq_index) materialise_level0(a, b, tid);
+                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.state[b].flip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
+                    __syncthreads();
+                    unflip_stream(a, b, tid);
+                    __syncthreads();
+                    if (tid == 0) a.state[b].flip = 0;
+                }
             }
             // everything this workgroup wrote for the stream is visible to whoever takes its next frame: every wave's
             // stores have left, then ONE agent-scope release, then the counter (MI355X_MICROARCH.md, inter-workgroup visibility)
@@ -221,8 +275,8 @@ __global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (__hip_atomic_load(fl.frame_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0)  // (< 0: a later frame gave up on this stream)
-                    __hip_atomic_store(fl.frame_done + b, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int seen = k;  // k -> k + 1, unless a later frame has given up on this stream (-1 stays)
+                __hip_atomic_compare_exchange_strong(fl.frame_done + b, &seen, k + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         // NOTE: the loop body must END with a barrier. With a lane-0-only block here the compiler

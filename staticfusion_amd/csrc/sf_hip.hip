@@ -58,6 +58,10 @@ __global__ __launch_bounds__(256) void sf_clear_sync_kernel(StreamState *state, 
     if (b < batch) {
         state[b].sync_epoch = 0;
         state[b].sync_failed = 0;
+        // a multi-frame launch that gave up on a stream (sf_frame_kernels.hip: skip) may have left its pyramid buffers swapped and
+        // level 0 referring to the caller's pool: back to the layout the host assumes (the images are to be set again)
+        state[b].flip = 0;
+        for (int q = 0; q < 4; q++) ((const float **)state[b].lvl0)[q] = nullptr;
     }
 }
 
@@ -499,10 +503,10 @@ int sf_synchronize(sf_handle *h) {
 
 int sf_clear_sync_timeout(sf_handle *h) {
     if (!h) return fail(SF_ERR_ARG, "null");
-    if (!h->k.cluster_g) return SF_OK;
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));  // no launch of this handle is polling the granules any more
-    HIP_TRY(hipMemsetAsync(h->k.sync, 0, sizeof(unsigned long long) * (size_t)h->k.batch * 2 * h->k.cluster_g * SF_SYNC_WORDS, h->stream));
+    if (h->k.cluster_g)
+        HIP_TRY(hipMemsetAsync(h->k.sync, 0, sizeof(unsigned long long) * (size_t)h->k.batch * 2 * h->k.cluster_g * SF_SYNC_WORDS, h->stream));
     hipLaunchKernelGGL(sf_clear_sync_kernel, dim3((h->k.batch + 255) / 256), dim3(256), 0, h->stream, h->k.state, h->k.batch);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));

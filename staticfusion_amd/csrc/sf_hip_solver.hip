@@ -21,6 +21,11 @@ __global__ __launch_bounds__(256) void sf_advance_kernel(float *cur_d, float *cu
     }
 }
 
+// sf_microbench_copy: what a plain streaming kernel reaches (16-byte loads and stores, grid-stride)
+__global__ __launch_bounds__(256) void sf_copy_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n16) {
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n16; q += (size_t)gridDim.x * 256) dst[q] = src[q];
+}
+
 extern "C" {
 
 static int upload_pair(sf_handle *h, float *const *set, int stream, const float *depth, const float *intensity) {
@@ -256,9 +261,15 @@ static int process_frames(sf_handle *h, const void *pool_depth, const void *pool
         ml.seq_index = h->d_multi_index;
         ml.pool_d = (const float *)pool_depth;
         ml.pool_i = (const float *)pool_intensity;
-        ml.flip_ok = std::getenv("SF_NO_PYRAMID_FLIP") ? 0 : 1;  // (A/B switch; results are identical either way)
+        // 2: swap the pyramid buffers and read level 0 of both images in the pool; 1: swap, copy the new frame in (round 4's form);
+        // 0: copy both images, rebuild the prediction's pyramid (A/B switches; the results are identical in all three)
+        ml.flip_ok = std::getenv("SF_NO_PYRAMID_FLIP") ? 0 : std::getenv("SF_NO_POOL_IN_PLACE") ? 1 : 2;
     }
-    if (T_out) ml.traj = h->d_traj;
+    if (T_out) {
+        ml.traj = h->d_traj;
+        // a frame the launch skips (its stream's previous frame never finished: SF_STATUS_SYNC_TIMEOUT) leaves its row NaN
+        HIP_TRY(hipMemsetAsync(h->d_traj, 0xff, sizeof(float) * 16 * B * n_frames, h->stream));
+    }
     const int m = ST_PYR_OLD | solve_mask(h, 1) | ST_SEGM_IMAGE | ST_PUSH_HISTORY | ST_AUTO_RESIDUALS;
     if (int e = launch(h, m, im_count0, n_frames, &ml)) return e;
     if (T_out) {
@@ -542,6 +553,37 @@ int sf_microbench_pass(sf_handle *h, int which, int variant, int reps, float *el
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     if (elapsed_ms) *elapsed_ms = ms;
+    return SF_OK;
+}
+int sf_microbench_copy(sf_handle *h, size_t bytes, int reps, float *elapsed_ms) {
+    if (!h || !elapsed_ms || bytes < 4096 || (bytes & 15u) || bytes > ((size_t)1 << 36) || reps < 1 || reps > 1000) return fail(SF_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    void *src = nullptr, *dst = nullptr;
+    if (hipMalloc(&src, bytes) != hipSuccess || hipMalloc(&dst, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        if (src) (void)hipFree(src);
+        return fail(SF_ERR_NOMEM, "sf_microbench_copy: scratch blocks");
+    }
+    int e = SF_OK;
+    float ms = 0.f;
+    const size_t n16 = bytes / 16;
+    const int grid = (int)std::min<size_t>((n16 + 255) / 256, (size_t)std::max(1, h->max_blocks / std::max(1, h->wg_per_cu)) * 8);
+    auto body = [&]() -> int {
+        HIP_TRY(hipMemsetAsync(src, 0x3c, bytes, h->stream));
+        hipLaunchKernelGGL(sf_copy_kernel, dim3(grid), dim3(256), 0, h->stream, (const float4 *)src, (float4 *)dst, n16);  // warm-up: page tables, clocks
+        HIP_TRY(hipEventRecord(h->ev0, h->stream));
+        for (int r = 0; r < reps; r++) hipLaunchKernelGGL(sf_copy_kernel, dim3(grid), dim3(256), 0, h->stream, (const float4 *)src, (float4 *)dst, n16);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(h->ev1, h->stream));
+        HIP_TRY(hipEventSynchronize(h->ev1));
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        return SF_OK;
+    };
+    e = body();
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    if (e) return e;
+    *elapsed_ms = ms;
     return SF_OK;
 }
 int sf_last_solver_kernel_ms(sf_handle *h, float *ms) {

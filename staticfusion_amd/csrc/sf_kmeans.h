@@ -142,6 +142,7 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
     const int lane = tid & 63, wave = tid >> 6;
     const size_t sb = (size_t)b * a.n_tot;
     const auto depth = as_global((const float *)pyr_plane(a, b, 0, 0));
+    const auto depth0 = as_global(pyr_level(a, b, 0, 0, 0));  // level 0 may lie in the caller's frame pool (pyr_level)
     const LevelCoord lc0 = level_coord(a, 0), lc1 = level_coord(a, 1);
     const auto labels = as_global(a.labels + sb);
     StreamState &st = a.state[b];
@@ -491,7 +492,7 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
                 in[q] = (blk0 + q < n_blocks) && u < cols0 && v < rows0;
                 const int uc = min(u, cols0 - 1), vc = min(v, rows0 - 1);
                 pidx[q] = vc + uc * rows0;
-                pz[q] = gld(depth, pidx[q]);
+                pz[q] = gld(depth0, pidx[q]);
                 px[q] = coord_x(lc0, uc, pz[q]);
                 py[q] = coord_y(lc0, vc, pz[q]);
                 low[q] = gld(labels, o1 + (vc / 2) + (uc / 2) * rows_km);
@@ -527,9 +528,9 @@ __device__ __noinline__ void stage_kmeans(const KArgs &a, int b, LDS KmShared &s
                 split_uv(lc0, idx, uu[q], vv[q]);
                 in[q] = (base + q * SF_NT < n0) && uu[q] < cols0 - 1 && vv[q] < rows0 - 1;
                 const int i1 = in[q] ? idx + 1 : idx, i2 = in[q] ? idx + rows0 : idx;  // the last row / column has no neighbour
-                dz[q] = gld(depth, idx);
-                dzd[q] = gld(depth, i1);
-                dzr[q] = gld(depth, i2);
+                dz[q] = gld(depth0, idx);
+                dzd[q] = gld(depth0, i1);
+                dzr[q] = gld(depth0, i2);
                 la[q] = gld(labels, idx);
                 ld[q] = gld(labels, i1);
                 lr[q] = gld(labels, i2);

@@ -31,7 +31,7 @@ __device__ __noinline__ void stage_pyramid(const KArgs &a, int b, int which, int
             const auto inten = as_global(pyr_plane(a, b, si == 0 ? 1 : 0, 1));
             const auto d_here = depth + a.loff[L], i_here = inten + a.loff[L];
             {
-            const auto d_prev = depth + a.loff[L - 1], i_prev = inten + a.loff[L - 1];
+            const auto d_prev = as_global(pyr_level(a, b, si == 0 ? 1 : 0, 0, L - 1)), i_prev = as_global(pyr_level(a, b, si == 0 ? 1 : 0, 1, L - 1));
             const int rows_p = a.lrows[L - 1];
             // A wave produces 62 consecutive pixels of the level (column-major: consecutive rows v of a column u); lanes 0 and 63
             // are halo lanes. Every lane loads rows 2v, 2v+1 of the four input columns 2u-1 .. 2u+2 as 8-byte pairs (8 loads

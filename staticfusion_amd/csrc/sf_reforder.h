@@ -312,11 +312,14 @@ __device__ __forceinline__ bool ordered_tile_splat(const SplatGeom &g, const Lev
 template <class Src>
 __device__ __forceinline__ void ordered_splat(const KArgs &a, const SplatGeom &g, const LevelCoord &lc, int rows_i, int cols_i,
                                               const Src &src, gptr<long long> acc_d, gptr<long long> acc_i, gptr<int> list,
-                                              LDS SplatWin &win, int tid) {
+                                              LDS SplatWin &win, int tid, long long *fallbacks = nullptr) {
 #ifndef SF_ORDERED_TILE_SPLAT
 #define SF_ORDERED_TILE_SPLAT 1  // 0: always the lists (A/B and bisection builds)
 #endif
-    if (SF_ORDERED_TILE_SPLAT && rows_i <= SPLAT_TV && ordered_tile_splat(g, lc, rows_i, cols_i, src, acc_d, acc_i, win, tid)) return;
+    if (SF_ORDERED_TILE_SPLAT && rows_i <= SPLAT_TV) {
+        if (ordered_tile_splat(g, lc, rows_i, cols_i, src, acc_d, acc_i, win, tid)) return;
+        if (tid == 0 && fallbacks) *fallbacks += 1;  // (a counter of the stream's profile: tests want to know that this path ran)
+    }
     ro_splat(g, lc, rows_i * cols_i, src, acc_d, acc_i, list, tid);
 }
 

@@ -29,7 +29,7 @@ __device__ __forceinline__ RoPlanes ro_planes(const KArgs &a, int b, int L, cons
     const size_t rb = (size_t)uniform_i(s.rec_slot) * a.n0;
 #pragma unroll
     for (int q = 0; q < R_COUNT; q++) r.p[q] = as_global((const float *)a.rec[q] + rb);
-    r.dnew = as_global((const float *)pyr_plane(a, b, 0, 0) + a.loff[L]);
+    r.dnew = as_global(pyr_level(a, b, 0, 0, L));
     r.lab = as_global((const uint8_t *)a.rec_lab + rb);
     return r;
 }
@@ -163,7 +163,7 @@ __device__ __noinline__ void ro_seg_prior(const KArgs &a, int b, int L, LDS Solv
     const int n = a.ln[L];
     const float kz = a.p.kz;
     const size_t sb = (size_t)b * a.n_tot + a.loff[L], rb = (size_t)cl_slot(cs) * a.n0;
-    const auto dnew = as_global((const float *)pyr_plane(a, b, 0, 0) + a.loff[L]);
+    const auto dnew = as_global(pyr_level(a, b, 0, 0, L));
     const auto dwp = as_global((const float *)a.rec[R_DW] + rb);
     const auto labp = as_global((const uint8_t *)a.labels + sb);
     const auto vlab = as_global((const uint8_t *)a.rec_lab + rb);

@@ -34,7 +34,7 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
     const int rows = a.lrows[0], cols = a.lcols[0], n = a.ln[0];
     const int G = cl_G(cs), rank = cl_rank(cs);
     const size_t sb = (size_t)b * a.n_tot, rb = (size_t)cl_slot(cs) * a.n0;
-    const auto dcur = as_global((const float *)pyr_plane(a, b, 0, 0)), icur = as_global((const float *)pyr_plane(a, b, 0, 1));  // depthCurrent / intensityCurrent
+    const auto dcur = as_global(pyr_level(a, b, 0, 0, 0)), icur = as_global(pyr_level(a, b, 0, 1, 0));  // depthCurrent / intensityCurrent
     const auto labels0 = as_global((const uint8_t *)a.labels + sb);
     const int idx_to_warp = (index - SF_HISTORY) % SF_HISTORY;
     const auto dbuf = as_global((const float *)a.hist_d + ((size_t)idx_to_warp * a.batch + b) * a.n0);
@@ -102,7 +102,11 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
     } src{dbuf, ibuf, dcur, inv_f_i, g.disp_u_i, g.disp_v_i};
     if (ordered) {
         LevelCoord lc0 = level_coord(a, 0);
+#if SF_RESIDUALS_ORDERED_WRAPPER  // bisection switch for the round-4 fault (profiles/HISTORY.md): the wrapper with its (dead, here) tile path
+        ordered_splat(a, g, lc0, rows, cols, src, acc_d, acc_i, ro_list_of(a, rb, b), s.win, tid);
+#else
         ro_splat(g, lc0, n, src, acc_d, acc_i, ro_list_of(a, rb, b), tid);  // (full resolution: the per-cell lists; the LDS tiles serve the solver's coarse levels)
+#endif
     } else
         tiled_splat(g, rows, cols, src, acc_d, acc_i, s.win, s.marks, tid, rank, G, lazy, &st.prof[PF_SPLAT_REPLAYS]);
     cluster_rendezvous(cs, tid);
@@ -271,7 +275,7 @@ __device__ __noinline__ void stage_push_history(const KArgs &a, int b, int im_co
     const int G = cl_G(cs), rank = cl_rank(cs);
     StreamState &st = a.state[b];
     const int slot = im_count % SF_HISTORY, n = copy_images ? a.ln[0] : 0;
-    const auto dcur = as_global((const float *)pyr_plane(a, b, 0, 0)), icur = as_global((const float *)pyr_plane(a, b, 0, 1));
+    const auto dcur = as_global(pyr_level(a, b, 0, 0, 0)), icur = as_global(pyr_level(a, b, 0, 1, 0));
     const auto dbuf = as_global(a.hist_d + ((size_t)slot * a.batch + b) * a.n0);
     const auto ibuf = as_global(a.hist_i + ((size_t)slot * a.batch + b) * a.n0);
     for (int base = tid * 4 + rank * SF_NT * 8; base < n; base += SF_NT * 4 * 2 * G) {  // 16-byte copies, two per trip

@@ -232,10 +232,10 @@ __device__ __forceinline__ void split_index(const LevelGeom &g, int idx, float &
 //  accumulators are read by the linearisation.
 // ---------------------------------------------------------------------------------------------
 __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveShared &s, LDS ClusterShared &cs, int tid) {
-    const int rows_i = a.lrows[L], cols_i = a.lcols[L], n = a.ln[L], o = a.loff[L];
+    const int rows_i = a.lrows[L], cols_i = a.lcols[L], n = a.ln[L];
     const int G = cl_G(cs), rank = cl_rank(cs);
     const size_t rb = (size_t)cl_slot(cs) * a.n0;
-    const auto dpred = as_global((const float *)pyr_plane(a, b, 1, 0) + o), ipred = as_global((const float *)pyr_plane(a, b, 1, 1) + o);
+    const auto dpred = as_global(pyr_level(a, b, 1, 0, L)), ipred = as_global(pyr_level(a, b, 1, 1, L));
     const auto acc_d = as_global(a.acc_d + rb);
     const auto acc_i = as_global(a.acc_i + rb);
 
@@ -281,7 +281,7 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
         }
     } src{dpred, ipred, level_coord(a, L)};
     if (ordered)
-        ordered_splat(a, g, level_coord(a, L), rows_i, cols_i, src, acc_d, acc_i, ro_list_of(a, rb, b), s.win, tid);
+        ordered_splat(a, g, level_coord(a, L), rows_i, cols_i, src, acc_d, acc_i, ro_list_of(a, rb, b), s.win, tid, &a.state[b].prof[PF_ORDERED_FALLBACKS]);
     else
         tiled_splat(g, rows_i, cols_i, src, acc_d, acc_i, s.win, s.marks, tid, rank, G, lazy, &a.state[b].prof[PF_SPLAT_REPLAYS]);
     cluster_rendezvous(cs, tid);  // all atomics of the workgroup(s) performed: the linearisation reads the cells with atomic loads
@@ -301,8 +301,8 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
     const int rows_i = a.lrows[L], cols_i = a.lcols[L], o = a.loff[L];
     const int G = cl_G(cs), rank = cl_rank(cs);  // a cluster's workgroups take every G-th tile
     const size_t sb = (size_t)b * a.n_tot, rb = (size_t)cl_slot(cs) * a.n0;
-    const auto dnew = as_global((const float *)pyr_plane(a, b, 0, 0) + o), inew = as_global((const float *)pyr_plane(a, b, 0, 1) + o);
-    const auto dpred = as_global((const float *)pyr_plane(a, b, 1, 0) + o), ipred = as_global((const float *)pyr_plane(a, b, 1, 1) + o);
+    const auto dnew = as_global(pyr_level(a, b, 0, 0, L)), inew = as_global(pyr_level(a, b, 0, 1, L));
+    const auto dpred = as_global(pyr_level(a, b, 1, 0, L)), ipred = as_global(pyr_level(a, b, 1, 1, L));
     const auto acc_d = as_global((const long long *)a.acc_d + rb), acc_i = as_global((const long long *)a.acc_i + rb);
     const auto labels = as_global((const uint8_t *)a.labels + sb + o);
     gptr<float> rec[R_COUNT];
@@ -573,7 +573,7 @@ __device__ __noinline__ void solve_seg_prior(const KArgs &a, int b, int L, LDS S
     const int n = a.ln[L];
     const float kz = a.p.kz;
     const size_t sb = (size_t)b * a.n_tot + a.loff[L], rb = (size_t)cl_slot(cs) * a.n0;
-    const auto dnew = uniform_ptr((gcfloat *)(pyr_plane(a, b, 0, 0) + a.loff[L]));
+    const auto dnew = uniform_ptr((gcfloat *)pyr_level(a, b, 0, 0, L));
     const auto dwp = uniform_ptr((gcfloat *)(a.rec[R_DW] + rb));
     const auto labp = uniform_ptr((gcu8 *)(a.labels + sb));
     if (tid < SF_NC) {
@@ -881,7 +881,7 @@ __device__ __forceinline__ IrlsCtx make_irls_ctx(const KArgs &a, int b, int L, c
     const size_t rb = (size_t)uniform_i(s.rec_slot) * a.n0;
 #pragma unroll
     for (int q = 0; q < R_COUNT; q++) c.rp.p[q] = uniform_ptr((gcfloat *)(a.rec[q] + rb));
-    c.rp.dnew = uniform_ptr((gcfloat *)(pyr_plane(a, b, 0, 0) + a.loff[L]));
+    c.rp.dnew = uniform_ptr((gcfloat *)pyr_level(a, b, 0, 0, L));
     c.rp.lab = uniform_ptr((gcu8 *)(a.rec_lab + rb));
     c.rp.with_labels = uniform_i(a.p.segmentation_enabled);
     c.n = uniform_i(s.px_end);
@@ -1573,7 +1573,7 @@ __device__ __forceinline__ void debug_rows(const KArgs &a, int b, float *out, in
     g.inv_max_c = st.inv_max_c;
     g.inv_max_d = st.inv_max_d;
     g.first = st.last_first;
-    const float *dnew = pyr_plane(a, b, 0, 0) + a.loff[L];
+    const float *dnew = pyr_level(a, b, 0, 0, L);
     for (int idx = gtid; idx < n; idx += gstride) {
         const float dw = a.rec[R_DW][rb + idx];
 #if SF_REFORDER && SF_RO_BEHIND

@@ -101,11 +101,12 @@ class Scene:
         self.sphere_r = 0.25
         self.sphere_tex = Texture(sphere_seed)
 
-    def render(self, T_cam, W=640, H=480, sphere_offset=(0.0, 0.0, 0.0), fovh=FOVH):
-        """Ray-cast from a camera with pose T_cam (camera -> world). Returns (depth[m], intensity) HxW float64."""
+    def render(self, T_cam, W=640, H=480, sphere_offset=(0.0, 0.0, 0.0), fovh=FOVH, stride=1):
+        """Ray-cast from a camera with pose T_cam (camera -> world). Returns (depth[m], intensity) HxW float64.
+        stride = 2 casts only the rays of the pixels a [::2, ::2] decimation keeps (H/2 x W/2 output)."""
         f = W / (2.0 * np.tan(0.5 * fovh))
         cx, cy = W / 2.0 - 1.0, H / 2.0 - 1.0  # decimation-consistent principal point (see module doc)
-        u, v = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+        u, v = np.meshgrid(np.arange(0, W, stride, dtype=np.float64), np.arange(0, H, stride, dtype=np.float64))
         rays_c = np.stack([(u - cx) / f, (v - cy) / f, np.ones_like(u)], axis=-1)
         R, o = T_cam[:3, :3], T_cam[:3, 3]
         d = rays_c @ R.T
@@ -143,8 +144,9 @@ class Scene:
         return depth, inten
 
 
-def quantise_and_decimate(depth, inten, max_depth=None):
-    """uint16 mm depth / 8-bit grey, like the reference's loaders, then [::2, ::2]."""
+def quantise_and_decimate(depth, inten, max_depth=None, decimate=True):
+    """uint16 mm depth / 8-bit grey, like the reference's loaders, then [::2, ::2] (decimate=False: the images were
+    rendered with stride 2 -- only the rays that survive the decimation, the same values)."""
     d_mm = np.clip(np.rint(depth * 1000.0), 0, 65535).astype(np.uint16)
     if max_depth is not None:
         d_mm = np.where(depth < max_depth, d_mm, 0).astype(np.uint16)
@@ -152,6 +154,8 @@ def quantise_and_decimate(depth, inten, max_depth=None):
     g8 = np.clip(np.rint(inten * 255.0), 0, 255).astype(np.uint8)
     x = g8.astype(np.float32) * np.float32(1.0 / 255.0)
     i = np.float32(0.299) * x + np.float32(0.587) * x + np.float32(0.114) * x  # FrontEnd.cpp:236
+    if not decimate:
+        return np.ascontiguousarray(d), np.ascontiguousarray(i.astype(np.float32))
     return np.ascontiguousarray(d[::2, ::2]), np.ascontiguousarray(i[::2, ::2].astype(np.float32))
 
 
@@ -212,15 +216,57 @@ def sequence_trajectory(seed, frames, scale=1.0):
 def _render_sequence_frame(args):
     seed, pose, offset, sphere, W, H = args
     scene = Scene(seed=seed, sphere=sphere, sphere_seed=seed + 4444)
-    return quantise_and_decimate(*scene.render(pose, W, H, sphere_offset=offset if sphere else (0, 0, 0)))
+    # stride 2: only the rays of the pixels the loaders' decimation keeps (every operation of render() is per pixel: the same
+    # bits as rendering all of them and dropping three quarters, tests/test_capi_and_host.py; 0.03 s instead of 0.12 s a frame)
+    return quantise_and_decimate(*scene.render(pose, W, H, sphere_offset=offset if sphere else (0, 0, 0), stride=2), decimate=False)
 
 
 def make_sequence(seed, frames, sphere=True, out_rows=240, out_cols=320, scale=1.0, pool=None):
     """One synthetic RGB-D sequence: `frames` (depth, intensity) QVGA images rendered at 2x the output size along
     sequence_trajectory(seed). T_gt[k] = pose_{k-1}^-1 pose_k is what the solver should report for frame k against frame
-    k - 1 as prediction. `pool`: an optional multiprocessing pool for the ray casting (0.17 s per VGA frame and core)."""
+    k - 1 as prediction. `pool`: an optional multiprocessing pool for the ray casting (0.03 s per frame and core)."""
     poses, offsets = sequence_trajectory(seed, frames, scale)
     jobs = [(seed, poses[k], offsets[k], sphere, 2 * out_cols, 2 * out_rows) for k in range(frames)]
     imgs = pool.map(_render_sequence_frame, jobs, chunksize=4) if pool is not None else [_render_sequence_frame(j) for j in jobs]
     T_gt = [np.eye(4)] + [np.linalg.inv(poses[k - 1]) @ poses[k] for k in range(1, frames)]
     return {"frames": imgs, "poses": poses, "T_gt": T_gt}
+
+
+def _source_tag():
+    """A short hash of this file: cached renderings belong to the generator that made them."""
+    import hashlib
+
+    with open(__file__.replace(".pyc", ".py"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:10]
+
+
+def sequence_arrays(seed, frames, out_rows=240, out_cols=320, pool=None, cache_dir=None):
+    """make_sequence(seed, frames) in the layout of the solver's HBM frame pools: (depth [frames][n0], intensity [frames][n0],
+    T_gt [frames][4][4]) with column-major images. With `cache_dir` a sequence rendered before is read back from there; the
+    file name carries the seed, the frame count, the resolution and a hash of this generator, the shape is checked on load
+    and the file appears by an atomic rename (several ranks of a node may render the same seed at once: last rename wins,
+    every reader sees a complete file)."""
+    import os
+
+    n0 = out_rows * out_cols
+    path = None
+    if cache_dir:
+        path = os.path.join(cache_dir, "sf_seq_%s_%d_%d_%dx%d_u%d.npz" % (_source_tag(), seed, frames, out_rows, out_cols, os.getuid()))
+        try:
+            with np.load(path) as z:
+                if z["d"].shape == (frames, n0) and z["i"].shape == (frames, n0):
+                    return z["d"], z["i"], z["T_gt"]
+        except Exception:
+            pass
+    seq = make_sequence(seed, frames, sphere=True, out_rows=out_rows, out_cols=out_cols, pool=pool)
+    col = lambda a: np.ascontiguousarray(np.asarray(a, np.float32).T).ravel()
+    d, i = np.stack([col(f[0]) for f in seq["frames"]]), np.stack([col(f[1]) for f in seq["frames"]])
+    T_gt = np.stack(seq["T_gt"])
+    if path:
+        try:
+            tmp = "%s.%d.tmp.npz" % (path, os.getpid())
+            np.savez(tmp, d=d, i=i, T_gt=T_gt)
+            os.replace(tmp, path)
+        except Exception:
+            pass
+    return d, i, T_gt

@@ -244,6 +244,7 @@ def test_abi_version_and_struct_sizes(ora):
 
     hdr = open(os.path.join(ROOT, "include", "sf.h")).read()
     version = int(re.search(r"#define SF_ABI_VERSION (\d+)", hdr).group(1))
+    assert version == capi.ABI_VERSION, "staticfusion_amd/_capi.py mirrors another version of include/sf.h"
     libs = [ora.lib.sfo_abi_version]
     if os.path.exists(sf.LIB):
         libs.append(ctypes.CDLL(sf.LIB).sf_abi_version)
@@ -253,3 +254,27 @@ def test_abi_version_and_struct_sizes(ora):
         assert fn(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == version
         assert a.value == ctypes.sizeof(capi.SfParams) and b.value == ctypes.sizeof(capi.SfFrameStats) and c.value == 32
         assert fn(None, None, None) == version
+
+
+def test_binding_refuses_a_library_of_another_abi(ora, tmp_path, monkeypatch):
+    """the check runs when a library is LOADED (Api.__init__), not only in a unit test."""
+    import staticfusion_amd as sf
+    from oracle import binding
+    from staticfusion_amd import capi
+
+    monkeypatch.setattr(capi, "ABI_VERSION", capi.ABI_VERSION + 1)
+    with pytest.raises(sf.SfError, match="ABI mismatch"):
+        capi.Api(binding.LIB, "sfo_")
+
+
+def test_render_with_stride_two_is_the_decimated_full_render():
+    """The sequence generator casts only the rays of the pixels the loaders' [::2, ::2] decimation keeps (synth.py: stride = 2):
+    the same bits as rendering every pixel and dropping three quarters."""
+    from staticfusion_amd.synth import Scene, quantise_and_decimate, sequence_trajectory
+
+    for seed, k in ((1000, 0), (1001, 57), (1003, 199)):
+        poses, offs = sequence_trajectory(seed, 200)
+        sc = Scene(seed=seed, sphere=True, sphere_seed=seed + 4444)
+        full = quantise_and_decimate(*sc.render(poses[k], 640, 480, sphere_offset=offs[k]))
+        fast = quantise_and_decimate(*sc.render(poses[k], 640, 480, sphere_offset=offs[k], stride=2), decimate=False)
+        assert np.array_equal(full[0], fast[0]) and np.array_equal(full[1], fast[1]), (seed, k)

@@ -213,3 +213,42 @@ def test_strong_roll_takes_the_coarse_levels_out_of_their_tile_windows(hip, ora,
     a, b = sg.stats(), so.stats()
     assert (a.n_outer, a.n_irls) == (b.n_outer, b.n_irls) and a.status == b.status == 0
     assert np.array_equal(sg.labels(0), so.labels(0)) and np.array_equal(sg.b_image() > 0.5, so.b_image() > 0.5)
+
+
+def test_list_fallback_where_the_scratch_blocks_are_shared(hip_auto, pair):
+    """the per-cell source lists of the ordered coarse splat (`ro_splat`, the fall-back of a level whose
+    taps leave a tile's window) live in scratch blocks handed out per STREAM while the handle has one for each, else per
+    WORKGROUP of the launch (sf_reforder.h: ro_list_of, `blockIdx.x`). Here: one multi-frame launch of 2048 QVGA streams on the
+    throughput build -- more streams than resident workgroups, frames of a stream on different workgroups -- in which every third
+    stream is the strong-roll pair (its 40 x 30 level falls back, counted) and the others are ordinary pairs: every stream's pose of
+    every frame, its labels, b and b image equal, bit for bit, the same stream solved in a handle of two."""
+    import staticfusion_amd as sf
+
+    api = hip_auto.with_variant("throughput")
+    roll = make_pair(seed=17, sphere=True, out_rows=240, out_cols=320, xi=(0.25, 0.0, 0.0, 0.25, 0.0, 0.0))
+    plain = pair(seed=7, sphere=True, rows=240, cols=320)
+    K = 7  # frames 0 .. 6 of every stream in ONE launch: the last two with the five-frame residuals
+    which = lambda b: roll if b % 3 == 0 else plain
+
+    def run(batch, kinds):
+        s = make_solver(api, 240, 320, driver_params(api), batch=batch)
+        for b in range(batch):
+            s.set_current(b, *kinds(b)["new"])
+            s.set_prediction(b, *kinds(b)["old"])
+        T = s.process_frames(0, K, trajectory=True)
+        return s, T
+
+    ref, T_ref = run(2, lambda b: (roll, plain)[b])
+    assert ref.ordered_fallbacks() >= K, "the roll pair did not send a level to the lists: this test would test nothing"
+    B = 2048
+    big, T = run(B, which)
+    assert big.resident_workgroups()[1] < B, "the batch must exceed the resident workgroups (scratch blocks per workgroup, not per stream)"
+    assert big.ordered_fallbacks() >= K * ((B + 2) // 3)
+    for b in range(B):
+        r = 0 if b % 3 == 0 else 1
+        assert np.array_equal(T[:, b], T_ref[:, r]), b
+    for b in list(range(0, 64)) + list(range(B - 64, B)) + list(range(700, 764)):
+        r = 0 if b % 3 == 0 else 1
+        assert np.array_equal(big.labels(0, b), ref.labels(0, r)) and np.array_equal(big.b_image(b), ref.b_image(r)), b
+        assert np.array_equal(big.b(b), ref.b(r)) and np.array_equal(big.cluster_residuals(b), ref.cluster_residuals(r), equal_nan=True), b
+    assert big.stats(0).status == ref.stats(0).status

@@ -26,3 +26,7 @@ build all_shortcuts    RO_FLAGS="-DSF_RO_SPLAT=0 -DSF_RO_ROWS=0 -DSF_RO_P1_FP64=
 # the product's arithmetic everywhere EXCEPT the warp / residual splat of the coarse levels (image levels >= 2: 6 300 of 102 300 pixels at
 # QVGA), which adds the reference's floats in the reference's order: what an ordered coarse splat in the product would buy
 build all_but_coarse_splat RO_FLAGS="-DSF_RO_SPLAT_MIN_LEVEL=2 -DSF_RO_ROWS=0 -DSF_RO_P1_FP64=0 -DSF_RO_LABSUM=0 -DSF_RO_JACOBI=0 -DSF_RO_INIT_RES=0 -DSF_RO_BEHIND=0" RO_FAST_WEIGHTS=1 RO_ROWS_FMA=1 RO_FAST_NORMALISE=1
+# round 5: the floor an ordered splat at ALL levels could reach -- every product shortcut on EXCEPT the
+# integer splat -- and the same with the integer splat kept at image level 0 only (ordered floats at levels >= 1)
+build all_but_splat        RO_FLAGS="-DSF_RO_ROWS=0 -DSF_RO_P1_FP64=0 -DSF_RO_LABSUM=0 -DSF_RO_JACOBI=0 -DSF_RO_INIT_RES=0 -DSF_RO_BEHIND=0" RO_FAST_WEIGHTS=1 RO_ROWS_FMA=1 RO_FAST_NORMALISE=1
+build all_but_splat_above0 RO_FLAGS="-DSF_RO_SPLAT_MIN_LEVEL=1 -DSF_RO_ROWS=0 -DSF_RO_P1_FP64=0 -DSF_RO_LABSUM=0 -DSF_RO_JACOBI=0 -DSF_RO_INIT_RES=0 -DSF_RO_BEHIND=0" RO_FAST_WEIGHTS=1 RO_ROWS_FMA=1 RO_FAST_NORMALISE=1

@@ -378,8 +378,10 @@ extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_launch_ir
     hipLaunchKernelGGL(sf_irls_pass_kernel, dim3(grid), dim3(SF_NT), 0, st, ka, which, variant, reps, slices);
 #endif
 }
-// bit 0: this object is a reference-order build (sf_reforder.h): the host allocates its source lists and refuses the cluster variant
-extern "C" __attribute__((visibility("hidden"))) int SF_VARIANT_FN(sf_variant_flags)(void) { return SF_REFORDER ? 1 : 0; }
+// bit 0: this object is a reference-order build (sf_reforder.h): the host allocates its source lists and refuses the cluster variant;
+// bits 8..: SF_ORDERED_SPLAT_MAX_PIXELS as THIS object was compiled -- the host sizes the scratch blocks of the ordered coarse splat
+// from it (an experiment built with another threshold would otherwise overrun blocks sized from the host's own constant)
+extern "C" __attribute__((visibility("hidden"))) int SF_VARIANT_FN(sf_variant_flags)(void) { return (SF_REFORDER ? 1 : 0) | (SF_ORDERED_SPLAT_MAX_PIXELS << 8); }
 extern "C" __attribute__((visibility("hidden"))) void SF_VARIANT_FN(sf_variant_geometry)(int *threads, int *blocks_per_cu) {
     *threads = SF_NT;
     *blocks_per_cu = SF_BLOCKS_PER_CU;

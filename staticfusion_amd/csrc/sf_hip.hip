@@ -398,10 +398,12 @@ int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, 
     if (h->reforder) {
         TRY_OR_FREE(dev_alloc(h, &k.ro_list, slots * N0 * RO_LIST_K));  // source indices per cell of every record slot (sf_reforder.h)
     } else {
-        // the ordered float splat of the coarse levels (sf_reforder.h): source lists per RESIDENT WORKGROUP, 1 MB each
-        // (one per stream while that is fewer: sf_reforder.h, ro_list_of)
+        // the ordered float splat of the coarse levels (sf_reforder.h): source lists per RESIDENT WORKGROUP, 256 KB each at the
+        // product's 2048 pixels (one per stream while that is fewer: sf_reforder.h, ro_list_of). The block size is the FRAME
+        // OBJECT's SF_ORDERED_SPLAT_MAX_PIXELS (sf_variant_flags), which indexes them -- never smaller than this file's own
         const size_t wgs = h->cluster_grid ? (size_t)h->cluster_grid : std::min<size_t>(B, (size_t)std::max(h->max_blocks, h->max_blocks_o5));
-        TRY_OR_FREE(dev_alloc(h, &k.ro_list, wgs * SF_ORDERED_SPLAT_MAX_PIXELS * RO_LIST_K));
+        const size_t block_px = std::max<size_t>((size_t)(sf_variant_flags_nt256() >> 8), (size_t)SF_ORDERED_SPLAT_MAX_PIXELS);
+        TRY_OR_FREE(dev_alloc(h, &k.ro_list, wgs * block_px * RO_LIST_K));
         k.ro_blocks = (int)wgs;
     }
     if (k.cluster_g) TRY_OR_FREE(dev_alloc(h, &k.sync, B * 2 * k.cluster_g * SF_SYNC_WORDS));

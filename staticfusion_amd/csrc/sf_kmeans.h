@@ -19,13 +19,20 @@
 #include "sf_device_common.h"
 
 #define KM_CHUNK (SF_NT * SF_LOAD_BATCH)  // pixels per chunk of the Lloyd pass: SF_LOAD_BATCH per lane
+#define KM_ROW (SF_NC + 1)                // entries per row of the candidate table (one of padding: LDS banks)
 
 struct KmShared {
     float cent_a[3 * SF_NC], cent_b[3 * SF_NC];
     union {  // the radix-select histogram (initialisation only) and the centre-distance tables (Lloyd iterations onwards)
         unsigned hist[SF_NC * 256];
         struct {
-            vfloat2 cand[SF_NC * SF_NC];    // row l: (distance to, index of) the other centres, ascending distance: one 8-byte LDS read
+            // row l, entry j: the j-th nearest other centre of centre l as (distance to it, its z, x, y) -- ONE 16-byte LDS read
+            // whose address does not depend on what the previous read returned (round 5; it was (distance, index) and the
+            // centre a second, dependent read) -- and its index, read once, after the walk, for the winner only
+            // (rows of KM_ROW = 25 entries: with 24 the rows of different centres start 96 dwords apart, i.e. on TWO groups of LDS
+            // banks for all of them; 100 dwords apart they start on 16 different ones)
+            vfloat4 cand4[SF_NC * KM_ROW];
+            uint8_t cand_i[SF_NC * KM_ROW];
             float pair_dist[SF_NC * SF_NC];
             float chunk[3][KM_CHUNK];       // (z, x, y) of one chunk of pixels, stably partitioned by cluster
         };
@@ -61,7 +68,8 @@ __device__ __noinline__ void km_sort_centres(LDS KmShared &s, int tid) {
             const float dj = s.pair_dist[l * SF_NC + lj];
             rank += (dj < d || (dj == d && lj < li)) ? 1 : 0;
         }
-        s.cand[l * SF_NC + rank] = vfloat2{d, __int_as_float(li)};
+        s.cand4[l * KM_ROW + rank] = vfloat4{d, s.cent_a[3 * li], s.cent_a[3 * li + 1], s.cent_a[3 * li + 2]};
+        s.cand_i[l * KM_ROW + rank] = (uint8_t)li;
     }
     if (tid < SF_NC) s.cent4[tid] = vfloat4{s.cent_a[3 * tid], s.cent_a[3 * tid + 1], s.cent_a[3 * tid + 2], 0.f};
     __syncthreads();
@@ -69,24 +77,23 @@ __device__ __noinline__ void km_sort_centres(LDS KmShared &s, int tid) {
 
 // pruned nearest-centre search starting from `last` (KMeans.cpp:196-212 and :263-285)
 __device__ __forceinline__ int km_search(const LDS KmShared &s, int last, float pz, float px, float py) {
-    int best = last;
+    int best_j = 0;  // position of the best candidate in row `last` (0: `last` itself)
     const vfloat4 c0 = s.cent4[last];
     const float d_last = sqdist3(c0.x, c0.y, c0.z, pz, px, py);
     float best_d = d_last;
     const float lim = 4.f * d_last;
-    vfloat2 cd = s.cand[last * SF_NC + 1];
+    vfloat4 cd = s.cand4[last * KM_ROW + 1];
     for (int li = 1; li < SF_NC; li++) {
         if (cd.x > lim) break;
-        const int c = __float_as_int(cd.y);
-        const vfloat4 cc = s.cent4[c];
-        if (li + 1 < SF_NC) cd = s.cand[last * SF_NC + li + 1];  // next candidate in flight during the distance
-        const float dl = sqdist3(cc.x, cc.y, cc.z, pz, px, py);
+        const vfloat4 cc = cd;
+        if (li + 1 < SF_NC) cd = s.cand4[last * KM_ROW + li + 1];  // next candidate in flight during the distance
+        const float dl = sqdist3(cc.y, cc.z, cc.w, pz, px, py);
         if (dl < best_d) {
             best_d = dl;
-            best = c;
+            best_j = li;
         }
     }
-    return best;
+    return best_j ? (int)s.cand_i[last * KM_ROW + best_j] : last;
 }
 
 // The same search for N independent pixels of a lane in lock step: the dependent LDS reads of one pixel
@@ -97,18 +104,25 @@ template <int N>
 __device__ __forceinline__ void km_search_n(const LDS KmShared &s, const int (&last)[N], const float (&pz)[N], const float (&px)[N],
                                             const float (&py)[N], const bool (&act)[N], int (&best)[N], int *trips = nullptr) {
     float best_d[N], lim[N];
-    vfloat2 cd[N];
+    int best_j[N], row[N];
 #pragma unroll
     for (int k = 0; k < N; k++) {
         const vfloat4 c0 = s.cent4[last[k]];
-        best[k] = last[k];
+        best_j[k] = 0;
+        row[k] = last[k] * KM_ROW;
         best_d[k] = sqdist3(c0.x, c0.y, c0.z, pz[k], px[k], py[k]);
         // the rows of candidates are sorted by distance, so "this candidate is farther than 4 d_last" stays true once it is:
         // no per-pixel "still running" flag is needed, and a pixel that is not searched gets a limit nothing passes
         lim[k] = act[k] ? 4.f * best_d[k] : -1.f;
-        cd[k] = s.cand[last[k] * SF_NC + 1];
     }
     for (int li = 1; li < SF_NC; li++) {
+        // the trip's N reads (candidate li of every pixel's row: distance and centre in one 16-byte entry) are issued together;
+        // nothing is carried from trip to trip but the running best (a prefetch of the next trip's entries cost 16 more
+        // registers and spilled inside the chunk loop of the 96-register kernel: measured 6.5 % slower than round 4's table)
+        vfloat4 cd[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) cd[k] = s.cand4[row[k] + li];
+        __builtin_amdgcn_sched_barrier(0);
         bool any = false;
 #pragma unroll
         for (int k = 0; k < N; k++) any = any || !(cd[k].x > lim[k]);
@@ -116,25 +130,18 @@ __device__ __forceinline__ void km_search_n(const LDS KmShared &s, const int (&l
 #ifdef SF_KM_FINE_PROFILE
         if (trips) (*trips)++;
 #endif
-        const int nxt = min(li + 1, SF_NC - 1);
-        // all 2 N LDS reads of the trip are issued before any of them is consumed (the compiler otherwise sinks every read
-        // next to its use and waits for each in turn: N dependent LDS round trips per trip instead of one)
-        vfloat4 cc[N];
-        vfloat2 cdn[N];
-#pragma unroll
-        for (int k = 0; k < N; k++) cc[k] = s.cent4[__float_as_int(cd[k].y)];
-#pragma unroll
-        for (int k = 0; k < N; k++) cdn[k] = s.cand[last[k] * SF_NC + nxt];
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            const int c = __float_as_int(cd[k].y);
-            const float dl = sqdist3(cc[k].x, cc[k].y, cc[k].z, pz[k], px[k], py[k]);
+            const float dl = sqdist3(cd[k].y, cd[k].z, cd[k].w, pz[k], px[k], py[k]);
             const bool upd = !(cd[k].x > lim[k]) && (dl < best_d[k]);
             best_d[k] = upd ? dl : best_d[k];
-            best[k] = upd ? c : best[k];
-            cd[k] = cdn[k];
+            best_j[k] = upd ? li : best_j[k];
         }
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const int c = (int)s.cand_i[row[k] + best_j[k]];  // (entry 0 of a row is not read as a candidate: best_j = 0 means `last`)
+        best[k] = best_j[k] ? c : last[k];
     }
 }
 

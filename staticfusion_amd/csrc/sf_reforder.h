@@ -316,8 +316,12 @@ __device__ __forceinline__ void ordered_splat(const KArgs &a, const SplatGeom &g
 #ifndef SF_ORDERED_TILE_SPLAT
 #define SF_ORDERED_TILE_SPLAT 1  // 0: always the lists (A/B and bisection builds)
 #endif
-    if (SF_ORDERED_TILE_SPLAT && rows_i <= SPLAT_TV) {
-        if (ordered_tile_splat(g, lc, rows_i, cols_i, src, acc_d, acc_i, win, tid)) return;
+    // Both conditions go through readfirstlane: `rows_i` arrives in a VGPR (a member of KArgs read through a pointer the
+    // compiler cannot prove uniform) and a branch on it is compiled as a DIVERGENT one -- EXEC masks around code that holds
+    // barriers. That is how round 4's "address 0" fault came about (profiles/HISTORY.md, round 5; tools/diag/exec_lint.py): the
+    // exit block of ro_splat's cell loop got a register copy IN FRONT of the `s_or_b64 exec` that re-enables its lanes.
+    if (SF_ORDERED_TILE_SPLAT && uniform_i(rows_i) <= SPLAT_TV) {
+        if (uniform_i(ordered_tile_splat(g, lc, rows_i, cols_i, src, acc_d, acc_i, win, tid) ? 1 : 0)) return;
         if (tid == 0 && fallbacks) *fallbacks += 1;  // (a counter of the stream's profile: tests want to know that this path ran)
     }
     ro_splat(g, lc, rows_i * cols_i, src, acc_d, acc_i, list, tid);

@@ -61,8 +61,8 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
         s.lab_sum[tid] = 0;
         s.lab_cnt[tid] = 0;
     }
-    const bool ordered = splat_ordered(0, n, G);  // full resolution: the reference-order build, or an image of at most 8192 pixels
-    const bool lazy = ordered || splat_lazy_ok(rows, cols, G);  // see solve_warp
+    const bool ordered = uniform_i(splat_ordered(0, n, G) ? 1 : 0) != 0;  // full resolution: the reference-order build, or an image of at most 2048 pixels
+    const bool lazy = ordered || uniform_i(splat_lazy_ok(rows, cols, G) ? 1 : 0) != 0;  // see solve_warp
     if (!lazy)
     for (int idx = tid + rank * SF_NT; idx < n; idx += SF_NT * G) {  // agent-scope stores: see solve_warp
         if (G > 1) {
@@ -102,11 +102,10 @@ __device__ __noinline__ void stage_residuals(const KArgs &a, int b, int index, b
     } src{dbuf, ibuf, dcur, inv_f_i, g.disp_u_i, g.disp_v_i};
     if (ordered) {
         LevelCoord lc0 = level_coord(a, 0);
-#if SF_RESIDUALS_ORDERED_WRAPPER  // bisection switch for the round-4 fault (profiles/HISTORY.md): the wrapper with its (dead, here) tile path
-        ordered_splat(a, g, lc0, rows, cols, src, acc_d, acc_i, ro_list_of(a, rb, b), s.win, tid);
-#else
-        ro_splat(g, lc0, n, src, acc_d, acc_i, ro_list_of(a, rb, b), tid);  // (full resolution: the per-cell lists; the LDS tiles serve the solver's coarse levels)
-#endif
+        // an image of at most SPLAT_TV rows in LDS tiles, else the per-cell lists. (Round 4 called ro_splat directly here after
+        // this instantiation had faulted at address 0: a miscompiled divergent branch, profiles/HISTORY.md round 5 -- the
+        // conditions of ordered_splat are scalar now and tools/diag/exec_lint.py checks every built library for the pattern.)
+        ordered_splat(a, g, lc0, rows, cols, src, acc_d, acc_i, ro_list_of(a, rb, b), s.win, tid, &st.prof[PF_ORDERED_FALLBACKS]);
     } else
         tiled_splat(g, rows, cols, src, acc_d, acc_i, s.win, s.marks, tid, rank, G, lazy, &st.prof[PF_SPLAT_REPLAYS]);
     cluster_rendezvous(cs, tid);

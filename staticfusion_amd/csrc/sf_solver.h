@@ -243,8 +243,9 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
     // a cluster's workgroups zero every G-th block. Agent-scope (write-through) stores: the cells are only ever touched by
     // agent-scope atomics and atomic loads after this, so the two hand-overs below need no fence (sf_cluster.h)
     // coarse levels (and every level of the reference-order build): the reference's float sums in the reference's order
-    const bool ordered = splat_ordered(L, n, G);
-    const bool lazy = ordered || splat_lazy_ok(rows_i, cols_i, G);  // one workgroup: the splat zeroes / initialises the cells itself
+    // (uniform by construction, made so for the compiler: branches around barriers must be scalar branches, see ordered_splat)
+    const bool ordered = uniform_i(splat_ordered(L, n, G) ? 1 : 0) != 0;
+    const bool lazy = ordered || uniform_i(splat_lazy_ok(rows_i, cols_i, G) ? 1 : 0) != 0;  // one workgroup: the splat zeroes / initialises the cells itself
     if (!lazy)
     for (int idx = tid + rank * SF_NT; idx < n; idx += SF_NT * G) {
         if (G > 1) {

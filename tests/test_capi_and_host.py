@@ -278,3 +278,26 @@ def test_render_with_stride_two_is_the_decimated_full_render():
         full = quantise_and_decimate(*sc.render(poses[k], 640, 480, sphere_offset=offs[k]))
         fast = quantise_and_decimate(*sc.render(poses[k], 640, 480, sphere_offset=offs[k], stride=2), decimate=False)
         assert np.array_equal(full[0], fast[0]) and np.array_equal(full[1], fast[1]), (seed, k)
+
+
+def test_no_vector_instruction_in_front_of_an_exec_restore_at_a_barrier():
+    """tools/diag/exec_lint.py over every built library: the miscompilation behind round 4's "address 0" fault (a register copy that
+    the compiler placed in front of the `s_or_b64 exec` of a loop-exit block that holds a barrier: executed with EXEC = 0, it restores
+    nothing) shows in the disassembly, and no library that ships may contain it. profiles/HISTORY.md, round 5."""
+    import glob
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("exec_lint", os.path.join(ROOT, "tools", "diag", "exec_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    if not os.path.exists(lint.OBJDUMP):
+        pytest.skip("no llvm-objdump in this image")
+    libs = sorted(glob.glob(os.path.join(ROOT, "staticfusion_amd", "csrc", "libsf_hip*.so")))
+    assert any(os.path.basename(p) == "libsf_hip.so" for p in libs)
+    for path in libs:
+        assert len(lint.code_objects(path)) >= 5, path  # (the host objects' kernels + the frame-kernel builds)
+        assert lint.lint(path) == [], path
+    # the lint recognises the pattern (the block as the faulting build had it)
+    bad = "\ts_cbranch_execz .LBB1_7\n.LBB1_7:\n\tv_mov_b64_e32 v[62:63], v[92:93]\n\ts_barrier\n\ts_or_b64 exec, exec, s[10:11]\n"
+    good = "\ts_cbranch_execz .LBB1_7\n.LBB1_7:\n\ts_or_b64 exec, exec, s[10:11]\n\tv_mov_b64_e32 v[62:63], v[92:93]\n\ts_barrier\n"
+    assert len(lint.lint_text(bad)) == 1 and lint.lint_text(good) == []

@@ -202,16 +202,38 @@ def test_warp_with_targets_outside_the_tile_windows(hip, ora, pair):
     d_old[patch] *= 0.3
     fence = {"new": pr["new"], "old": (d_old, pr["old"][1])}
     sg, so = solve_both(hip, ora, 240, 320, lambda a: driver_params(a, debug_planes=1), fence)
-    # (the fence has 1200 depth edges: a pixel or two of validPixels may sit on the other side of a centi-pixel boundary)
-    # (a pixel more or less of validPixels moves the mean residual by 1e-3 and the unclamped b of the cluster it belongs to by
-    # up to 1e-2 -- 1.924 against 1.921 here, both far above the clamp at 1 of the b image, whose decisions are compared exactly)
-    assert_traces_match(sg, so, tol_twist=1e-5, tol_b=1e-2, n_valid_slack=4, rtol_aver=3e-3)
-    # (the b image is the clamped b of each pixel's cluster: the same bound; 6.9e-3 measured in the cluster build, < 3e-4 in the others)
-    assert np.array_equal(sg.b_image() > 0.5, so.b_image() > 0.5) and np.abs(sg.b_image() - so.b_image()).max() < 1e-2
+    # The fence has 1200 depth edges: a last-bit difference of T can put a tap on the other side of a centi-pixel boundary there and
+    # a cell or two in or out of validPixels. The bounds depend on whether that HAPPENED (one blanket tolerance would
+    # hide a regression of the ordered splat's list path). Measured, profiles/r05b_fence_measured.txt: no such pixel in the latency
+    # and cluster builds (b 1.2e-5, mean residual 2.7e-5 relative), two in the throughput build (b 6.9e-3 -- the UNCLAMPED b of the
+    # cluster they belong to, 1.924 against 1.921 --, mean residual 1.2e-3).
+    a, b = sg.stats(), so.stats()
+    flipped = int(np.abs(trace_array(a, "n_valid") - trace_array(b, "n_valid")).max())
+    assert flipped <= 4
+    if flipped:
+        assert_traces_match(sg, so, tol_twist=3e-6, tol_b=1e-2, n_valid_slack=4, rtol_aver=3e-3)
+        assert np.abs(sg.b_image() - so.b_image()).max() < 1e-2
+    else:
+        assert_traces_match(sg, so, tol_twist=2e-6, tol_b=1e-4, rtol_aver=2e-4)
+        assert np.abs(sg.b_image() - so.b_image()).max() < 1e-4
+    assert np.array_equal(sg.b_image() > 0.5, so.b_image() > 0.5)
     for L in range(4):  # level 4 is warped once: Warped := Pred
+        o0 = so.plane(capi.SET_WARPED, 0, L).astype(np.float64)
+        pad = np.pad(o0, 1, mode="edge")
+        nb = np.stack([pad[1 + dv:pad.shape[0] - 1 + dv, 1 + du:pad.shape[1] - 1 + du] for dv in (-1, 0, 1) for du in (-1, 0, 1)])
+        smooth = (nb.max(0) - nb.min(0)) < 0.1  # cells whose 3 x 3 neighbourhood of the oracle's warped depth holds no depth edge
         for ch in range(2):
-            # hard bound: a tap that falls on the other side of a centi-pixel at a fence edge mixes depths 1.9 m apart (0.88 measured)
-            assert_planes_close(sg.plane(capi.SET_WARPED, ch, L), so.plane(capi.SET_WARPED, ch, L), frac=0.97, hard=2.0)
+            d = np.abs(sg.plane(capi.SET_WARPED, ch, L).astype(np.float64) - so.plane(capi.SET_WARPED, ch, L).astype(np.float64))
+            assert np.isfinite(d).all()
+            if L >= 2:
+                # the coarse levels: the fence is gone (3-pixel bands at level 0) and levels 3 / 4 take the reference's ordered float
+                # sums -- every cell to rounding (measured 4.8e-7)
+                assert d.max() <= 5e-6, (L, ch, d.max())
+                continue
+            # away from the depth edges the old tight bounds hold (measured: >= 0.9955 of those cells within 5e-5, worst 4.2e-3) ...
+            assert (d[smooth] <= 5e-5).mean() >= 0.99 and d[smooth].max() <= 1.5e-2, (L, ch, (d[smooth] <= 5e-5).mean(), d[smooth].max())
+            # ... at an edge a tap on the other side of a centi-pixel mixes depths 1.9 m apart (0.88 m measured at level 0, 1.1e-2 at 1)
+            assert (d <= 5e-5).mean() >= 0.99 and d.max() <= (1.0 if L == 0 else 0.05), (L, ch, (d <= 5e-5).mean(), d.max())
     rot, trans = pose_delta(so.T(), sg.T())
     assert rot <= POSE_TOL and trans <= POSE_TOL
     assert np.array_equal(sg.labels(0), so.labels(0))

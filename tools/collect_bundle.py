@@ -30,6 +30,9 @@ for f in sorted(os.listdir(G)):
             json.dump(dd, g)
         json.dump({k: dd[k] for k in ("meta", "summary") if k in dd}, open(os.path.join(P, f.replace(".json", "_summary.json")), "w"), indent=1)
 cp("%s_gputest.log" % T, "%s_gputest_three_variants.log" % T)
+for f in sorted(os.listdir(G)):
+    if f.startswith("%s_long_hunt_" % T) and f.endswith(".json"):
+        cp(f)
 for f in os.listdir(G):
     if f.startswith("traffic_") and f.endswith(".json") and "summary" not in f:
         cp(f)

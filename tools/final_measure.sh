@@ -11,7 +11,7 @@
 set -u
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 mkdir -p gpurun_out profiles
-T=${1:-r04w}
+T=${1:-r05w}
 export TMPDIR=/tmp
 STEPS=20  # the driver's --steps: the sequences blocks are measured as ONE launch of that many frames, like the bench times them
 for spec in "static 16384 0" "sphere 16384 0" "sequences 4096 $STEPS" "sequences 16384 $STEPS"; do
@@ -36,6 +36,12 @@ for b in throughput latency; do
 done
 timeout -k 10 900 python tools/diag/sequence_hunt.py --first 8000 --count 600 --size 640x480 --builds cluster --json gpurun_out/${T}_hunt_qvga_s8000_n600_cluster.json > gpurun_out/${T}_hunt_qvga_cluster.log 2>&1
 timeout -k 10 600 python tools/diag/sequence_hunt.py --first 7000 --count 300 --size 640x480 --no-seg --json gpurun_out/${T}_hunt_qvga_noseg_s7000_n300.json > gpurun_out/${T}_hunt_qvga_noseg.log 2>&1
+# round 5: sequences of the length BASELINE's configs have (tools/diag/long_sequence_hunt.py: N x 200 QVGA frames against the oracle)
+timeout -k 10 900 python tools/diag/long_sequence_hunt.py --seeds 2000:2128 --variant throughput --out gpurun_out/${T}_long_hunt_throughput_s2000_n128.json > gpurun_out/${T}_long_hunt_throughput.log 2>&1
+timeout -k 10 900 python tools/diag/long_sequence_hunt.py --seeds 2000:2128 --variant latency --out gpurun_out/${T}_long_hunt_latency_s2000_n128.json > gpurun_out/${T}_long_hunt_latency.log 2>&1
+timeout -k 10 900 python tools/diag/long_sequence_hunt.py --seeds 2000:2032 --variant cluster --chunk 8 --out gpurun_out/${T}_long_hunt_cluster_s2000_n32.json > gpurun_out/${T}_long_hunt_cluster.log 2>&1
+SF_HIP_LIB=$PWD/$C/libsf_hip_reforder.so timeout -k 10 900 python tools/diag/long_sequence_hunt.py --seeds 2000:2032 --variant throughput --out gpurun_out/${T}_long_hunt_reforder_s2000_n32.json > gpurun_out/${T}_long_hunt_reforder.log 2>&1
+for f in throughput latency cluster reforder; do grep -h "^episodes\|\"total\"" gpurun_out/${T}_long_hunt_$f.log | cut -c1-400; done
 timeout -k 10 1800 python -m pytest tests -m gpu -q > gpurun_out/${T}_gputest.log 2>&1
 tail -3 gpurun_out/${T}_gputest.log
 for f in qvga_throughput qvga_latency 160x120_throughput 160x120_latency; do tail -n 5 gpurun_out/${T}_hunt_$f.log | cut -c1-200; done

@@ -285,7 +285,7 @@ def test_bench_gpus_n_started_directly(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["world_size"] == 2 and len(d["per_rank"]) == 2 and len(d["devices"]) == 2
     assert abs(d["frames_per_s"] * d["ms_per_step"] * 1e-3 - 2 * 32) < 1e-6 * 64
-    assert len(list(tmp_path.glob("sf_bench_seq_v1_*.npz"))) == 4  # two ranks x two sequences, rendered once and cached
+    assert len(list(tmp_path.glob("sf_seq_*.npz"))) == 4  # two ranks x two sequences, rendered once and cached
 
     import torch
 

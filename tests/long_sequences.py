@@ -141,8 +141,11 @@ def compare(ref, got, thr):
     if "b_img" in ref and "b_img" in got:
         rec["b_img"] = float(np.abs(ref["b_img"] - got["b_img"]).max())
         rec["identical"] = rec["identical"] and bool(np.array_equal(ref["b_img"], got["b_img"]) and np.array_equal(ref["labels"], got["labels"]))
-    if ref["counts"] != got["counts"]:
+    # the IRLS counts PER OUTER ITERATION, not their totals: two ties in one frame can cancel in the sum (seed 3098, frame 95:
+    # 3 + 2 + 3 + 2 + 1 against 3 + 2 + 2 + 2 + 2 iterations, 4.7e-3 m apart -- filed under "no count mismatch" until round 5 looked)
+    if ref["counts"] != got["counts"] or [o[:3] for o in ref["outer"]] != [o[:3] for o in got["outer"]]:
         rec["flip"] = classify_flip(ref["outer"], got["outer"], thr)
+        rec["per_level_counts"] = [[o[2] for o in ref["outer"]], [o[2] for o in got["outer"]]]
     return rec
 
 
@@ -203,7 +206,7 @@ def summarise_stream(recs, bar=POSE_BAR):
     return {
         "frames": len(recs),
         "frames_past_bar": int((dist > bar).sum()), "worst": float(dist.max()), "median": float(np.median(dist)),
-        "count_mismatches": sum(1 for r in recs if r["counts"] != r["counts_ref"]),
+        "count_mismatches": sum(1 for r in recs if "flip" in r),  # per outer iteration (compare()), not only in the totals
         "label_mismatch_frames": sum(1 for r in recs if not r["label_equal"]),
         "decision_mismatch_frames": sum(1 for r in recs if r["decision_px"]),
         "b24_over_1e-5": sum(1 for r in recs if r["b24"] > 1e-5), "b24_over_1e-4": sum(1 for r in recs if r["b24"] > 1e-4),

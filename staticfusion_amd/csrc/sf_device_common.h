@@ -512,6 +512,7 @@ struct SplatWin {
     long long d[WIN_CELLS];
     long long i[WIN_CELLS];  // packed like the global cell
     int vmin, umin;
+    int vmax, umax;  // lazy mode: the last row / column any tap of the tile can reach (the flush walks the touched box, not the window)
     unsigned ovf[SPLAT_MAX_LAZY_TILES / 32];  // lazy mode: tiles with targets outside their window (replayed at the end)
 };
 // Lazy initialisation (one workgroup per stream only): no pass zeroes the accumulator image before the splat. A watermark
@@ -524,6 +525,9 @@ struct SplatWin {
 // right, so the watermark of a column only grows. Targets outside a tile's window (rare: strong local stretch) cannot go
 // straight to the global cells -- their cell may not be initialised yet -- so the tile is flagged and replayed after the
 // last tile. (-DSF_SPLAT_FRESH=0: the round-2 form -- zero the columns a window reaches first, atomics for every cell.)
+#ifndef SF_SPLAT_BOX
+#define SF_SPLAT_BOX 1  // 0: the flush walks the whole window (round 4)
+#endif
 struct SplatMarks {
     unsigned short zrow[SPLAT_LAZY_COLS];
 };
@@ -558,12 +562,12 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
             }
         }
     };
-    int pend_u0 = -1, pend_z = 0;  // the columns the last flush reached and their new watermark (set one trip later: no barrier of its own)
+    int pend_u0 = -1, pend_nu = 0, pend_z = 0;  // the columns the last flush reached and their new watermark (set one trip later: no barrier of its own)
     // lazy: a second walk over the tiles (it >= n_tiles) replays the flagged ones for their out-of-window targets
     for (int it = tile_first; it < (lazy ? 2 * n_tiles : n_tiles); it += tile_step) {  // a cluster's workgroups take every G-th tile
         const bool replay = it >= n_tiles;
         if (SF_SPLAT_FRESH && pend_u0 >= 0) {  // (the flush that read the watermarks ended with a barrier)
-            if (tid < WIN_U && pend_u0 + tid < cols_i && pend_z > (int)marks.zrow[pend_u0 + tid]) marks.zrow[pend_u0 + tid] = (unsigned short)pend_z;
+            if (tid < pend_nu && pend_u0 + tid < cols_i && pend_z > (int)marks.zrow[pend_u0 + tid]) marks.zrow[pend_u0 + tid] = (unsigned short)pend_z;
             pend_u0 = -1;
         }
         const int tile = replay ? it - n_tiles : it;
@@ -596,6 +600,8 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
         if (tid == 0) {
             win.vmin = 0x7fffffff;
             win.umin = 0x7fffffff;
+            win.vmax = -1;
+            win.umax = -1;
         }
         // target pixel (qu, qv) and the centi-pixel offsets (ru, rv) inside it: uwarp = 100 qu + ru (reference FrontEnd.cpp:819-853)
         int qu[SPLAT_PX], ru[SPLAT_PX], qv[SPLAT_PX], rv[SPLAT_PX];
@@ -611,6 +617,7 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
             ok[k] = src.load(v, u, idx, z[k], xr[k], yr[k], iw[k]) && inside;
         }
         int vtop = 0, utop = 0;  // max over the lane's valid pixels of INT_MAX - q (q >= 0): the wave maximum gives the minimum
+        int vbot = 0, ubot = 0;  // ... and of q + 2 (0: no valid pixel): the last row / column a tap can reach, + 1
 #pragma unroll
         for (int k = 0; k < SPLAT_PX; k++) {
             const float x_w = g.T[0] * xr[k] + g.T[1] * yr[k] + g.T[2] * z[k] + g.T[3];
@@ -629,15 +636,28 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
             if (ok[k]) {
                 vtop = max(vtop, 0x7fffffff - qv[k]);
                 utop = max(utop, 0x7fffffff - qu[k]);
+                vbot = max(vbot, qv[k] + 2);
+                ubot = max(ubot, qu[k] + 2);
             }
         }
         SF_DPP_REDUCE(vtop, dpp_i32, sf_op_maxi)
         SF_DPP_REDUCE(utop, dpp_i32, sf_op_maxi)
         const int vmin = 0x7fffffff - __builtin_amdgcn_readlane(vtop, 63), umin = 0x7fffffff - __builtin_amdgcn_readlane(utop, 63);
+        int vlast = 0, ulast = 0;
+        if (SF_SPLAT_BOX && lazy) {  // (uniform)
+            SF_DPP_REDUCE(vbot, dpp_i32, sf_op_maxi)
+            SF_DPP_REDUCE(ubot, dpp_i32, sf_op_maxi)
+            vlast = __builtin_amdgcn_readlane(vbot, 63) - 1;
+            ulast = __builtin_amdgcn_readlane(ubot, 63) - 1;
+        }
         __syncthreads();  // window cleared, origin initialised
         if (lane == 0) {
             lds_min(&win.vmin, vmin);
             lds_min(&win.umin, umin);
+            if (SF_SPLAT_BOX && lazy) {
+                __hip_atomic_fetch_max(&win.vmax, vlast, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(&win.umax, ulast, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
         __syncthreads();
         const int wv0 = uniform_i(win.vmin), wu0 = uniform_i(win.umin);
@@ -710,13 +730,19 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
                 // Groups of 16 lanes take 16 rows that start on a multiple of 16 (a 128-byte line of cells where the level's
                 // rows are a multiple of 16, as at QVGA's level 0): the stores are whole lines, written once. Rows [r0, znew)
                 // of every window column: the window's cells and the padding up to the next multiple of 16 either side.
-                const int vend = min(wv0 + WIN_V, rows_i);
+                // (round 5) only the box the tile's taps can have reached -- a rigid warp moves a 64 x 16 tile into about 66 x 18 cells of
+                // its 70 x 22 window --: what lies beyond it in the window holds zeros that nobody needs to write now (the
+                // watermarks say what is initialised; a later window, or the sweep after the last tile, takes care of the rest)
+                const int vreach = SF_SPLAT_BOX ? min(wv0 + WIN_V, uniform_i(win.vmax) + 1) : wv0 + WIN_V;
+                const int ureach = SF_SPLAT_BOX ? min(WIN_U, uniform_i(win.umax) + 1 - wu0) : WIN_U;
+                const int vend = min(vreach, rows_i);
                 const int znew = min((vend + 15) & ~15, rows_i), r0 = wv0 & ~15;
                 const int ng = (znew - r0 + 15) >> 4;  // groups per column
                 // gi / ng == (gi * mdiv) >> 16 for gi * ng < 65536 (mdiv = floor(65536 / ng) + 1; the quotient is far from an
                 // integer unless ng is a power of two, where the reciprocal is exact)
                 const unsigned mdiv = (unsigned)(65536.f * __builtin_amdgcn_rcpf((float)ng)) + 1u;
-                const int total = ng * min(WIN_U, cols_i - wu0);
+                const int ncols = min(ureach, cols_i - wu0);
+                const int total = ng * ncols;
                 for (int g0 = 0; g0 < total; g0 += SF_NT / 16) {  // (wave-uniform trip count: zero_flagged wants the whole wave)
                     const int gi = g0 + (tid >> 4);
                     const int du = (int)(((unsigned)gi * mdiv) >> 16), gr = gi - du * ng;
@@ -740,6 +766,7 @@ __device__ __forceinline__ void tiled_splat(const SplatGeom &g, int rows_i, int 
                     zero_flagged(live && gr == 0 && (tid & 15) == 0 && z < r0, c, z, r0);
                 }
                 pend_u0 = wu0;
+                pend_nu = ncols;
                 pend_z = znew;
             }
         } else if (!replay)

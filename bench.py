@@ -357,6 +357,7 @@ def run_pairs_workload(hx, args, workload, batch, with_parity):
     #      synchronisation. HIP events recorded on the handle's stream around the same K launches give the average kernel
     #      duration; the device-side counters give the IRLS iterations those K steps executed (read outside the region).
     c0 = solver.counters()
+    clk0 = solver.shader_clock_counters()
     hx.barrier(solver)
     t0 = time.perf_counter()
     region_ms = solver.timed_process_frames(im, args.steps)
@@ -364,6 +365,7 @@ def run_pairs_workload(hx, args, workload, batch, with_parity):
     elapsed = time.perf_counter() - t0
     im += args.steps
     c1 = solver.counters()
+    shader_mhz = solver.shader_clock_mhz(clk0, solver.shader_clock_counters())
     frames_timed, iters_total, pix_total = c1[0] - c0[0], c1[1] - c0[1], c1[3] - c0[3]
     assert frames_timed == B * args.steps, (frames_timed, B, args.steps)
     k_ms = region_ms / args.steps
@@ -415,6 +417,9 @@ def run_pairs_workload(hx, args, workload, batch, with_parity):
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             # the second fraction SURVEY 8(d) asks for: against a plain copy kernel measured on this box right before the timed region
             "copy_gbs": copy_gbs, "frac_of_copy": achieved / copy_gbs,
+            # the shader clock the timed stream-frames ran at (in-kernel: clock64 over the 100 MHz wall clock): the package's
+            # power management restarts low at every launch and climbs for several hundred ms
+            "shader_clock_mhz": shader_mhz,
             # HBM bytes per launch from the PMC counters (measured per frame of every stream, tools/measure_traffic.sh, times the
             # frames of this launch), or null when no measurement of THESE sources exists
             "traffic": traffic["hbm_bytes_per_launch"] * (1 if os.environ.get("SF_TIMED_LAUNCH_PER_FRAME") else args.steps) if traffic else None,
@@ -604,6 +609,7 @@ def run_sequences_workload(hx, args, B, pool):
     solver.synchronize()
     copy_gbs = copy_bandwidth(solver)
     c0 = solver.counters()
+    clk0 = solver.shader_clock_counters()
     hx.barrier(solver)
     t0 = time.perf_counter()
     if args.launch_per_frame:
@@ -617,6 +623,7 @@ def run_sequences_workload(hx, args, B, pool):
     hx.barrier(solver)
     elapsed = time.perf_counter() - t0
     c1 = solver.counters()
+    shader_mhz = solver.shader_clock_mhz(clk0, solver.shader_clock_counters())
     frames_timed, iters_total = c1[0] - c0[0], c1[1] - c0[1]
     assert frames_timed == B * args.steps
     T_after_timed = solver.batch_results()[0].copy()  # pose of the last timed frame of every stream (sequences_parity)
@@ -706,6 +713,9 @@ def run_sequences_workload(hx, args, B, pool):
             "kernel": "sf_frame_kernel (%s build)" % variant[0],
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "copy_gbs": copy_gbs, "frac_of_copy": achieved / copy_gbs,
+            # the shader clock the timed stream-frames ran at (in-kernel: clock64 over the 100 MHz wall clock): the package's
+            # power management restarts low at every launch and climbs for several hundred ms
+            "shader_clock_mhz": shader_mhz,
             "traffic": traffic["hbm_bytes_per_launch"] * (1 if args.launch_per_frame else args.steps) if traffic else None,
             "traffic_provenance": traffic, "traffic_note": why,
             "frames_per_launch": 1 if args.launch_per_frame else args.steps,

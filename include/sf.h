@@ -452,7 +452,10 @@ int SF_FN(get_counters)(sf_handle *h, int64_t *frames, int64_t *n_irls, int64_t 
  * 11 residuals-vs-history 12 segm image + history push 13 total; 14..20 K-means sub-stages
  * (init, centre sort, assignment, stable partition, sequential sums, level-0 labels, connectivity +
  * label pyramid); 21..23 belong to the profiling builds; 24 is a counter, not a timer: warp tiles that were replayed
- * because some of their targets fell outside the tile's accumulation window (one-workgroup builds). */
+ * because some of their targets fell outside the tile's accumulation window (one-workgroup builds); 25 a counter:
+ * levels whose ordered tile splat gave up and took the per-cell lists; 26 the shader clock's cycles over the intervals of
+ * slot 13: 100 * [26] / [13] MHz is the clock the stream-frames ran at (it starts low at every launch and climbs for
+ * several hundred ms: the package's power management, not the library). */
 int SF_FN(get_stage_profile)(sf_handle *h, int64_t ticks[32]);
 /* The IRLS streaming passes in isolation: `reps` executions of pass `which` (1 = weights + normal
  * equations, 2 = residuals + label sums) over the level-0 records of every stream left by the last

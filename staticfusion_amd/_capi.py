@@ -553,6 +553,18 @@ class Solver:
         self.api.check(self.api.get_stage_profile(self.h, t))
         return int(t[25])
 
+    def shader_clock_counters(self):
+        """(shader cycles, 100 MHz ticks) the workgroups have spent inside stream-frames since creation (slots 26 and 13 of
+        the stage profile): the difference of two readings gives the clock the frames in between ran at,
+        100 * cycles / ticks MHz -- what the package's power management granted, measured where the work ran"""
+        t = (C.c_int64 * 32)()
+        self.api.check(self.api.get_stage_profile(self.h, t))
+        return int(t[26]), int(t[13])
+
+    @staticmethod
+    def shader_clock_mhz(before, after):
+        return 100.0 * (after[0] - before[0]) / max(1, after[1] - before[1])
+
     def microbench_pass(self, which, variant, reps):
         ms = C.c_float()
         self.api.check(self.api.microbench_pass(self.h, which, variant, reps, C.byref(ms)))

@@ -32,6 +32,7 @@ enum {
     PF_KM_INIT, PF_KM_SORT, PF_KM_ASSIGN, PF_KM_PARTITION, PF_KM_SUM, PF_KM_LABEL0, PF_KM_CONN_PYR,
     PF_SPLAT_REPLAYS = 24,  // not a timer (a slot of its own: 21..23 are shared by the profiling builds and the isolated-pass kernel): warp tiles replayed for targets outside their window (tiled_splat, lazy mode)
     PF_ORDERED_FALLBACKS = 25,  // not a timer: levels whose ordered tile splat gave up (a tap outside its window) and took the per-cell lists
+    PF_SHADER_CYCLES = 26,  // the shader clock's cycles (clock64) over the same intervals as PF_TOTAL: cycles / ticks x 100 MHz = the clock the stream-frames ran at
     SF_PROF_SLOTS = 32
 };
 

@@ -58,7 +58,7 @@ __device__ __forceinline__ void run_stages(const KArgs &a, int b, int stage_mask
         }                                     \
     } while (0)
 #endif
-    const long long t_begin = wall_clock64();
+    const long long t_begin = wall_clock64(), c_begin = clock64();
     t0 = t_begin;
     if ((stage_mask & (ST_PYR_OLD | ST_PYR_NEW)) == (ST_PYR_OLD | ST_PYR_NEW)) {
         STAGE_TIMED(PF_PYR_NEW, stage_pyramid(a, b, 3, tid, cs));  // both pyramids behind one barrier / rendezvous per level
@@ -93,6 +93,7 @@ __device__ __forceinline__ void run_stages(const KArgs &a, int b, int stage_mask
         t1 = wall_clock64();
         prof[PF_SEGM_HIST] += t1 - t0;
         prof[PF_TOTAL] += t1 - t_begin;
+        prof[PF_SHADER_CYCLES] += clock64() - c_begin;
     }
 }
 

@@ -148,6 +148,18 @@ def test_argument_checks(hip, pair):
     assert np.array_equal(T[0, 1], s.T(1))
 
 
+def test_shader_clock_of_the_stream_frames(hip, pair):
+    """Slot 26 of the stage profile: shader cycles over the intervals of slot 13 (the bench line's `shader_clock_mhz`). A
+    plausible clock, and counters that only move when frames run."""
+    s = make_solver(hip, 60, 80, driver_params(hip), pair(seed=3, rows=60, cols=80, sphere=True), batch=64)
+    c0 = s.shader_clock_counters()
+    assert s.shader_clock_counters() == c0
+    s.process_frames(0, 4)
+    c1 = s.shader_clock_counters()
+    assert c1[0] > c0[0] and c1[1] > c0[1]
+    assert 300.0 < s.shader_clock_mhz(c0, c1) < 3500.0, (c0, c1)
+
+
 def test_pool_arguments_are_checked(hip, pair):
     """a frame number outside the pool or a misaligned pool must be refused on the host, nothing launched."""
     import ctypes

@@ -23,6 +23,23 @@
 #include "sf_cluster.h"
 #include "sf_device_common.h"
 #include "sf_smallmath.h"
+// the linearisation walks register strips in the one-workgroup builds (solve_linearise_strips) and LDS tiles in a cluster,
+// whose workgroups share a level tile by tile (solve_linearise); -DSF_LIN_STRIPS=0: tiles everywhere (A/B)
+#ifndef SF_LIN_STRIPS
+#ifdef SF_CLUSTER
+#define SF_LIN_STRIPS 0
+#else
+#define SF_LIN_STRIPS 1
+#endif
+#endif
+#if SF_REFORDER && SF_RO_BEHIND
+#define LS_RO_BEHIND 1  // validPixels by the reference's rule (:415-427), carried by the label plane
+#else
+#define LS_RO_BEHIND 0
+#endif
+#ifndef LS_ROWS
+#define LS_ROWS 62  // rows a wave owns in a strip (lanes 1 .. LS_ROWS; lane 0 and lane LS_ROWS + 1 hold the halo rows)
+#endif
 #define TILE_V 64
 #define TILE_U (2 * SF_NT / TILE_V)  // two centre pixels per lane
 #define TILE_LV (TILE_V + 2)
@@ -288,12 +305,79 @@ __device__ __noinline__ void solve_warp(const KArgs &a, int b, int L, LDS SolveS
     cluster_rendezvous(cs, tid);  // all atomics of the workgroup(s) performed: the linearisation reads the cells with atomic loads
 }
 
+// The end of a linearisation, whatever walked the pixels: the level's maxima of the raw pre-weights, its valid-pixel count and
+// the two initial |res| sums, from every lane's share to the stream's state (through the cluster's gather when there is one).
+__device__ __forceinline__ void lin_finish(LDS SolveShared &s, LDS ClusterShared &cs, int tid, float min_ec, float min_ed, int n_valid, double abs_c,
+                                           double abs_d) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int G = cl_G(cs);
+    // global max of the raw pre-weights (reference :505-509) and the valid-pixel count
+    // min of non-negative floats through the max of (largest finite pattern - bits)
+    const float max_c = wave_max_f32(__int_as_float(0x7f7fffff - __float_as_int(min_ec)));
+    const float max_d = wave_max_f32(__int_as_float(0x7f7fffff - __float_as_int(min_ed)));
+    n_valid = wave_sum_i32(n_valid);
+    abs_c = wave_sum_f64(abs_c);
+    abs_d = wave_sum_f64(abs_d);
+    if (lane == 0) {
+        s.redf[wave][0] = max_c;
+        s.redf[wave][1] = max_d;
+        s.redi[wave] = n_valid;
+        s.red[wave][0] = abs_c;
+        s.red[wave][1] = abs_d;
+    }
+    __syncthreads();
+    // this workgroup's partial results -> payload words; every workgroup of the cluster then receives all of them and
+    // combines them in rank order (maxima, counts and the fixed-point sums are order free; the two fp64 sums are added in
+    // the same order everywhere). The gather also is the barrier behind which the records may be read by everybody.
+    enum { W_TC = 0, W_TD, W_NV, W_AC, W_AD = W_AC + 2, W_LIN_WORDS = W_AD + 2 };
+    if (tid == 0) {
+        int tc = 0, td = 0, nv = 0;  // transformed minima, see above
+        double ac = 0.0, ad = 0.0;
+        for (int w = 0; w < SF_NW; w++) {
+            tc = max(tc, __float_as_int(s.redf[w][0]));
+            td = max(td, __float_as_int(s.redf[w][1]));
+            nv += s.redi[w];
+            ac += s.red[w][0];
+            ad += s.red[w][1];
+        }
+        cs.in[W_TC] = (unsigned)tc;
+        cs.in[W_TD] = (unsigned)td;
+        cs.in[W_NV] = (unsigned)nv;
+        put_f64(&cs.in[W_AC], ac);
+        put_f64(&cs.in[W_AD], ad);
+    }
+    const int n_words = (int)W_LIN_WORDS;
+    cluster_gather(cs, n_words, tid, true);
+    if (tid == 0) {
+        int tc = 0, td = 0, nv = 0;
+        double ac = 0.0, ad = 0.0;
+        for (int p = 0; p < G; p++) {
+            const LDS unsigned *w = &cs.all[p * n_words];
+            tc = max(tc, (int)w[W_TC]);
+            td = max(td, (int)w[W_TD]);
+            nv += (int)w[W_NV];
+            ac += get_f64(&w[W_AC]);
+            ad += get_f64(&w[W_AD]);
+        }
+        s.init_abs_c = ac;
+        s.init_abs_d = ad;
+        const float mc = sqrtf(1.f / (1.f + __int_as_float(0x7f7fffff - tc)));    // = max over validPixels of the raw weights_c
+        const float md = sqrtf(1.f / (0.01f + __int_as_float(0x7f7fffff - td)));  //   "    weights_d (reference :494-509)
+        s.n_valid = nv;
+        s.inv_max_c = (nv > 0) ? 1.f / mc : 0.f;
+        s.inv_max_d = (nv > 0) ? 1.f / md : 0.f;
+        if (nv == 0) s.status |= SF_STATUS_EMPTY_LEVEL;
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 //  linearise: calculateCoord + calculateDerivatives + computeWeights (raw) + computeSegPrior
 // ---------------------------------------------------------------------------------------------
 // Tile geometry: TILE_V x TILE_U centre pixels (TILE_CPX per lane) + a 1-pixel halo.  The loads of
 // tile t+1 (halo elements + the centre pixels' coordinates / labels) are issued into registers before
 // tile t is evaluated from LDS, so the global-memory latency overlaps the stencil arithmetic.
+#if !SF_LIN_STRIPS
 #define TILE_CPX 2
 #define TILE_EPT ((TILE_N + SF_NT - 1) / SF_NT)  // halo-tile elements per lane
 
@@ -499,67 +583,239 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
         }
     }
 
-    // global max of the raw pre-weights (reference :505-509) and the valid-pixel count
-    // min of non-negative floats through the max of (largest finite pattern - bits)
-    const float max_c = wave_max_f32(__int_as_float(0x7f7fffff - __float_as_int(min_ec)));
-    const float max_d = wave_max_f32(__int_as_float(0x7f7fffff - __float_as_int(min_ed)));
-    n_valid = wave_sum_i32(n_valid);
-    abs_c = wave_sum_f64(abs_c);
-    abs_d = wave_sum_f64(abs_d);
-    if (lane == 0) {
-        s.redf[wave][0] = max_c;
-        s.redf[wave][1] = max_d;
-        s.redi[wave] = n_valid;
-        s.red[wave][0] = abs_c;
-        s.red[wave][1] = abs_d;
-    }
-    __syncthreads();
-    // this workgroup's partial results -> payload words; every workgroup of the cluster then receives all of them and
-    // combines them in rank order (maxima, counts and the fixed-point sums are order free; the two fp64 sums are added in
-    // the same order everywhere). The gather also is the barrier behind which the records may be read by everybody.
-    enum { W_TC = 0, W_TD, W_NV, W_AC, W_AD = W_AC + 2, W_LIN_WORDS = W_AD + 2 };
-    if (tid == 0) {
-        int tc = 0, td = 0, nv = 0;  // transformed minima, see above
-        double ac = 0.0, ad = 0.0;
-        for (int w = 0; w < SF_NW; w++) {
-            tc = max(tc, __float_as_int(s.redf[w][0]));
-            td = max(td, __float_as_int(s.redf[w][1]));
-            nv += s.redi[w];
-            ac += s.red[w][0];
-            ad += s.red[w][1];
-        }
-        cs.in[W_TC] = (unsigned)tc;
-        cs.in[W_TD] = (unsigned)td;
-        cs.in[W_NV] = (unsigned)nv;
-        put_f64(&cs.in[W_AC], ac);
-        put_f64(&cs.in[W_AD], ad);
-    }
-    const int n_words = (int)W_LIN_WORDS;
-    cluster_gather(cs, n_words, tid, true);
-    if (tid == 0) {
-        int tc = 0, td = 0, nv = 0;
-        double ac = 0.0, ad = 0.0;
-        for (int p = 0; p < G; p++) {
-            const LDS unsigned *w = &cs.all[p * n_words];
-            tc = max(tc, (int)w[W_TC]);
-            td = max(td, (int)w[W_TD]);
-            nv += (int)w[W_NV];
-            ac += get_f64(&w[W_AC]);
-            ad += get_f64(&w[W_AD]);
-        }
-        s.init_abs_c = ac;
-        s.init_abs_d = ad;
-        const float mc = sqrtf(1.f / (1.f + __int_as_float(0x7f7fffff - tc)));    // = max over validPixels of the raw weights_c
-        const float md = sqrtf(1.f / (0.01f + __int_as_float(0x7f7fffff - td)));  //   "    weights_d (reference :494-509)
-        s.n_valid = nv;
-        s.inv_max_c = (nv > 0) ? 1.f / mc : 0.f;
-        s.inv_max_d = (nv > 0) ? 1.f / md : 0.f;
-        if (nv == 0) s.status |= SF_STATUS_EMPTY_LEVEL;
-    }
-    __syncthreads();
+    lin_finish(s, cs, tid, min_ec, min_ed, n_valid, abs_c, abs_d);
 }
 
 #undef LIN_PREFETCH
+#endif  // !SF_LIN_STRIPS
+
+// ---------------------------------------------------------------------------------------------
+//  linearise, one-workgroup builds: the same arithmetic on REGISTER STRIPS.
+//  A wave owns LS_ROWS consecutive rows of the (column-major) level -- lane l holds row v0 - 1 + l, lanes 0 and 63 are the
+//  halo rows -- and sweeps the columns: every lane keeps the Inter depth / intensity / Null of the columns u - 1, u, u + 1 in
+//  registers, the upper and lower neighbours of column u come from the adjacent lanes over the DPP network (wave_shr /
+//  wave_shl, as in the pyramid), and the loads of column u + 4 are issued while column u is evaluated. No LDS, no barrier,
+//  every cell is normalised once by the lane that loads it (the tiles normalised 660 halo elements per 512 pixels, staged
+//  seven LDS words each and paid two barriers per tile: 5.6 wave instructions per pixel, of which the stencil is 1.5).
+//  Few rows (the coarse levels) leave waves over: the columns are then cut into as many segments as waves are free.
+//  Bit for bit the records, maxima and counts of the tiled form; the two fp64 sums of the initial |res| add the same terms
+//  in another order.
+// ---------------------------------------------------------------------------------------------
+#if SF_LIN_STRIPS
+// (The first linearisation of a frame and the debug planes' stores are copies of their own: a memory operation the sweep may or
+// may not issue makes every wait for a load a full one -- the compiler counts the operations that are certain to follow it.)
+template <bool DBG, bool FIRST>
+__device__ __noinline__ void solve_linearise_strips(const KArgs &a, int b, int L, LDS SolveShared &s, LDS ClusterShared &cs, int tid) {
+    constexpr bool first = FIRST;
+    const int lane = tid & 63, wave = uniform_i(tid >> 6);  // (scalar: the items, the column range and the sweep's loop control with it)
+    const int rows_i = uniform_i(a.lrows[L]), cols_i = uniform_i(a.lcols[L]), o = uniform_i(a.loff[L]);
+    const size_t sb = (size_t)b * a.n_tot, rb = (size_t)cl_slot(cs) * a.n0;
+    const auto dnew = as_global(pyr_level(a, b, 0, 0, L)), inew = as_global(pyr_level(a, b, 0, 1, L));
+    const auto dpred = as_global(pyr_level(a, b, 1, 0, L)), ipred = as_global(pyr_level(a, b, 1, 1, L));
+    const auto acc_d = as_global((const long long *)a.acc_d + rb), acc_i = as_global((const long long *)a.acc_i + rb);
+    const auto labels = as_global((const uint8_t *)a.labels + sb + o);
+    gptr<float> rec[R_COUNT];
+#pragma unroll
+    for (int q = 0; q < R_COUNT; q++) rec[q] = as_global(a.rec[q] + rb);
+    const auto rec_lab = as_global(a.rec_lab + rb);
+    const bool seg = uniform_i(a.p.segmentation_enabled) != 0;
+    constexpr bool dbg = DBG;
+    const bool ordered = uniform_i(splat_ordered(L, a.ln[L], 1) ? 1 : 0) != 0;  // what solve_warp left in the accumulator cells of this level
+    if (tid == 0) s.first = first ? 1 : 0;
+
+    const float f = float(cols_i) / (2.f * a.tan_half_fovh);
+    const float inv_f_w = 1.f / f;  // the warp's 1/f (reference FrontEnd.cpp:874), not the pyramid's
+    const float disp_u_i = 0.5f * float(cols_i - 1);
+    const float disp_v_i = 0.5f * float(rows_i - 1);
+    const float epsilon_intensity = 1e-6f, epsilon_depth = 0.005f;
+
+    float min_ec = 3.0e38f, min_ed = 3.0e38f;  // max w = w(min e), see solve_linearise
+    double abs_c = 0.0, abs_d = 0.0;
+    int n_valid = 0;
+
+    const int n_strips = (rows_i + LS_ROWS - 1) / LS_ROWS;
+    // as many column segments as it takes for the items to go round the waves evenly: SF_NW / gcd(strips, SF_NW)
+    int g_ = n_strips, h_ = SF_NW;
+    while (h_) {
+        const int t_ = g_ % h_;
+        g_ = h_;
+        h_ = t_;
+    }
+    const int n_seg = min(cols_i, SF_NW / g_);
+    const int seg_w = (cols_i + n_seg - 1) / n_seg;
+    const int n_items = n_strips * n_seg;
+
+    for (int item = wave; item < n_items; item += SF_NW) {  // (wave-uniform)
+        const int strip = item % n_strips, sg = item / n_strips;
+        const int ub = sg * seg_w, ue = min(cols_i, ub + seg_w);
+        if (ub >= ue) continue;
+        const int v = strip * LS_ROWS - 1 + lane;  // this lane's row
+        const bool row_in = v >= 0 && v < rows_i;
+        const bool owner = lane >= 1 && lane <= LS_ROWS && v < rows_i;  // lanes 0 and 63 only lend their row to the neighbours
+        const bool v_inner = owner && v != 0 && v != rows_i - 1;
+
+        // loads in flight (a ring of three columns) and the three committed columns around the one being evaluated
+        float r_dn[3], r_in[3];
+        long long r_ad[3], r_ai[3];
+        int r_lab[3];
+        float wD[3], wI[3], w_dn[3], w_dw[3], w_in[3], w_iw[3];
+        int wN[3];  // bit 0: Null; bits 8..: the pixel's label
+#define LS_LOAD(S, COL)                                                                                             \
+    do {                                                                                                            \
+        const int cc_ = (COL);                                                                                      \
+        const int idx_ = (row_in && cc_ >= 0 && cc_ < cols_i) ? v + cc_ * rows_i : 0;                               \
+        r_dn[S] = gld(dnew, idx_);                                                                                  \
+        r_in[S] = gld(inew, idx_);                                                                                  \
+        if (first) { /* Warped := Pred (reference FrontEnd.cpp:1103-1110): carry the float bits in r_ad */          \
+            const unsigned lo_ = __float_as_uint(gld(dpred, idx_)), hi_ = __float_as_uint(gld(ipred, idx_));        \
+            r_ad[S] = (long long)(((unsigned long long)hi_ << 32) | lo_);                                           \
+            r_ai[S] = 0;                                                                                            \
+        } else {                                                                                                    \
+            r_ad[S] = gld_agent_i64(acc_d, idx_);                                                                   \
+            r_ai[S] = gld_agent_i64(acc_i, idx_);                                                                   \
+        }                                                                                                           \
+        r_lab[S] = (int)gld(labels, idx_); /* (also without segmentation: see above; the plane exists) */            \
+    } while (0)
+#define LS_COMMIT(S, COL)                                                                                           \
+    do { /* branch-free: a loaded register consumed on one side of a divergent branch only costs the waits their precision */ \
+        const int cc_ = (COL);                                                                                      \
+        const bool in_ = row_in && cc_ >= 0 && cc_ < cols_i;                                                        \
+        float dw_, iw_;                                                                                             \
+        if (first) {                                                                                                \
+            dw_ = __uint_as_float((unsigned)((unsigned long long)r_ad[S] & 0xffffffffu));                           \
+            iw_ = __uint_as_float((unsigned)((unsigned long long)r_ad[S] >> 32));                                   \
+        } else { /* normalise the warp accumulators (reference :876-881); touched <=> sum(w) > 0 */                 \
+            if (ordered)                                                                                            \
+                ro_unpack_cell(r_ad[S], dw_, iw_);                                                                  \
+            else                                                                                                    \
+                normalise_acc(r_ad[S], r_ai[S], dw_, iw_);                                                          \
+            const bool touched_ = r_ai[S] != 0;                                                                     \
+            dw_ = touched_ ? dw_ : 0.f;                                                                             \
+            iw_ = touched_ ? iw_ : 0.f;                                                                             \
+        }                                                                                                           \
+        const float dn_ = in_ ? r_dn[S] : 0.f, i_ = in_ ? r_in[S] : 0.f;                                            \
+        dw_ = in_ ? dw_ : 0.f;                                                                                      \
+        iw_ = in_ ? iw_ : 0.f;                                                                                      \
+        const bool nul_ = !(in_ && (dn_ != 0.f) && (dw_ != 0.f));                                                   \
+        int lab_ = r_lab[S]; /* pinned here: hoisted into the loop's latch (as the compiler did: the expression recurs behind */ \
+        asm volatile("" : "+v"(lab_)); /* the loop) it waited there for the youngest load of the sweep */               \
+        wN[S] = (nul_ ? 1 : 0) | (lab_ << 8);                                                                       \
+        wD[S] = nul_ ? 0.f : 0.5f * (dn_ + dw_);                                                                    \
+        wI[S] = 0.5f * (i_ + iw_);                                                                                  \
+        w_dn[S] = dn_;                                                                                              \
+        w_in[S] = i_;                                                                                               \
+        w_dw[S] = dw_;                                                                                              \
+        w_iw[S] = iw_;                                                                                              \
+    } while (0)
+        // column c of the item (counted from ub - 1) lives in slot c % 3 of both rings
+        LS_LOAD(0, ub - 1);
+        LS_LOAD(1, ub);
+        LS_LOAD(2, ub + 1);
+        LS_COMMIT(0, ub - 1);
+        LS_LOAD(0, ub + 2);
+        LS_COMMIT(1, ub);
+        LS_LOAD(1, ub + 3);
+#define LS_COLUMN(U_, J_)                                                                                            \
+    do {                                                                                                            \
+        const int u = (U_);                                                                                         \
+        const int sl = (J_) % 3, sc = ((J_) + 1) % 3, sr = ((J_) + 2) % 3; /* slots of the columns u - 1, u, u + 1 */ \
+        LS_COMMIT(sr, u + 1);                                                                                       \
+        LS_LOAD(sr, u + 4);  /* (unconditionally: a load the sweep may or may not issue would make every wait a full one) */\
+        /* the rows above and below, from the neighbouring lanes: every lane of the wave takes part */              \
+        const float Dc = wD[sc], Ic = wI[sc];                                                                       \
+        const float D_up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Dc), 0x138, 0xf, 0xf, false));  /* wave_shr: row v - 1 */\
+        const float D_dn = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Dc), 0x130, 0xf, 0xf, false));  /* wave_shl: row v + 1 */\
+        const float I_up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Ic), 0x138, 0xf, 0xf, false));\
+        const float I_dn = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Ic), 0x130, 0xf, 0xf, false));\
+        const int N_up = __builtin_amdgcn_update_dpp(1, wN[sc], 0x138, 0xf, 0xf, false);                            \
+        if (owner) {                                                                                                \
+            const int idx = v + u * rows_i;                                                                         \
+            const float dn = w_dn[sc], dw = w_dw[sc];                                                               \
+            const bool nul = (wN[sc] & 1) != 0;                                                                     \
+            const float dct_ = w_in[sc] - w_iw[sc];                                                                 \
+            const float ddt_ = dn - dw;                                                                             \
+            const int lab = seg ? (wN[sc] >> 8) : ((dn != 0.f) ? 0 : SF_NC);                                        \
+            /* validPixels (reference :415-427), with the product's rule for points behind the camera (solve_linearise) */\
+            const bool valid = v_inner && !nul && (LS_RO_BEHIND || dw > 0.f) && (u != 0) && (u != cols_i - 1);      \
+            float dcu_ = 0.f, dcv_ = 0.f, ddu_ = 0.f, ddv_ = 0.f;                                                   \
+            if (valid) {  /* (an inner pixel: all four neighbours are inside the image) */                          \
+                const float D_l = wD[sl], I_l = wI[sl], D_r = wD[sr], I_r = wI[sr];                                 \
+                /* rx / ry weights of this pixel and of its left / upper neighbour (reference :448-462) */          \
+                const float rx_c = fabsf(D_r - Dc) + epsilon_depth;                                                 \
+                const float rxi_c = fabsf(I_r - Ic) + epsilon_intensity;                                            \
+                const float ry_c = fabsf(D_dn - Dc) + epsilon_depth;                                                \
+                const float ryi_c = fabsf(I_dn - Ic) + epsilon_intensity;                                           \
+                const bool nulL = (wN[sl] & 1) != 0, nulU = (N_up & 1) != 0;                                        \
+                const float rx_l = nulL ? 1.f : fabsf(Dc - D_l) + epsilon_depth;                                    \
+                const float rxi_l = nulL ? 1.f : fabsf(Ic - I_l) + epsilon_intensity;                               \
+                const float ry_u = nulU ? 1.f : fabsf(Dc - D_up) + epsilon_depth;                                   \
+                const float ryi_u = nulU ? 1.f : fabsf(Ic - I_up) + epsilon_intensity;                              \
+                dcu_ = (rxi_l * (I_r - Ic) + rxi_c * (Ic - I_l)) / (rxi_c + rxi_l);                                 \
+                ddu_ = (rx_l * (D_r - Dc) + rx_c * (Dc - D_l)) / (rx_c + rx_l);                                     \
+                dcv_ = (ryi_u * (I_dn - Ic) + ryi_c * (Ic - I_up)) / (ryi_c + ryi_u);                               \
+                ddv_ = (ry_u * (D_dn - Dc) + ry_c * (Dc - D_up)) / (ry_c + ry_u);                                   \
+                /* raw pre-weights (reference :487-502): only their global maxima are needed here */                \
+                const float error_l_c = 10.f * (fabsf(dct_) + fabsf(dcu_) + fabsf(dcv_));                           \
+                const float error_l_d = 200.f * (fabsf(ddt_) + fabsf(ddu_) + fabsf(ddv_));                          \
+                min_ec = (error_l_c < min_ec) ? error_l_c : min_ec;                                                 \
+                min_ed = (error_l_d < min_ed) ? error_l_d : min_ed;                                                 \
+                abs_c += (double)(vrsq(1.f + error_l_c) * fabsf(dct_));  /* IRLS-side quantity: 1-ulp rsq like the passes */\
+                abs_d += (double)(vrsq(0.01f + error_l_d) * fabsf(ddt_));                                           \
+                n_valid++;                                                                                          \
+            }                                                                                                       \
+            /* the SIGN carries validPixels (solve_linearise); LS_RO_BEHIND: the label plane does, the sign is the warp's */\
+            gst(rec[R_DW], idx, (LS_RO_BEHIND || valid) ? dw : -fabsf(dw));                                         \
+            gst(rec[R_DCU], idx, dcu_);                                                                             \
+            gst(rec[R_DCV], idx, dcv_);                                                                             \
+            gst(rec[R_DCT], idx, (valid || dbg) ? dct_ : 0.f);  /* 0 outside validPixels: the passes run branch-free over every pixel */\
+            gst(rec[R_DDU], idx, ddu_);                                                                             \
+            gst(rec[R_DDV], idx, ddv_);                                                                             \
+            if (seg || dbg || SF_REFORDER) gst(rec_lab, idx, valid ? (uint8_t)(seg ? lab : 0) : (uint8_t)SF_INVALID_LABEL);\
+            if (dbg) {                                                                                              \
+                float d_i = 0.f, x_i = 0.f, y_i = 0.f, xw = 0.f, yw = 0.f;                                          \
+                const LevelCoord lcd = level_coord(a, L);                                                           \
+                if (first) {  /* xxWarped := xxPrediction (:1107-1108) */                                           \
+                    xw = coord_x(lcd, u, dw);                                                                       \
+                    yw = coord_y(lcd, v, dw);                                                                       \
+                } else if (dw != 0.f) {                                                                             \
+                    xw = (float(u) - disp_u_i) * dw * inv_f_w;                                                      \
+                    yw = (float(v) - disp_v_i) * dw * inv_f_w;                                                      \
+                }                                                                                                   \
+                if (!nul) {                                                                                         \
+                    d_i = Dc;                                                                                       \
+                    x_i = 0.5f * (coord_x(lcd, u, dn) + xw);                                                        \
+                    y_i = 0.5f * (coord_y(lcd, v, dn) + yw);                                                        \
+                }                                                                                                   \
+                a.rec_null[rb + idx] = nul ? 1 : 0;                                                                 \
+                const size_t q = sb + o + idx;                                                                      \
+                a.dbg_warped[0][q] = dw;                                                                            \
+                a.dbg_warped[1][q] = w_iw[sc];                                                                      \
+                a.dbg_warped[2][q] = xw;                                                                            \
+                a.dbg_warped[3][q] = yw;                                                                            \
+                a.dbg_inter[0][q] = d_i;                                                                            \
+                a.dbg_inter[1][q] = Ic;                                                                             \
+                a.dbg_inter[2][q] = x_i;                                                                            \
+                a.dbg_inter[3][q] = y_i;                                                                            \
+            }                                                                                                       \
+        }                                                                                                           \
+    } while (0)
+        // whole triples of columns in a loop without an exit in its body (the waits for the loads in flight stay exact), the
+        // last one or two columns behind it
+        int u0 = ub;
+        for (; u0 + 3 <= ue; u0 += 3) {
+            LS_COLUMN(u0, 0);
+            LS_COLUMN(u0 + 1, 1);
+            LS_COLUMN(u0 + 2, 2);
+        }
+        if (u0 < ue) LS_COLUMN(u0, 0);
+        if (u0 + 1 < ue) LS_COLUMN(u0 + 1, 1);
+#undef LS_COLUMN
+#undef LS_LOAD
+#undef LS_COMMIT
+    }
+    lin_finish(s, cs, tid, min_ec, min_ed, n_valid, abs_c, abs_d);
+}
+#endif  // SF_LIN_STRIPS
 
 // ---------------------------------------------------------------------------------------------
 //  computeSegPrior (reference SegmentationBackground.cpp:53-103): per cluster the pixel count, the count of non-Null
@@ -1462,7 +1718,20 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, LDS SolveShared 
             const bool first = (i == 0) && (k == 0);
             if (!first) solve_warp(a, b, L, s, cs, tid);
             PROF_MARK(s, tid, PF_WARP);
+#if SF_LIN_STRIPS
+            if (uniform_i(a.p.debug_planes)) {
+                if (first)
+                    solve_linearise_strips<true, true>(a, b, L, s, cs, tid);
+                else
+                    solve_linearise_strips<true, false>(a, b, L, s, cs, tid);
+            } else if (first) {
+                solve_linearise_strips<false, true>(a, b, L, s, cs, tid);
+            } else {
+                solve_linearise_strips<false, false>(a, b, L, s, cs, tid);
+            }
+#else
             solve_linearise(a, b, L, first, s, cs, tid);
+#endif
 #if SF_REFORDER
             if (a.p.segmentation_enabled) ro_seg_prior(a, b, L, s, cs, tid);
 #else

@@ -8,8 +8,8 @@
 // Data flow per outer iteration at level L (N_L pixels):
 //   warp        scatter the Pred level into 3 order-independent fixed-point accumulators
 //               (64-bit integer atomics: the result does not depend on the scatter order)
-//   linearise   64x8 tiles + 1-px halo staged in LDS: Inter images, edge-aware gradients, temporal
-//               differences, raw pre-weights  ->  11 float planes + 1 label byte per pixel
+//   linearise   register strips (a wave sweeps the columns of 62 rows; LDS tiles in the cluster build): Inter images,
+//               edge-aware gradients, temporal differences, raw pre-weights  ->  11 float planes + 1 label byte per pixel
 //               ("records", 45 B/px), plus the global max of the pre-weights and the per-label prior
 //   IRLS        <= max_iter_irls iterations of two streaming passes over the records:
 //                 pass 1  rebuild the two Jacobian rows, Cauchy x b weights, accumulate the 21+6

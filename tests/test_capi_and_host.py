@@ -301,3 +301,25 @@ def test_no_vector_instruction_in_front_of_an_exec_restore_at_a_barrier():
     bad = "\ts_cbranch_execz .LBB1_7\n.LBB1_7:\n\tv_mov_b64_e32 v[62:63], v[92:93]\n\ts_barrier\n\ts_or_b64 exec, exec, s[10:11]\n"
     good = "\ts_cbranch_execz .LBB1_7\n.LBB1_7:\n\ts_or_b64 exec, exec, s[10:11]\n\tv_mov_b64_e32 v[62:63], v[92:93]\n\ts_barrier\n"
     assert len(lint.lint_text(bad)) == 1 and lint.lint_text(good) == []
+
+
+def test_the_linearisation_sweep_keeps_its_loads_in_flight():
+    """the register-strip linearisation issues the loads of column u + 4 while it evaluates column u. That only holds
+    while the compiler's wait counter stays exact in the sweep -- no spill, no memory operation that may or may not be issued, no
+    consumer hoisted into the loop's latch: each of them turned every wait into `vmcnt(0)` (and the stage from - 37 % to + 10 %)
+    when the sweep was written. Checked where it shows: the disassembly of the product library (tools/diag/loop_waits.py)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("loop_waits", os.path.join(ROOT, "tools", "diag", "loop_waits.py"))
+    lw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lw)
+    if not os.path.exists(lw.exec_lint.OBJDUMP):
+        pytest.skip("no llvm-objdump in this image")
+    lib = os.path.join(ROOT, "staticfusion_amd", "csrc", "libsf_hip.so")
+    for kern in ("256", "256o5", "1024"):
+        loops = lw.innermost_loops(lib, kern, "solve_linearise_stripsILb0ELb0")
+        sweep = max(loops, key=lambda r: r["valu"])
+        assert sweep["loads"] >= 15 and sweep["dpp"] >= 15 and sweep["lds"] == 0, (kern, sweep)  # three columns per trip
+        assert sweep["scratch"] == 0 and sweep["flat"] == 0, (kern, sweep)
+        assert sweep["waits"] and min(sweep["waits"]) >= 4, (kern, sweep)  # (at least one column's loads stay in flight at every wait)
+

@@ -177,6 +177,25 @@ def test_vga_six_levels(ro, ora, pair):
     assert_state_identical(*solvers)
 
 
+@pytest.mark.parametrize("rows", (64, 124, 128, 188, 248, 252))
+def test_strip_boundaries_of_the_linearisation(ro, ora, pair, rows):
+    """The register-strip linearisation gives a wave 62 rows of a level: image heights whose levels end exactly on a
+    strip (124 = 2 x 62, 248 = 4 x 62, level 1 of 124: one strip), two rows behind one (64, 126, 188), or need a fifth strip
+    (252: the columns are then cut into segments) -- the rows next to a strip edge get their upper / lower neighbours from the
+    halo lanes of ANOTHER wave's strip. Three levels each, full solver, every trace value and the warped planes bit for bit."""
+    cols = 96
+    pr = pair(seed=40 + rows, sphere=True, rows=rows, cols=cols)
+    solvers = []
+    for api in (ro, ora):
+        s = make_solver(api, rows, cols, driver_params(api, ctf_levels=3, debug_planes=1), pr)
+        s.build_pyramid(True)
+        s.run_solver(True)
+        s.build_segm_image()
+        solvers.append(s)
+    assert solvers[0].levels == 3
+    assert_state_identical(*solvers, warped_levels=range(3))
+
+
 def test_fp64_sums_row_by_row(ro, ora):
     """The oracle's [C1] sums (AtA / AtB, sum |res|, ||res||^2) are fp64 sums of float terms, row after row. Summed per lane and
     then over the lanes they differ in the 16th digit -- which moved the float they are converted to in ONE frame of 73 600

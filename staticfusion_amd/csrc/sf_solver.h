@@ -601,10 +601,17 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
 //  Bit for bit the records, maxima and counts of the tiled form; the two fp64 sums of the initial |res| add the same terms
 //  in another order.
 // ---------------------------------------------------------------------------------------------
+// computeSegPrior rides in the sweep (the product builds: its sums are integers, whoever adds them): the pass of its own read
+// 9 bytes per pixel again -- 2.7 % of the full solver's HBM traffic. The reference-order build keeps ro_seg_prior.
+#ifndef SF_LIN_FUSED_PRIOR
+#define SF_LIN_FUSED_PRIOR (SF_LIN_STRIPS && !SF_REFORDER)
+#endif
+__device__ __forceinline__ void seg_prior_begin(LDS SolveShared &s, int tid);
+__device__ __forceinline__ void seg_prior_finish(LDS SolveShared &s, LDS ClusterShared &cs, int tid);
 #if SF_LIN_STRIPS
 // (The first linearisation of a frame and the debug planes' stores are copies of their own: a memory operation the sweep may or
 // may not issue makes every wait for a load a full one -- the compiler counts the operations that are certain to follow it.)
-template <bool DBG, bool FIRST>
+template <bool DBG, bool FIRST, bool SEG>
 __device__ __noinline__ void solve_linearise_strips(const KArgs &a, int b, int L, LDS SolveShared &s, LDS ClusterShared &cs, int tid) {
     constexpr bool first = FIRST;
     const int lane = tid & 63, wave = uniform_i(tid >> 6);  // (scalar: the items, the column range and the sweep's loop control with it)
@@ -618,10 +625,15 @@ __device__ __noinline__ void solve_linearise_strips(const KArgs &a, int b, int L
 #pragma unroll
     for (int q = 0; q < R_COUNT; q++) rec[q] = as_global(a.rec[q] + rb);
     const auto rec_lab = as_global(a.rec_lab + rb);
-    const bool seg = uniform_i(a.p.segmentation_enabled) != 0;
+    constexpr bool seg = SEG;  // (a template parameter like the two others: no label load, no prior sums without segmentation)
     constexpr bool dbg = DBG;
     const bool ordered = uniform_i(splat_ordered(L, a.ln[L], 1) ? 1 : 0) != 0;  // what solve_warp left in the accumulator cells of this level
     if (tid == 0) s.first = first ? 1 : 0;
+    constexpr bool fuse_prior = SF_LIN_FUSED_PRIOR && seg;
+    if (fuse_prior) seg_prior_begin(s, tid);  // (uniform; a barrier)
+    const float kz = uniform_f(a.p.kz);
+    int pr_cur = 0, pr_size = 0, pr_nn = 0, pr_valid = 0;  // running totals for the label of this lane's last pixel (solve_seg_prior)
+    long long pr_sum = 0;
 
     const float f = float(cols_i) / (2.f * a.tan_half_fovh);
     const float inv_f_w = 1.f / f;  // the warp's 1/f (reference FrontEnd.cpp:874), not the pyramid's
@@ -674,7 +686,7 @@ __device__ __noinline__ void solve_linearise_strips(const KArgs &a, int b, int L
             r_ad[S] = gld_agent_i64(acc_d, idx_);                                                                   \
             r_ai[S] = gld_agent_i64(acc_i, idx_);                                                                   \
         }                                                                                                           \
-        r_lab[S] = (int)gld(labels, idx_); /* (also without segmentation: see above; the plane exists) */            \
+        r_lab[S] = seg ? (int)gld(labels, idx_) : 0;                                                                \
     } while (0)
 #define LS_COMMIT(S, COL)                                                                                           \
     do { /* branch-free: a loaded register consumed on one side of a divergent branch only costs the waits their precision */ \
@@ -715,6 +727,17 @@ __device__ __noinline__ void solve_linearise_strips(const KArgs &a, int b, int L
         LS_LOAD(0, ub + 2);
         LS_COMMIT(1, ub);
         LS_LOAD(1, ub + 3);
+#define LS_PRIOR_FLUSH()                                           \
+    do {                                                           \
+        if (pr_size) {                                             \
+            lds_add(&s.prior_size[pr_cur], pr_size);               \
+            if (pr_nn) {                                           \
+                lds_add(&s.prior_nonnull[pr_cur], pr_nn);          \
+                lds_add(&s.prior_sum[pr_cur], pr_sum);             \
+            }                                                      \
+            if (pr_valid) lds_add(&s.valid_cnt[pr_cur], pr_valid); \
+        }                                                          \
+    } while (0)
 #define LS_COLUMN(U_, J_)                                                                                            \
     do {                                                                                                            \
         const int u = (U_);                                                                                         \
@@ -762,6 +785,22 @@ __device__ __noinline__ void solve_linearise_strips(const KArgs &a, int b, int L
                 abs_c += (double)(vrsq(1.f + error_l_c) * fabsf(dct_));  /* IRLS-side quantity: 1-ulp rsq like the passes */\
                 abs_d += (double)(vrsq(0.01f + error_l_d) * fabsf(ddt_));                                           \
                 n_valid++;                                                                                          \
+            }                                                                                                       \
+            if (fuse_prior && (wN[sc] >> 8) != SF_NC) { /* computeSegPrior's sums (solve_seg_prior: the same integers) */\
+                const int pl_ = wN[sc] >> 8;                                                                        \
+                if (pl_ != pr_cur) {                                                                                \
+                    LS_PRIOR_FLUSH();                                                                               \
+                    pr_cur = pl_;                                                                                   \
+                    pr_size = pr_nn = pr_valid = 0;                                                                 \
+                    pr_sum = 0;                                                                                     \
+                }                                                                                                   \
+                pr_size++;                                                                                          \
+                const float dwa_ = fabsf(dw);                                                                       \
+                if (dn != 0.f && dwa_ != 0.f) { /* not Null */                                                      \
+                    pr_nn++;                                                                                        \
+                    pr_sum += to_fix(1.f - kz * fabsf(dn - dwa_), FIX_RES, 1.0e6f);                                 \
+                }                                                                                                   \
+                pr_valid += valid ? 1 : 0;                                                                          \
             }                                                                                                       \
             /* the SIGN carries validPixels (solve_linearise); LS_RO_BEHIND: the label plane does, the sign is the warp's */\
             gst(rec[R_DW], idx, (LS_RO_BEHIND || valid) ? dw : -fabsf(dw));                                         \
@@ -813,6 +852,8 @@ __device__ __noinline__ void solve_linearise_strips(const KArgs &a, int b, int L
 #undef LS_LOAD
 #undef LS_COMMIT
     }
+    if (fuse_prior) LS_PRIOR_FLUSH();  // (the barriers of lin_finish stand between these atomics and seg_prior_finish)
+#undef LS_PRIOR_FLUSH
     lin_finish(s, cs, tid, min_ec, min_ed, n_valid, abs_c, abs_d);
 }
 #endif  // SF_LIN_STRIPS
@@ -826,13 +867,8 @@ __device__ __noinline__ void solve_linearise_strips(const KArgs &a, int b, int L
 //  are integers / Q32.32: exact, order free). The linearisation itself used to aggregate these per tile with wave ballots
 //  and 64-bit DPP sums -- more instructions than the stencil.
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ void solve_seg_prior(const KArgs &a, int b, int L, LDS SolveShared &s, LDS ClusterShared &cs, int tid) {
-    const int n = a.ln[L];
-    const float kz = a.p.kz;
-    const size_t sb = (size_t)b * a.n_tot + a.loff[L], rb = (size_t)cl_slot(cs) * a.n0;
-    const auto dnew = uniform_ptr((gcfloat *)pyr_level(a, b, 0, 0, L));
-    const auto dwp = uniform_ptr((gcfloat *)(a.rec[R_DW] + rb));
-    const auto labp = uniform_ptr((gcu8 *)(a.labels + sb));
+// the bins of computeSegPrior, zeroed (a barrier: nothing may flush into them before)
+__device__ __forceinline__ void seg_prior_begin(LDS SolveShared &s, int tid) {
     if (tid < SF_NC) {
         s.prior_sum[tid] = 0;
         s.prior_size[tid] = 0;
@@ -840,6 +876,57 @@ __device__ __noinline__ void solve_seg_prior(const KArgs &a, int b, int L, LDS S
         s.valid_cnt[tid] = 0;
     }
     __syncthreads();
+}
+
+// ... and what follows their last flush (behind a barrier): the cluster's gather, b_prior and lambda_t_w per label
+__device__ __forceinline__ void seg_prior_finish(LDS SolveShared &s, LDS ClusterShared &cs, int tid) {
+    enum { W_PSUM = 0, W_PSIZE = 2 * SF_NC, W_PNN = W_PSIZE + SF_NC, W_VCNT = W_PNN + SF_NC, W_WORDS = W_VCNT + SF_NC };
+    static_assert(W_WORDS <= SF_SYNC_WORDS, "payload of the prior rendezvous");
+    if (tid < SF_NC) {
+        put_i64(&cs.in[W_PSUM + 2 * tid], s.prior_sum[tid]);
+        cs.in[W_PSIZE + tid] = (unsigned)s.prior_size[tid];
+        cs.in[W_PNN + tid] = (unsigned)s.prior_nonnull[tid];
+        cs.in[W_VCNT + tid] = (unsigned)s.valid_cnt[tid];
+    }
+    cluster_gather(cs, W_WORDS, tid);
+    if (tid < SF_NC) {  // reference SegmentationBackground.cpp:84-102
+        const int l = tid, G = cl_G(cs);
+        long long psum = 0;
+        int psize = 0, pnn = 0, vcnt = 0;
+        for (int p = 0; p < G; p++) {
+            const LDS unsigned *w = &cs.all[p * W_WORDS];
+            psum += get_i64(&w[W_PSUM + 2 * l]);
+            psize += (int)w[W_PSIZE + l];
+            pnn += (int)w[W_PNN + l];
+            vcnt += (int)w[W_VCNT + l];
+        }
+        s.valid_cnt[l] = vcnt;  // num_pix_label of the whole level (the b-solve's 1 / (2 (n + 1)))
+        float bp = 0.f, lt = 0.f;
+        if (psize != 0) {
+            const float ratio = float(pnn) / float(psize);
+            if (ratio < 0.1f) {
+                lt = 0.1f;
+                bp = -1.f;
+            } else {
+                lt = ratio;
+                const float sum = (float)((double)psum * (1.0 / 4294967296.0));
+                bp = std_max(-1.f, std_min(2.f, sum / pnn));
+            }
+        }
+        s.b_prior[l] = bp;
+        s.lambda_t_w[l] = lt;
+    }
+    __syncthreads();
+}
+
+__device__ __noinline__ void solve_seg_prior(const KArgs &a, int b, int L, LDS SolveShared &s, LDS ClusterShared &cs, int tid) {
+    const int n = a.ln[L];
+    const float kz = a.p.kz;
+    const size_t sb = (size_t)b * a.n_tot + a.loff[L], rb = (size_t)cl_slot(cs) * a.n0;
+    const auto dnew = uniform_ptr((gcfloat *)pyr_level(a, b, 0, 0, L));
+    const auto dwp = uniform_ptr((gcfloat *)(a.rec[R_DW] + rb));
+    const auto labp = uniform_ptr((gcu8 *)(a.labels + sb));
+    seg_prior_begin(s, tid);
     int pb, pe;
     cluster_range(cs, n, 2, pb, pe);
     int cur = 0, c_size = 0, c_nn = 0, c_valid = 0;
@@ -880,43 +967,7 @@ __device__ __noinline__ void solve_seg_prior(const KArgs &a, int b, int L, LDS S
     }
     flush();
     __syncthreads();
-    enum { W_PSUM = 0, W_PSIZE = 2 * SF_NC, W_PNN = W_PSIZE + SF_NC, W_VCNT = W_PNN + SF_NC, W_WORDS = W_VCNT + SF_NC };
-    static_assert(W_WORDS <= SF_SYNC_WORDS, "payload of the prior rendezvous");
-    if (tid < SF_NC) {
-        put_i64(&cs.in[W_PSUM + 2 * tid], s.prior_sum[tid]);
-        cs.in[W_PSIZE + tid] = (unsigned)s.prior_size[tid];
-        cs.in[W_PNN + tid] = (unsigned)s.prior_nonnull[tid];
-        cs.in[W_VCNT + tid] = (unsigned)s.valid_cnt[tid];
-    }
-    cluster_gather(cs, W_WORDS, tid);
-    if (tid < SF_NC) {  // reference SegmentationBackground.cpp:84-102
-        const int l = tid, G = cl_G(cs);
-        long long psum = 0;
-        int psize = 0, pnn = 0, vcnt = 0;
-        for (int p = 0; p < G; p++) {
-            const LDS unsigned *w = &cs.all[p * W_WORDS];
-            psum += get_i64(&w[W_PSUM + 2 * l]);
-            psize += (int)w[W_PSIZE + l];
-            pnn += (int)w[W_PNN + l];
-            vcnt += (int)w[W_VCNT + l];
-        }
-        s.valid_cnt[l] = vcnt;  // num_pix_label of the whole level (the b-solve's 1 / (2 (n + 1)))
-        float bp = 0.f, lt = 0.f;
-        if (psize != 0) {
-            const float ratio = float(pnn) / float(psize);
-            if (ratio < 0.1f) {
-                lt = 0.1f;
-                bp = -1.f;
-            } else {
-                lt = ratio;
-                const float sum = (float)((double)psum * (1.0 / 4294967296.0));
-                bp = std_max(-1.f, std_min(2.f, sum / pnn));
-            }
-        }
-        s.b_prior[l] = bp;
-        s.lambda_t_w[l] = lt;
-    }
-    __syncthreads();
+    seg_prior_finish(s, cs, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1719,15 +1770,18 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, LDS SolveShared 
             if (!first) solve_warp(a, b, L, s, cs, tid);
             PROF_MARK(s, tid, PF_WARP);
 #if SF_LIN_STRIPS
-            if (uniform_i(a.p.debug_planes)) {
-                if (first)
-                    solve_linearise_strips<true, true>(a, b, L, s, cs, tid);
-                else
-                    solve_linearise_strips<true, false>(a, b, L, s, cs, tid);
-            } else if (first) {
-                solve_linearise_strips<false, true>(a, b, L, s, cs, tid);
-            } else {
-                solve_linearise_strips<false, false>(a, b, L, s, cs, tid);
+            {
+                const int which = (uniform_i(a.p.debug_planes) ? 4 : 0) | (first ? 2 : 0) | (uniform_i(a.p.segmentation_enabled) ? 1 : 0);
+                switch (which) {  // (uniform)
+                case 0: solve_linearise_strips<false, false, false>(a, b, L, s, cs, tid); break;
+                case 1: solve_linearise_strips<false, false, true>(a, b, L, s, cs, tid); break;
+                case 2: solve_linearise_strips<false, true, false>(a, b, L, s, cs, tid); break;
+                case 3: solve_linearise_strips<false, true, true>(a, b, L, s, cs, tid); break;
+                case 4: solve_linearise_strips<true, false, false>(a, b, L, s, cs, tid); break;
+                case 5: solve_linearise_strips<true, false, true>(a, b, L, s, cs, tid); break;
+                case 6: solve_linearise_strips<true, true, false>(a, b, L, s, cs, tid); break;
+                default: solve_linearise_strips<true, true, true>(a, b, L, s, cs, tid); break;
+                }
             }
 #else
             solve_linearise(a, b, L, first, s, cs, tid);
@@ -1735,7 +1789,11 @@ __device__ __noinline__ void stage_solve(const KArgs &a, int b, LDS SolveShared 
 #if SF_REFORDER
             if (a.p.segmentation_enabled) ro_seg_prior(a, b, L, s, cs, tid);
 #else
+#if SF_LIN_FUSED_PRIOR
+            if (uniform_i(a.p.segmentation_enabled)) seg_prior_finish(s, cs, tid);  // (the sums: solve_linearise_strips)
+#else
             if (a.p.segmentation_enabled) solve_seg_prior(a, b, L, s, cs, tid);
+#endif
 #endif
             PROF_MARK(s, tid, PF_LINEARISE);
             solve_irls(a, b, L, i, k, s, cs, tid);

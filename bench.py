@@ -107,7 +107,7 @@ def make_params(api, workload):
 # right-hand column; measured per stage group in profiles/*traffic_by_stage*): the IRLS passes stream 2 x 29 B records, the
 # linearisation reads ~29 B and writes 25 B instead of materialising A | B, ...
 ALGORITHMIC_B = {"irls": 60, "linearise": 88, "warp": 32, "pyramid": 48, "kmeans": 20, "segm_image": 8, "residuals": 32}
-MOVED_B = {"irls": 58, "linearise": 54, "warp": 25, "pyramid": 40, "kmeans": 6, "segm_image": 5, "residuals": 72}
+MOVED_B = {"irls": 58, "linearise": 50, "warp": 25, "pyramid": 40, "kmeans": 6, "segm_image": 5, "residuals": 72}  # linearise: 25 read (strips: no halo re-reads) + 25 written
 
 
 def algorithmic_bytes(stats_list, levels_n, n_l1, seg, with_residuals, pyramids_per_frame=2.0, per_unit=ALGORITHMIC_B):

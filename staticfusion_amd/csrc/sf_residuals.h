@@ -251,6 +251,15 @@ __device__ __noinline__ void stage_segm_image(const KArgs &a, int b, int tid, LD
     const int G = cl_G(cs), rank = cl_rank(cs);
     const auto labels0 = as_global((const uint8_t *)a.labels + (size_t)b * a.n_tot);
     const auto out = as_global(a.b_img + (size_t)b * a.n0);
+    // The value of a pixel depends on its label only: lane l of every wave works out label l's once (lane SF_NC: "assume static
+    // for invalid cluster"), a pixel then fetches its label's from that lane over the LDS crossbar -- not, as before, b_segm and
+    // cluster_res from the stream's state in global memory behind the load of its label, twice per pixel.
+    const int lane = tid & 63;
+    float mine = 1.f;
+    if (lane < SF_NC) {
+        mine = std_max(0.f, std_min(1.f, st.b_segm[lane]));
+        if ((double)st.cluster_res[lane] < 0.017) mine = std_max(mine, 1.0f - mine);
+    }
     for (int base = tid + rank * SF_NT * SF_LOAD_BATCH; base < n; base += SF_NT * SF_LOAD_BATCH * G) {
         int lab[SF_LOAD_BATCH];
 #pragma unroll
@@ -258,13 +267,9 @@ __device__ __noinline__ void stage_segm_image(const KArgs &a, int b, int tid, LD
 #pragma unroll
         for (int k = 0; k < SF_LOAD_BATCH; k++) {
             const int idx = base + k * SF_NT;
-            if (idx >= n) continue;
-            float bb = 1.f;  // "assume static for invalid cluster"
-            if (lab[k] != SF_NC) {
-                bb = std_max(0.f, std_min(1.f, st.b_segm[lab[k]]));
-                if ((double)st.cluster_res[lab[k]] < 0.017) bb = std_max(bb, 1.0f - bb);
-            }
-            gst(out, idx, bb);
+            // (every lane of the wave takes part in the exchange; labels are 0 .. SF_NC)
+            const float bb = __int_as_float(__builtin_amdgcn_ds_bpermute(lab[k] << 2, __float_as_int(mine)));
+            if (idx < n) gst(out, idx, bb);
         }
     }
 }

@@ -609,8 +609,9 @@ __device__ __noinline__ void solve_linearise(const KArgs &a, int b, int L, bool 
 __device__ __forceinline__ void seg_prior_begin(LDS SolveShared &s, int tid);
 __device__ __forceinline__ void seg_prior_finish(LDS SolveShared &s, LDS ClusterShared &cs, int tid);
 #if SF_LIN_STRIPS
-// (The first linearisation of a frame and the debug planes' stores are copies of their own: a memory operation the sweep may or
-// may not issue makes every wait for a load a full one -- the compiler counts the operations that are certain to follow it.)
+// (The first linearisation of a frame, the debug planes' stores and segmentation -- the label load, the prior's sums -- are
+// template parameters: a memory operation the sweep may or may not issue makes every wait for a load a full one, the compiler
+// counts the operations that are certain to follow it.)
 template <bool DBG, bool FIRST, bool SEG>
 __device__ __noinline__ void solve_linearise_strips(const KArgs &a, int b, int L, LDS SolveShared &s, LDS ClusterShared &cs, int tid) {
     constexpr bool first = FIRST;

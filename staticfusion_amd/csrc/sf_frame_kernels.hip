@@ -196,6 +196,22 @@ __global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__
         const int b = a.order ? __builtin_amdgcn_readfirstlane(a.order[j]) : j;
         int mask = fl.stage_mask;
         if ((mask & ST_AUTO_RESIDUALS) && fl.im_count + k >= SF_HISTORY) mask |= ST_RESIDUALS;
+        if (k == 0) {
+            // A launch starts with every image in the handle's own buffers: materialise_level0 / unflip_stream see to that at
+            // the end of a launch -- unless the launch GAVE UP on the stream (skip below), whose state then still names frames in
+            // the caller's pool of that launch, which may be gone by now. Such a stream goes back to the host's layout here, in
+            // the first frame of whatever is launched next (the launch that gave up cannot do it: the frame it waited for may
+            // still be running); its images are undefined until they are set again, as sf.h says, but nothing dangles.
+            const StreamState &st0 = a.state[b];
+            const unsigned long long stale = __hip_atomic_load((const unsigned long long *)&st0.lvl0[0][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) |
+                                             __hip_atomic_load((const unsigned long long *)&st0.lvl0[1][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (uniform_i(stale != 0)) {
+                __syncthreads();
+                if (tid < 4) ((const float **)a.state[b].lvl0)[tid] = nullptr;
+                if (tid == 4) a.state[b].flip = 0;
+                __syncthreads();
+            }
+        }
         if (fl.frame_done) {
             if (k > 0) {
                 // frame k - 1 of this stream may still be running on another CU (another XCD): poll its counter, then an

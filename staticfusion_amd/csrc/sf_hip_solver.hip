@@ -566,20 +566,32 @@ int sf_microbench_copy(sf_handle *h, size_t bytes, int reps, float *elapsed_ms) 
     }
     int e = SF_OK;
     float ms = 0.f;
+    // events of its own: the handle's ev0 / ev1 belong to the timed_* entry points, evk0 / evk1 to the solver launches
+    // (sf_last_solver_kernel_ms goes on reporting the last of those)
+    hipEvent_t c0 = nullptr, c1 = nullptr;
+    if (hipEventCreate(&c0) != hipSuccess || hipEventCreate(&c1) != hipSuccess) {
+        (void)hipGetLastError();
+        if (c0) (void)hipEventDestroy(c0);
+        (void)hipFree(src);
+        (void)hipFree(dst);
+        return fail(SF_ERR_DEVICE, "sf_microbench_copy: events");
+    }
     const size_t n16 = bytes / 16;
     const int grid = (int)std::min<size_t>((n16 + 255) / 256, (size_t)std::max(1, h->max_blocks / std::max(1, h->wg_per_cu)) * 8);
     auto body = [&]() -> int {
         HIP_TRY(hipMemsetAsync(src, 0x3c, bytes, h->stream));
         hipLaunchKernelGGL(sf_copy_kernel, dim3(grid), dim3(256), 0, h->stream, (const float4 *)src, (float4 *)dst, n16);  // warm-up: page tables, clocks
-        HIP_TRY(hipEventRecord(h->ev0, h->stream));
+        HIP_TRY(hipEventRecord(c0, h->stream));
         for (int r = 0; r < reps; r++) hipLaunchKernelGGL(sf_copy_kernel, dim3(grid), dim3(256), 0, h->stream, (const float4 *)src, (float4 *)dst, n16);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(h->ev1, h->stream));
-        HIP_TRY(hipEventSynchronize(h->ev1));
-        HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        HIP_TRY(hipEventRecord(c1, h->stream));
+        HIP_TRY(hipEventSynchronize(c1));
+        HIP_TRY(hipEventElapsedTime(&ms, c0, c1));
         return SF_OK;
     };
     e = body();
+    (void)hipEventDestroy(c0);
+    (void)hipEventDestroy(c1);
     (void)hipFree(src);
     (void)hipFree(dst);
     if (e) return e;

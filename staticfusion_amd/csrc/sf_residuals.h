@@ -260,14 +260,17 @@ __device__ __noinline__ void stage_segm_image(const KArgs &a, int b, int tid, LD
         mine = std_max(0.f, std_min(1.f, st.b_segm[lane]));
         if ((double)st.cluster_res[lane] < 0.017) mine = std_max(mine, 1.0f - mine);
     }
-    for (int base = tid + rank * SF_NT * SF_LOAD_BATCH; base < n; base += SF_NT * SF_LOAD_BATCH * G) {
+    // The trip count is the WAVE's (bounded on its first lane): ds_bpermute returns 0 for a source lane that EXEC has switched
+    // off, so no lane may leave before the wave's last pixel is served -- a last trip of r pixels with r % 64 in 1 .. SF_NC would
+    // otherwise read 0.0 for every label >= r % 64 (48 x 43, 36 x 116: n0 % 64 = 16).
+    for (int base = tid + rank * SF_NT * SF_LOAD_BATCH; base - lane < n; base += SF_NT * SF_LOAD_BATCH * G) {
         int lab[SF_LOAD_BATCH];
 #pragma unroll
         for (int k = 0; k < SF_LOAD_BATCH; k++) lab[k] = level0_label(a, labels0, min(base + k * SF_NT, n - 1));
 #pragma unroll
         for (int k = 0; k < SF_LOAD_BATCH; k++) {
             const int idx = base + k * SF_NT;
-            // (every lane of the wave takes part in the exchange; labels are 0 .. SF_NC)
+            // (every lane of the wave takes part in the exchange -- see the loop bound; labels are 0 .. SF_NC)
             const float bb = __int_as_float(__builtin_amdgcn_ds_bpermute(lab[k] << 2, __float_as_int(mine)));
             if (idx < n) gst(out, idx, bb);
         }

@@ -196,6 +196,26 @@ def test_strip_boundaries_of_the_linearisation(ro, ora, pair, rows):
     assert_state_identical(*solvers, warped_levels=range(3))
 
 
+@pytest.mark.parametrize("rows,cols,levels", [(48, 43, 3), (36, 116, 2), (20, 52, 2), (44, 45, 2)])
+def test_last_wave_partly_filled(ro, ora, pair, rows, cols, levels):
+    """Pixel counts that are no multiple of the wave size (n0 % 64 = 16 or 60) and odd column counts: the last wave of every
+    per-pixel loop is partly filled, and round 5's cross-lane code (ds_bpermute in stage_segm_image, DPP neighbours in the strip
+    linearisation) depends on which lanes are still there. Every value bit for bit, the segm image included."""
+    pr = pair(seed=5, sphere=True, rows=rows, cols=cols)
+    d_new = pr["new"][0].copy()
+    d_new[-3:, -1] = 0  # label 24 inside the last wave
+    prm = {"new": (d_new, pr["new"][1]), "old": pr["old"]}
+    solvers = []
+    for api in (ro, ora):
+        s = make_solver(api, rows, cols, driver_params(api, kb=1.5, ctf_levels=levels, debug_planes=1), prm)
+        s.build_pyramid(True)
+        s.run_solver(True)
+        s.build_segm_image()
+        solvers.append(s)
+    assert (solvers[0].labels(0) == 24).any()
+    assert_state_identical(*solvers, warped_levels=range(levels))
+
+
 def test_fp64_sums_row_by_row(ro, ora):
     """The oracle's [C1] sums (AtA / AtB, sum |res|, ||res||^2) are fp64 sums of float terms, row after row. Summed per lane and
     then over the lanes they differ in the 16th digit -- which moved the float they are converted to in ONE frame of 73 600

@@ -187,3 +187,61 @@ def test_pool_arguments_are_checked(hip, pair):
     s.advance_sequences_device(base, base, np.array([-1, 1], np.int32), 3)     # a negative entry leaves that stream alone
     s.synchronize()
     hiprt.hipFree(ptr)
+
+
+def test_a_launch_that_gave_up_on_streams_leaves_nothing_dangling(hip, monkeypatch):
+    """a sequence launch that gives up on a stream (SF_STATUS_SYNC_TIMEOUT: the wait for the stream's previous
+    frame ran into its bound -- cannot happen, so the bound is lowered to one poll here) skips materialise_level0 for it: the
+    stream's state keeps naming frames in the caller's pool. The pool is released after the launch, then a frame is launched on
+    the handle BEFORE sf_clear_sync_timeout: the first frame of that launch puts the stream back into the host's layout (nothing
+    reads the pool any more), and after the clear + fresh images the handle computes what a fresh handle computes."""
+    import ctypes
+
+    if hip.default_variant == "cluster":
+        pytest.skip("the cluster build runs such calls frame by frame: no frame waits for another inside a launch")
+    hiprt = ctypes.CDLL("libamdhip64.so")
+    D, F, K, B = 2, 8, 6, 64
+    seqs = [make_sequence(2100 + q, F, sphere=True, out_rows=60, out_cols=80) for q in range(D)]
+    col = lambda a: np.ascontiguousarray(np.asarray(a, np.float32).T).ravel()
+    pd_h = np.stack([col(f[0]) for sq in seqs for f in sq["frames"]])
+    pi_h = np.stack([col(f[1]) for sq in seqs for f in sq["frames"]])
+    ptrs = []
+    for h in (pd_h, pi_h):
+        p = ctypes.c_void_p()
+        assert hiprt.hipMalloc(ctypes.byref(p), ctypes.c_size_t(h.nbytes)) == 0
+        assert hiprt.hipMemcpy(p, h.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(h.nbytes), 1) == 0
+        ptrs.append(p)
+    index = np.stack([(np.arange(B) % D) * F + k for k in range(K + 1)]).astype(np.int32)
+    s = make_solver(hip, 60, 80, driver_params(hip), batch=B)
+    s.advance_sequences_device(ptrs[0].value, ptrs[1].value, index[0], D * F)
+    s.push_history(0)
+    # 64 streams on a chip with room for > 1000 workgroups: frame k of a stream is taken while frame k - 1 still runs
+    monkeypatch.setenv("SF_DEBUG_FRAME_SPIN_LIMIT", "1")
+    T = s.process_sequence_frames_device(ptrs[0].value, ptrs[1].value, index[1:], D * F, 1, trajectory=True)
+    monkeypatch.delenv("SF_DEBUG_FRAME_SPIN_LIMIT")
+    gave_up = [b for b in range(B) if s.stats(b).status & capi.STATUS_SYNC_TIMEOUT]
+    assert gave_up, "no frame gave up: the hook did not act"
+    assert all(np.isnan(T[K - 1, b]).all() for b in gave_up)
+    # the pools go away (poisoned first: whoever still reads them reads NaN, if the allocator keeps the pages mapped)
+    for p, h in zip(ptrs, (pd_h, pi_h)):
+        assert hiprt.hipMemset(p, 0xFF, ctypes.c_size_t(h.nbytes)) == 0
+        assert hiprt.hipFree(p) == 0
+    s.process_frame(K + 1)  # before the clear: must not touch the pool
+    s.synchronize()
+    s.clear_sync_timeout()
+    fresh = make_solver(hip, 60, 80, driver_params(hip), batch=B)
+    for x in (s, fresh):
+        for b in range(B):
+            f0, f1 = seqs[b % D]["frames"][0], seqs[b % D]["frames"][1]
+            x.set_prediction(b, *f0)
+            x.set_current(b, *f1)
+            if x is fresh:  # what runSolver / buildSegmImage carry over from the frames before (FrontEnd.cpp:1134-1144)
+                x.set_twist_old(b, s.twist_old(b))
+                x.set_segm_state(b, cluster_res=s.cluster_residuals(b))
+        x.build_pyramid(True)
+        x.run_solver(True)
+        x.build_segm_image()
+    for b in sorted(set(gave_up[:4] + [0, B - 1])):
+        assert np.array_equal(s.T(b), fresh.T(b)) and np.array_equal(s.b(b), fresh.b(b)), b
+        assert np.array_equal(s.b_image(b), fresh.b_image(b)) and np.array_equal(s.labels(0, b), fresh.labels(0, b)), b
+        assert s.stats(b).status & capi.STATUS_SYNC_TIMEOUT == 0

@@ -112,6 +112,10 @@ int sfo_abi_version(int *sizeof_params, int *sizeof_frame_stats, int *stage_prof
 int sfo_create(const sf_params *p, int rows, int cols, int batch, int device, sf_handle **out) {
     (void)device;
     if (!p || !out || rows < 8 || cols < 8 || batch < 1) return fail(SF_ERR_ARG, "bad argument");
+    // KMeans.cpp:267 starts the full-resolution search at labels_lowres(v/2, u/2): outside the rows/2 x cols/2 matrix for an odd
+    // size (the reference, without bounds checks, reads whatever lies there). Undefined in the reference: refused on both sides.
+    if (p->segmentation_enabled && ((rows | cols) & 1))
+        return fail(SF_ERR_ARG, "segmentation_enabled needs even rows and cols (the reference reads labels_lowres(v/2, u/2) outside its matrix otherwise, KMeans.cpp:267)");
     auto *h = new sf_handle;
     h->rows = rows;
     h->cols = cols;
@@ -156,6 +160,7 @@ int sfo_set_params(sf_handle *h, const sf_params *p) {
     if (!h || !p) return fail(SF_ERR_ARG, "null");
     if (p->ctf_levels > 0 && p->ctf_levels > int(h->s[0]->pyr_levels_alloc))
         return fail(SF_ERR_ARG, "ctf_levels exceeds the allocated pyramid");
+    if (p->segmentation_enabled && ((h->rows | h->cols) & 1)) return fail(SF_ERR_ARG, "segmentation_enabled needs even rows and cols (KMeans.cpp:267)");
     const int keep = h->params.ctf_levels;
     h->params = *p;
     if (p->ctf_levels <= 0) h->params.ctf_levels = keep;

@@ -21,8 +21,10 @@ from staticfusion_amd.synth import make_pair, pose_delta
 pytestmark = pytest.mark.gpu
 
 
-def test_segm_image_residual_threshold_from_both_sides(hip, ora):
-    rows, cols = 60, 80
+@pytest.mark.parametrize("rows,cols,levels", [(60, 80, 0), (40, 42, 3), (20, 52, 2), (20, 44, 2)])
+def test_segm_image_residual_threshold_from_both_sides(hip, ora, rows, cols, levels):
+    """(40 x 42, 20 x 52: n0 % 64 = 16, 20 x 44: 48 -- the last wave of the image is partly filled, and the value of a label comes
+    from the lane of that number: ADVICE round 5)"""
     rng = np.random.RandomState(3)
     labels = rng.randint(0, 25, size=(rows, cols)).astype(np.int32)  # 24 = invalid cluster
     b = rng.uniform(-0.3, 1.3, 24).astype(np.float32)
@@ -34,17 +36,37 @@ def test_segm_image_residual_threshold_from_both_sides(hip, ora):
     res[10:] = rng.uniform(0.0165, 0.0175, 14).astype(np.float32)
     out = []
     for api in (hip, ora):
-        s = make_solver(api, rows, cols, driver_params(api))
+        s = make_solver(api, rows, cols, driver_params(api, ctf_levels=levels))
         s.set_segm_state(0, labels, b, res)
         s.build_segm_image()
         out.append(s.b_image().copy())
     assert np.array_equal(out[0], out[1])
+    assert np.all(out[0][labels == 24] == 1.0)
     # the rule itself, on the clusters that straddle the threshold
     for l, below in ((0, False), (1, True), (2, False), (3, True), (4, False), (7, False), (8, True)):
         px = out[0][labels == l]
         bb = min(max(float(b[l]), 0.0), 1.0)
         want = max(bb, 1.0 - bb) if below else bb
         assert px.size and np.all(px == np.float32(want)), (l, below)
+
+
+def test_odd_image_sizes_are_refused_with_segmentation(hip, ora):
+    """KMeans.cpp:267 starts the full-resolution search of pixel (v, u) at labels_lowres(v/2, u/2), a rows/2 x cols/2 matrix: with an
+    odd size the reference reads past its end, and what it finds there decides labels. Nothing to be identical to: both sides of
+    the ABI refuse (found in round 6 by the oracle's bounds-checked containers at 48 x 43); pure odometry has no such read."""
+    import staticfusion_amd as sf
+    from conftest import config2_params
+
+    for api in (hip, ora):
+        for rows, cols in ((48, 43), (45, 48)):
+            with pytest.raises(sf.SfError, match="even rows and cols"):
+                sf.Solver(api, rows, cols, 1, driver_params(api, ctf_levels=2))
+        s = sf.Solver(api, 48, 43, 1, config2_params(api, levels=2))
+        p = api.default_params_struct()
+        p.ctf_levels = 2
+        with pytest.raises(sf.SfError, match="even rows and cols"):
+            s.set_params(p)
+        s.close()
 
 
 def _near_patch_pair():

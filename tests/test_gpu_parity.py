@@ -441,8 +441,9 @@ def test_many_seeds_small(hip, ora, pair, seed):
     assert np.abs(sg.b() - so.b()).max() < 2e-4
 
 
-# sizes whose level 0 ends in a PARTLY filled wave: n0 % 64 = 16 (fewer active lanes than labels) and an odd column count
-PARTIAL_WAVE_SIZES = [(48, 43, 3), (36, 116, 2), (20, 52, 2), (44, 45, 2)]
+# sizes whose level 0 ends in a PARTLY filled wave: n0 % 64 = 16 (fewer active lanes than labels) or 48; odd rows / columns from
+# level 1 on (level 0 itself must be even with segmentation: KMeans.cpp:267 reads labels_lowres(v/2, u/2))
+PARTIAL_WAVE_SIZES = [(40, 42, 3), (36, 116, 2), (20, 52, 2), (26, 104, 3), (34, 72, 4), (20, 44, 2)]
 
 
 def partial_wave_pair(pair, rows, cols, seed=5):
@@ -456,9 +457,9 @@ def partial_wave_pair(pair, rows, cols, seed=5):
 def test_last_wave_partly_filled(hip, ora, pair, rows, cols, levels):
     """Images whose pixel count is not a multiple of the wave size (sf_create_ex only asks for a multiple of 4 per level): the
     cross-lane code -- ds_bpermute in stage_segm_image, the DPP neighbours of the strip linearisation, the ballots of K-means --
-    meets a last wave with 16 (or 60) active pixels, fewer than there are labels. Round 5's segm image gave such pixels b = 0
+    meets a last wave with 16 (or 48) active pixels, fewer than there are labels. Round 5's segm image gave such pixels b = 0
     when their label was >= the number of active lanes (a lane that has left the loop returns 0 to ds_bpermute)."""
-    assert (rows * cols) % 64 in (16, 60)
+    assert (rows * cols) % 64 in (16, 48)
     pr = partial_wave_pair(pair, rows, cols)
     solvers = []
     for api in (hip, ora):
@@ -513,3 +514,18 @@ def test_last_wave_partly_filled_frame_sequence(hip, ora, pair, rows, cols, leve
         assert np.all(bg[sg.labels(0) == 24] == 1.0), k
         rot, trans = pose_delta(so.T(), sg.T())
         assert rot <= POSE_TOL and trans <= POSE_TOL, k
+
+
+@pytest.mark.parametrize("rows,cols,levels", [(48, 43, 2), (45, 48, 2), (36, 117, 1)])
+def test_odd_image_sizes_pure_odometry(hip, ora, pair, rows, cols, levels):
+    """Odd rows / columns at level 0 exist for the pure odometry of configs[1] only (with segmentation both sides refuse them:
+    KMeans.cpp:267 reads outside its label matrix). 48 x 43: n0 % 64 = 16; 45 x 48: 48; 36 x 117: 52 (one level)."""
+    pr = pair(seed=6, rows=rows, cols=cols)
+    sg, so = solve_both(hip, ora, rows, cols, lambda a: config2_params(a, levels=levels), pr)
+    assert_traces_match(sg, so, tol_twist=5e-6, rtol_aver=2e-3)
+    rot, trans = pose_delta(so.T(), sg.T())
+    assert rot <= POSE_TOL and trans <= POSE_TOL
+    assert np.all(sg.b_image() == 1.0) and np.array_equal(sg.b(), so.b())
+    for L in range(levels):
+        for ch in range(4):
+            assert np.array_equal(sg.plane(capi.SET_NEW, ch, L), so.plane(capi.SET_NEW, ch, L)), (L, ch)

@@ -143,10 +143,11 @@ void SF_FN(ctor_params)(sf_params *p);
 
 /* Replaces StaticFusion::StaticFusion(res_factor) (FrontEnd.cpp:52-181) minus the GUI / map objects.
  * rows x cols is the solver resolution (240 x 320 for res_factor 2). device = HIP ordinal.
- * Sizes: rows, cols >= 8; every pyramid level a multiple of 4 pixels; the coarsest level at least 3 x 3; and, with
- * segmentation_enabled, EVEN rows and cols -- the reference starts the full-resolution K-means search of pixel (v, u) at
- * labels_lowres(v/2, u/2) (KMeans.cpp:267), which lies outside its rows/2 x cols/2 matrix for an odd size: undefined there,
- * SF_ERR_ARG here (sf_set_params likewise when it switches segmentation on). */
+ * Sizes: rows, cols >= 8; every pyramid level a multiple of 4 pixels; the coarsest level at least 3 x 3. K-means needs EVEN
+ * rows and cols: the reference starts the full-resolution search of pixel (v, u) at labels_lowres(v/2, u/2) (KMeans.cpp:267),
+ * outside its rows/2 x cols/2 matrix for an odd size -- undefined there; here sf_kmeans, and with segmentation_enabled
+ * sf_run_solver / sf_process_frame(s), return SF_ERR_ARG on such a handle (pure odometry, the input stage, prediction and
+ * the map take any size). */
 int SF_FN(create)(const sf_params *p, int rows, int cols, int batch, int device, sf_handle **out);
 /* The same with an explicit choice of the frame-kernel build. The reference has one code path;
  * the MI355X library carries several builds of the same algorithm that differ in how many lanes / CUs serve one

@@ -112,10 +112,6 @@ int sfo_abi_version(int *sizeof_params, int *sizeof_frame_stats, int *stage_prof
 int sfo_create(const sf_params *p, int rows, int cols, int batch, int device, sf_handle **out) {
     (void)device;
     if (!p || !out || rows < 8 || cols < 8 || batch < 1) return fail(SF_ERR_ARG, "bad argument");
-    // KMeans.cpp:267 starts the full-resolution search at labels_lowres(v/2, u/2): outside the rows/2 x cols/2 matrix for an odd
-    // size (the reference, without bounds checks, reads whatever lies there). Undefined in the reference: refused on both sides.
-    if (p->segmentation_enabled && ((rows | cols) & 1))
-        return fail(SF_ERR_ARG, "segmentation_enabled needs even rows and cols (the reference reads labels_lowres(v/2, u/2) outside its matrix otherwise, KMeans.cpp:267)");
     auto *h = new sf_handle;
     h->rows = rows;
     h->cols = cols;
@@ -160,7 +156,6 @@ int sfo_set_params(sf_handle *h, const sf_params *p) {
     if (!h || !p) return fail(SF_ERR_ARG, "null");
     if (p->ctf_levels > 0 && p->ctf_levels > int(h->s[0]->pyr_levels_alloc))
         return fail(SF_ERR_ARG, "ctf_levels exceeds the allocated pyramid");
-    if (p->segmentation_enabled && ((h->rows | h->cols) & 1)) return fail(SF_ERR_ARG, "segmentation_enabled needs even rows and cols (KMeans.cpp:267)");
     const int keep = h->params.ctf_levels;
     h->params = *p;
     if (p->ctf_levels <= 0) h->params.ctf_levels = keep;
@@ -310,8 +305,16 @@ int sfo_build_pyramid(sf_handle *h, int old_im) {
     for (auto &s : h->s) s->createImagePyramid(old_im != 0);
     return SF_OK;
 }
+// KMeans.cpp:267 starts the full-resolution search of pixel (v, u) at labels_lowres(v/2, u/2): outside the rows/2 x cols/2 matrix
+// for an odd image size (the reference, without bounds checks, reads whatever lies there and the labels depend on it). Undefined in
+// the reference: every call that runs kMeans3DCoord refuses such a handle, on both sides of the ABI.
+static int kmeans_size_ok(const sf_handle *h) {
+    if ((h->rows | h->cols) & 1) return fail(SF_ERR_ARG, "K-means with segmentation_enabled needs even rows and cols (the reference reads labels_lowres(v/2, u/2) outside its matrix otherwise, KMeans.cpp:267)");
+    return SF_OK;
+}
 int sfo_kmeans(sf_handle *h) {
     if (!h) return fail(SF_ERR_ARG, "null");
+    if (int e = kmeans_size_ok(h)) return e;
     for (auto &s : h->s) {
         s->stats.kmeans_iters = 0;
         s->kMeans3DCoord();
@@ -321,6 +324,8 @@ int sfo_kmeans(sf_handle *h) {
 }
 int sfo_run_solver(sf_handle *h, int create_image_pyr) {
     if (!h) return fail(SF_ERR_ARG, "null");
+    if (h->params.segmentation_enabled)
+        if (int e = kmeans_size_ok(h)) return e;
     auto t0 = std::chrono::steady_clock::now();
     for (auto &s : h->s) {
         s->runSolver(create_image_pyr != 0);
@@ -349,6 +354,8 @@ int sfo_build_segm_image(sf_handle *h) {
 }
 int sfo_process_frame(sf_handle *h, int im_count) {  // StaticFusion-datasets.cpp:171-184
     if (!h || im_count < 0) return fail(SF_ERR_ARG, "bad argument");
+    if (h->params.segmentation_enabled)
+        if (int e = kmeans_size_ok(h)) return e;
     sfo_build_pyramid(h, 1);
     sfo_run_solver(h, 1);
     if (im_count - SF_HISTORY >= 0) sfo_residuals_vs_history(h, im_count);

@@ -100,6 +100,11 @@ bool use_five_per_cu(const sf_handle *h) {
 // One launch of the frame kernel: `n_frames` consecutive frames of every stream (1: the per-call API). ml: the per-launch
 // pointers of a multi-frame launch (frame counters, index table, pools, trajectory), or null.
 int launch(sf_handle *h, int mask, int im_count, int n_frames, const FrameLaunch *ml) {
+    // The labelling at full resolution starts every pixel's search at labels_lowres(v/2, u/2) (KMeans.cpp:267), a matrix of
+    // rows/2 x cols/2 entries: with an odd image size the reference reads past its last row / column, and whatever lies there
+    // decides labels. There is nothing to be identical to: no launch runs K-means on such a handle (pure odometry, the input
+    // stage, prediction and the map have no such read and take any size sf_create accepts).
+    if ((mask & ST_KMEANS) && ((h->k.rows | h->k.cols) & 1)) return fail(SF_ERR_ARG, "K-means with segmentation_enabled needs even rows and cols (the reference reads labels_lowres(v/2, u/2) outside its matrix otherwise, KMeans.cpp:267)");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemsetAsync(h->k.queue, 0, sizeof(int), h->stream));
     if (h->args_dirty) {
@@ -204,15 +209,10 @@ int sf_abi_version(int *sizeof_params, int *sizeof_frame_stats, int *stage_profi
 }
 const char *sf_backend(void) { return (sf_variant_flags_nt256() & 1) ? "hip:gfx950:reference-order" : "hip:gfx950"; }
 
-static int validate_params(const sf_params *p, int levels, int rows, int cols) {
+static int validate_params(const sf_params *p, int levels) {
     // K-means clusters image level 1 (KMeans.cpp:145): a one-level pyramid is only meaningful without segmentation
     if (levels < (p->segmentation_enabled ? 2 : 1) || levels > SF_MAX_LEVELS)
         return fail(SF_ERR_ARG, "ctf_levels must be in [2, 8] (1 is accepted with segmentation_enabled = 0)");
-    // The labelling at full resolution starts every pixel's search at labels_lowres(v/2, u/2) (KMeans.cpp:267), a matrix of
-    // rows/2 x cols/2 entries: with an odd image size the reference reads past its last row / column -- whatever lies there
-    // decides the labels. There is nothing to be identical to: refused (the pure odometry of configs[1] has no such read).
-    if (p->segmentation_enabled && ((rows | cols) & 1))
-        return fail(SF_ERR_ARG, "segmentation_enabled needs even rows and cols (the reference reads labels_lowres(v/2, u/2) outside its matrix otherwise, KMeans.cpp:267)");
     if (p->max_iter_per_level < 1 || p->max_iter_irls < 1 || levels * p->max_iter_per_level > SF_MAX_OUTER)
         return fail(SF_ERR_ARG, "iteration counts out of range");
     return SF_OK;
@@ -275,7 +275,7 @@ int sf_create_ex(const sf_params *p, int rows, int cols, int batch, int device, 
     if (device < 0 || device >= ndev) return fail(SF_ERR_ARG, "device ordinal out of range");
     if (p->ctf_levels <= 0 && cols < 40) return fail(SF_ERR_ARG, "ctf_levels = 0 (log2(cols/40)+2, FrontEnd.cpp:61) needs cols >= 40");
     int levels = p->ctf_levels > 0 ? p->ctf_levels : int(std::log2(double(cols / 40)) + 2);  // FrontEnd.cpp:61
-    if (int e = validate_params(p, levels, rows, cols)) return e;
+    if (int e = validate_params(p, levels)) return e;
     if ((rows >> (levels - 1)) < 3 || (cols >> (levels - 1)) < 3)
         return fail(SF_ERR_ARG, "unsupported ctf_levels for this resolution");
     for (int L = 0; L < levels; L++)
@@ -463,7 +463,7 @@ int sf_set_params(sf_handle *h, const sf_params *p) {
     if (!h || !p) return fail(SF_ERR_ARG, "null");
     int levels = p->ctf_levels > 0 ? p->ctf_levels : h->k.levels;
     if (levels > h->k.levels) return fail(SF_ERR_ARG, "ctf_levels exceeds the allocated pyramid");
-    if (int e = validate_params(p, levels, h->k.rows, h->k.cols)) return e;
+    if (int e = validate_params(p, levels)) return e;
     if (p->debug_planes && !h->k.dbg_warped[0]) return fail(SF_ERR_ARG, "debug_planes must be set at sf_create");
     if (levels != h->k.levels) return fail(SF_ERR_ARG, "ctf_levels cannot change after sf_create");
     const float kb_old = h->k.p.kb;

@@ -50,22 +50,28 @@ def test_segm_image_residual_threshold_from_both_sides(hip, ora, rows, cols, lev
         assert px.size and np.all(px == np.float32(want)), (l, below)
 
 
-def test_odd_image_sizes_are_refused_with_segmentation(hip, ora):
+def test_kmeans_refuses_odd_image_sizes(hip, ora):
     """KMeans.cpp:267 starts the full-resolution search of pixel (v, u) at labels_lowres(v/2, u/2), a rows/2 x cols/2 matrix: with an
-    odd size the reference reads past its end, and what it finds there decides labels. Nothing to be identical to: both sides of
-    the ABI refuse (found in round 6 by the oracle's bounds-checked containers at 48 x 43); pure odometry has no such read."""
+    odd size the reference reads past its end, and what it finds there decides labels. Nothing to be identical to: every call
+    that runs K-means refuses such a handle on both sides of the ABI (found in round 6 by the oracle's bounds-checked containers
+    at 48 x 43); pure odometry, the input stage, prediction and the map have no such read (test_map_fusion runs 117 x 160)."""
     import staticfusion_amd as sf
     from conftest import config2_params
 
     for api in (hip, ora):
         for rows, cols in ((48, 43), (45, 48)):
-            with pytest.raises(sf.SfError, match="even rows and cols"):
-                sf.Solver(api, rows, cols, 1, driver_params(api, ctf_levels=2))
+            s = sf.Solver(api, rows, cols, 1, driver_params(api, ctf_levels=2))
+            s.build_pyramid(True)
+            for call in (s.kmeans, lambda: s.run_solver(True), lambda: s.process_frame(0)):
+                with pytest.raises(sf.SfError, match="even rows and cols"):
+                    call()
+            s.build_segm_image()  # a function of labels and b alone
+            s.close()
         s = sf.Solver(api, 48, 43, 1, config2_params(api, levels=2))
-        p = api.default_params_struct()
-        p.ctf_levels = 2
+        s.build_pyramid(True)
+        s.run_solver(True)
         with pytest.raises(sf.SfError, match="even rows and cols"):
-            s.set_params(p)
+            s.kmeans()
         s.close()
 
 

@@ -518,7 +518,7 @@ def test_last_wave_partly_filled_frame_sequence(hip, ora, pair, rows, cols, leve
 
 @pytest.mark.parametrize("rows,cols,levels", [(48, 43, 2), (45, 48, 2), (36, 117, 1)])
 def test_odd_image_sizes_pure_odometry(hip, ora, pair, rows, cols, levels):
-    """Odd rows / columns at level 0 exist for the pure odometry of configs[1] only (with segmentation both sides refuse them:
+    """Odd rows / columns at level 0 exist for the pure odometry of configs[1] only (K-means refuses them on both sides:
     KMeans.cpp:267 reads outside its label matrix). 48 x 43: n0 % 64 = 16; 45 x 48: 48; 36 x 117: 52 (one level)."""
     pr = pair(seed=6, rows=rows, cols=cols)
     sg, so = solve_both(hip, ora, rows, cols, lambda a: config2_params(a, levels=levels), pr)

@@ -185,20 +185,22 @@ def test_empty_and_degenerate_inputs(ora, pair):
     assert np.all(s.labels(0)[:, :40] == 24) and np.all(s.labels(0)[:, 41:] < 24)
 
 
-def test_odd_sizes_are_refused_with_segmentation(ora):
+def test_kmeans_refuses_odd_image_sizes(ora):
     """KMeans.cpp:267: labels_lowres(v/2, u/2) lies outside the rows/2 x cols/2 label matrix for an odd image size -- the reference
-    reads whatever is there. The oracle's bounds-checked containers threw on it (48 x 43, round 6); both sides of the ABI refuse."""
+    reads whatever is there. The oracle's bounds-checked containers threw on it (48 x 43, round 6); the calls that run K-means
+    refuse such a handle, on both sides of the ABI."""
     import staticfusion_amd as sf
-    from conftest import config2_params
 
     for rows, cols in ((48, 43), (45, 48)):
-        with pytest.raises(sf.SfError, match="even rows and cols"):
-            sf.Solver(ora, rows, cols, 1, driver_params(ora, ctf_levels=2))
+        s = sf.Solver(ora, rows, cols, 1, driver_params(ora, ctf_levels=2))
+        s.build_pyramid(True)
+        for call in (s.kmeans, lambda: s.run_solver(True), lambda: s.process_frame(0)):
+            with pytest.raises(sf.SfError, match="even rows and cols"):
+                call()
     s = sf.Solver(ora, 48, 43, 1, config2_params(ora, levels=2))  # pure odometry has no such read
-    p = ora.default_params_struct()
-    p.ctf_levels = 2
-    with pytest.raises(sf.SfError, match="even rows and cols"):
-        s.set_params(p)
+    s.build_pyramid(True)
+    s.run_solver(True)
+    assert np.isfinite(s.T()).all()
 
 
 def test_frame_sequence_history_and_residuals(ora, pair):

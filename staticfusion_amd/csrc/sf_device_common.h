@@ -68,6 +68,7 @@ struct FrameLaunch {
     float *traj;            // [n_frames][batch][16] T_odometry after every frame, or null
     unsigned spin_limit;    // polls a workgroup waits for the previous frame of its stream
     int flip_ok;            // sequences: swap the roles of the two pyramid buffers instead of copying prediction := current
+    int debug_give_up;      // test support: frame k = debug_give_up of every third stream is given up as if its wait had run out (0: never)
 };
 
 // fixed-point scales of the order-independent accumulations

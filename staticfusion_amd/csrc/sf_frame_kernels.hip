@@ -219,11 +219,12 @@ __global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__
                 if (tid == 0) {
                     unsigned spins = 0;
                     int done, skip = 0;
-                    while ((done = __hip_atomic_load(fl.frame_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < k) {
+                    const bool forced = fl.debug_give_up == k && b % 3 == 0;  // (test support: the path below cannot be provoked otherwise)
+                    while ((done = __hip_atomic_load(fl.frame_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < k || forced) {
                         // cannot happen (see above); never hang the device on a bug -- and never run a frame on a stream whose
                         // previous frame may still be writing: the rest of the stream's frames of this launch are skipped (the
                         // counter goes negative, so later frames see it at once) and every one of them reports the status
-                        if (done < 0 || ++spins > fl.spin_limit) {
+                        if (done < 0 || ++spins > fl.spin_limit || (forced && done >= k)) {
                             __hip_atomic_store(fl.frame_done + b, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             a.stats[b].status |= SF_STATUS_SYNC_TIMEOUT;
                             skip = 1;
@@ -293,7 +294,8 @@ __global__ __launch_bounds__(SF_NT, SF_OCC) void sf_frame_kernel(const KArgs *__
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 int seen = k;  // k -> k + 1, unless a later frame has given up on this stream (-1 stays)
-                __hip_atomic_compare_exchange_strong(fl.frame_done + b, &seen, k + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!__hip_atomic_compare_exchange_strong(fl.frame_done + b, &seen, k + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    a.stats[b].status |= SF_STATUS_SYNC_TIMEOUT;  // ... whose report this frame's own statistics have just overwritten
             }
         }
         // NOTE: the loop body must END with a barrier. With a lane-0-only block here the compiler

@@ -125,8 +125,9 @@ int launch(sf_handle *h, int mask, int im_count, int n_frames, const FrameLaunch
     fl.im_count = im_count;
     fl.n_frames = n_frames;
     fl.spin_limit = 1u << 27;
-    // test support (tests/test_multi_frame.py): a bound so small that waiting frames give up, which nothing else can provoke
-    if (const char *v = std::getenv("SF_DEBUG_FRAME_SPIN_LIMIT")) fl.spin_limit = (unsigned)std::strtoul(v, nullptr, 10);
+    // test support (tests/test_multi_frame.py): frame k of every third stream is given up once its previous frame is done -- the
+    // path of a wait that ran into its bound, which nothing else can provoke
+    if (const char *v = std::getenv("SF_DEBUG_GIVE_UP_AT_FRAME")) fl.debug_give_up = (int)std::strtol(v, nullptr, 10);
     const bool timed = (mask & ST_SOLVE) != 0;
     if (h->k.order && (mask & ST_SOLVE) && !std::getenv("SF_NO_STREAM_ORDER")) {
         // more streams than resident workgroups: hand the streams out longest-expected-first (their previous frame's IRLS

@@ -209,7 +209,8 @@ def measured_traffic(workload, batch, variant, frames_per_launch=None):
         return None, "measured with %d frame(s) per launch, this run has %d (tools/measure_traffic.sh %s %d %s %d)" % (
             t.get("frames_per_launch", 1), frames_per_launch, workload, batch, variant, frames_per_launch)
     return {"hbm_bytes_per_launch": t["hbm_bytes_per_launch"], "src_sha": t["src_sha"], "head": t.get("head"), "batch": t["batch"],
-            "variant": t.get("variant"), "frames_per_launch": t.get("frames_per_launch", 1), "per": t.get("per"), "ratio_to_algorithmic": None}, None
+            "variant": t.get("variant"), "frames_per_launch": t.get("frames_per_launch", 1), "per": t.get("per"), "ratio_to_algorithmic": None,
+            "valu_issue": t.get("valu_issue")}, None
 
 
 def _free_port():

@@ -51,4 +51,37 @@ if "FETCH_SIZE_KB_avg" in out and "WRITE_SIZE_KB_avg" in out:
     t = out["duration_ms_avg_timed"] * 1e-3
     out["hbm_GBps_corrected"] = out["hbm_bytes_per_launch"] / t / 1e9
     out["hbm_GBps_raw"] = out["hbm_bytes_per_launch_raw"] / t / 1e9
+# (round 6) vector-ALU issue: rocprofv3 --pmc with several counters stores one event per (dispatch, counter)
+def load_named(dbpath):
+    db = sqlite3.connect(dbpath)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    tab = lambda key: [t for t in tabs if key in t][0]
+    kd, ks, pe, pi = tab("rocpd_kernel_dispatch"), tab("rocpd_info_kernel_symbol"), tab("rocpd_pmc_event"), tab("rocpd_info_pmc")
+    names = {r[0]: r[1] for r in cur.execute("select id, kernel_name from %s" % ks)}
+    cname = {r[0]: r[1] for r in cur.execute("select id, name from %s" % pi)}
+    disp = list(cur.execute("select id, kernel_id, start, end, event_id from %s order by start" % kd))
+    vals = collections.defaultdict(lambda: collections.defaultdict(float))
+    for ev, pid, val in cur.execute("select event_id, pmc_id, value from %s" % pe):
+        vals[ev][cname.get(pid, str(pid))] += val
+    return names, disp, vals
+
+sq = glob.glob(os.path.join(a.dir, "sq", "*.db"))
+gr = glob.glob(os.path.join(a.dir, "grbm", "*.db"))
+if sq and gr:
+    c = collections.defaultdict(float)
+    for f in (sq[0], gr[0]):
+        names, disp, vals = load_named(f)
+        mine = [d for d in disp if a.kernel in names[d[1]]][-a.last:]
+        for d in mine:
+            for k, v in vals[d[4]].items():
+                c[k] += v / len(mine)
+    out["sq_counters_per_launch"] = dict(c)
+    XCDS, SIMDS = 8, 1024
+    cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / XCDS  # the counter is summed over the XCDs
+    if cyc > 0:
+        out["gpu_active_cycles_per_launch"] = cyc
+        out["valu_busy"] = 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (cyc * SIMDS)
+        out["valu_insts_per_launch"] = c.get("SQ_INSTS_VALU", 0.0)
+        out["valu_quad_cycles_per_inst"] = c.get("SQ_ACTIVE_INST_VALU", 0.0) / max(c.get("SQ_INSTS_VALU", 0.0), 1.0)
 print(json.dumps(out, indent=1))

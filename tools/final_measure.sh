@@ -11,12 +11,12 @@
 set -u
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 mkdir -p gpurun_out profiles
-T=${1:-r05w}
+T=${1:-r06w}
 export TMPDIR=/tmp
 STEPS=20  # the driver's --steps: the sequences blocks are measured as ONE launch of that many frames, like the bench times them
 for spec in "static 16384 0" "sphere 16384 0" "sequences 4096 $STEPS" "sequences 16384 $STEPS"; do
   set -- $spec
-  timeout -k 10 900 bash tools/measure_traffic.sh $1 $2 throughput $3 > gpurun_out/${T}_traffic_$1_b$2.log 2>&1
+  SF_PROF_SQ=1 timeout -k 10 1200 bash tools/measure_traffic.sh $1 $2 throughput $3 > gpurun_out/${T}_traffic_$1_b$2.log 2>&1
 done
 cp gpurun_out/traffic_*_b*.json profiles/ 2>/dev/null; rm -f profiles/traffic_*_summary.json
 timeout -k 10 1200 python bench.py --steps 20 --warmup 5 > gpurun_out/${T}_bench_default.json 2> gpurun_out/${T}_bench_default.err

@@ -26,8 +26,7 @@ out = {"workload": wl, "batch": B, "variant": var, "kernel": s["kernel"], "src_s
        "write_size_bytes": s["WRITE_SIZE_KB_avg"] * 1024.0 / max(K, 1), "kernel_ms_avg": s["duration_ms_avg_timed"] / max(K, 1),
        "valu_issue": ({"busy": s["valu_busy"], "insts": s["valu_insts_per_launch"] / max(K, 1), "quad_cycles_per_inst": s["valu_quad_cycles_per_inst"],
                        "gpu_active_cycles": s["gpu_active_cycles_per_launch"] / max(K, 1),
-                       "note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ... and --pmc GRBM_GUI_ACTIVE in passes of their own; busy = 4 x "
-                               "SQ_ACTIVE_INST_VALU (quad-cycles) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)"} if "valu_busy" in s else None),
+                       "note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ... and --pmc GRBM_GUI_ACTIVE in passes of their own; busy = 2 cycles x SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): a wave64 fp32 / integer-add / compare instruction occupies its SIMD for two cycles on gfx950, integer multiplies, fp64 and packed fp32 for four (tools/micro/valu_rate.hip, int_rate.hip) -- a LOWER bound of the occupancy; + 4 % dummy instructions cost the full solver 0 - 0.5 % (profiles/r06x_ab_dummy_valu.txt). Until round 6 this field assumed four cycles and read twice as much."} if "valu_busy" in s else None),
        "per": "frame of every stream" + (" (one launch of %d frames, divided by %d)" % (K, K) if K else " (one launch per frame)"),
        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/measure_traffic.sh); read bytes doubled per "
                "MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts wide coalesced reads at half size; tools/rocprof_calibrate.sh: raw/expected = 0.500)"}

@@ -81,7 +81,7 @@ if sq and gr:
     cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / XCDS  # the counter is summed over the XCDs
     if cyc > 0:
         out["gpu_active_cycles_per_launch"] = cyc
-        out["valu_busy"] = 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (cyc * SIMDS)
+        out["valu_busy"] = 2.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (cyc * SIMDS)  # two cycles per wave64 instruction on gfx950 (tools/micro/valu_rate.hip; it was 4 until round 6)
         out["valu_insts_per_launch"] = c.get("SQ_INSTS_VALU", 0.0)
         out["valu_quad_cycles_per_inst"] = c.get("SQ_ACTIVE_INST_VALU", 0.0) / max(c.get("SQ_INSTS_VALU", 0.0), 1.0)
 print(json.dumps(out, indent=1))

@@ -9,4 +9,4 @@ for path in sorted(glob.glob(os.path.join(sys.argv[1] if len(sys.argv) > 1 else 
         os.path.basename(os.path.dirname(path)), d, cyc / (d * 1e6), r["SQ_INSTS_VALU"] / B / 1e3, r["SQ_INSTS_SALU"] / B / 1e3, r["SQ_INSTS_LDS"] / B / 1e3,
         r["SQ_INSTS_VMEM_RD"] / B / 1e3, r["SQ_INSTS_VMEM_WR"] / B / 1e3,
         100 * r["SQ_ACTIVE_INST_ANY"] / r["SQ_WAVE_CYCLES"], 100 * r["SQ_WAIT_ANY"] / r["SQ_WAVE_CYCLES"], 100 * r["SQ_WAIT_INST_ANY"] / r["SQ_WAVE_CYCLES"],
-        100 * r["SQ_INSTS_VALU"] * 4 * 8 / (1024 * cyc), 100 * r["SQ_LDS_BANK_CONFLICT"] / max(1, r["SQ_LDS_IDX_ACTIVE"])))
+        100 * r["SQ_INSTS_VALU"] * 2 * 8 / (1024 * cyc)  # two cycles per wave64 instruction (tools/micro/valu_rate.hip), 100 * r["SQ_LDS_BANK_CONFLICT"] / max(1, r["SQ_LDS_IDX_ACTIVE"])))
